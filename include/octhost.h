@@ -1,0 +1,87 @@
+/*
+ * octhost.h -- C ABI of the host runtime around the pipeline: the acquisition ring buffer, a
+ * file/memory backed "virtual OCT system" producer and the processing loop that drains the ring
+ * into octpipe_process().  No Qt; plain threads and atomics.  Part of liboctpipe.so.
+ *
+ * Reference interfaces mirrored (paths relative to /root/reference/octproz_project/):
+ *   AcquisitionBuffer      octproz_devkit/src/acquisitionbuffer.{h,cpp}   (h:43-68, cpp:43-92)
+ *   AcquisitionParams      octproz_devkit/src/acquisitionparameter.h:31-37 (= OctPipeAcquisitionParams)
+ *   AcquisitionSystem      octproz_devkit/src/acquisitionsystem.h:38-75   (start/stopAcquisition, buffer, acqusitionRunning)
+ *   VirtualOCTSystem       octproz_plugins/octproz-virtual-oct-system/src/virtualoctsystem.cpp:59-353
+ *   Processing::slot_start octproz/src/processing.cpp:136-229            (poll ring, process, release slot, rates)
+ */
+#ifndef OCTHOST_H
+#define OCTHOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "octpipe.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- AcquisitionBuffer: N slots of 128-byte aligned host memory + ready flags + currIndex ---- */
+typedef struct octhost_buffer octhost_buffer_t;
+octhost_buffer_t* octhost_buffer_create(void);
+void     octhost_buffer_destroy(octhost_buffer_t* b);
+int      octhost_buffer_allocate(octhost_buffer_t* b, unsigned bufferCnt, size_t bytesPerBuffer); /* allocateMemory, cpp:43-76 */
+void     octhost_buffer_release(octhost_buffer_t* b);                                             /* releaseMemory, cpp:78-92 */
+unsigned octhost_buffer_count(const octhost_buffer_t* b);
+size_t   octhost_buffer_bytes(const octhost_buffer_t* b);
+void*    octhost_buffer_slot(octhost_buffer_t* b, unsigned index);        /* bufferArray[index] */
+int      octhost_buffer_ready(const octhost_buffer_t* b, unsigned index); /* bufferReadyArray[index] */
+void     octhost_buffer_set_ready(octhost_buffer_t* b, unsigned index, int ready);
+int      octhost_buffer_curr_index(const octhost_buffer_t* b);            /* currIndex, -1 before start */
+void     octhost_buffer_set_curr_index(octhost_buffer_t* b, int index);
+
+/* ---- VirtualOCTSystem: simulatorParams of virtualoctsystem.h ---- */
+typedef struct OctHostVirtualParams {
+	const char* filePath;     /* headerless raw file, little endian, sample fastest; NULL with memory source */
+	unsigned bitDepth;
+	unsigned width;           /* samples per A-scan */
+	unsigned height;          /* A-scans per B-scan */
+	unsigned depth;           /* B-scans per buffer */
+	unsigned buffersPerVolume;
+	unsigned buffersFromFile;
+	unsigned bscanOffset;
+	unsigned waitTimeUs;
+	int copyFileToRam;
+	int syncWithProcessing;
+} OctHostVirtualParams;
+
+typedef struct octhost_system octhost_system_t;
+/* file-backed producer (the three feeding modes of virtualoctsystem.cpp:163-353) */
+octhost_system_t* octhost_virtual_system_create(const OctHostVirtualParams* p);
+/* same producer fed from memory (buffersFromFile buffers laid out back to back) instead of a file */
+octhost_system_t* octhost_memory_system_create(const OctHostVirtualParams* p, const void* data, size_t bytes);
+void octhost_system_destroy(octhost_system_t* s);
+int  octhost_system_start(octhost_system_t* s);   /* startAcquisition on its own thread; returns after acquisitionStarted */
+int  octhost_system_stop(octhost_system_t* s);    /* stopAcquisition: acqusitionRunning=false, joins the thread */
+int  octhost_system_running(const octhost_system_t* s);
+octhost_buffer_t* octhost_system_buffer(octhost_system_t* s);
+int  octhost_system_acquisition_params(const octhost_system_t* s, OctPipeAcquisitionParams* out);
+const char* octhost_last_error(void);
+
+/* ---- Processing loop ---- */
+typedef struct OctHostStats {       /* the six numbers of updateInfoBox, processing.cpp:194-204 */
+	uint64_t buffersProcessed;
+	double elapsedSeconds;
+	double volumesPerSecond, buffersPerSecond, bscansPerSecond, ascansPerSecond;
+	double bufferSizeMB, dataThroughputMBs;   /* MB = 2^20 bytes */
+} OctHostStats;
+
+typedef int (*octhost_consume_fn)(void* rawBuffer, unsigned bufferNrInVolume, void* user); /* 0 = ok */
+
+/* Drains the ring until maxBuffers buffers were processed or maxSeconds elapsed (0 = unlimited)
+ * or the system stops: poll currIndex/ready flag, consume, clear the flag (processing.cpp:176-218). */
+int octhost_processing_run(octhost_system_t* s, octhost_consume_fn consume, void* user,
+                           uint64_t maxBuffers, double maxSeconds, OctHostStats* stats);
+/* the same loop with consume = octpipe_process(pipe, buffer) */
+int octhost_processing_run_pipeline(octhost_system_t* s, octpipe_t* pipe, uint64_t maxBuffers, double maxSeconds, OctHostStats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTHOST_H */

@@ -1,0 +1,214 @@
+/*
+ * octpipe.h -- C ABI of the MI355X-native OCT processing pipeline (liboctpipe.so).
+ *
+ * This is the drop-in boundary for ONE path of spectralcode/OCTproZ: the per-A-scan GPU
+ * processing chain that the reference implements in
+ *     octproz_project/octproz/src/cuda_code.cu           ("cu:")
+ * and exposes through the `extern "C"` block of
+ *     octproz_project/octproz/src/kernels.h:63-84        ("kernels.h:")
+ * to its single caller octproz_project/octproz/src/processing.cpp ("processing.cpp:").
+ *
+ * The reference passes a Qt-bearing C++ object (OctAlgorithmParameters*, QString members) across
+ * that boundary and keeps all state in module globals (cu:39-105), so it is not a C ABI.  Here the
+ * same entry points take a POD mirror of the fields the pipeline actually reads and a handle.
+ * Every function below names the reference interface it replaces; INTEGRATION.md shows the
+ * ~80-line adapter that re-exports the 15 legacy names on top of these for the Qt host.
+ *
+ * Conventions: plain pointers and sizes only; every call returns an int status (OCTPIPE_OK = 0)
+ * instead of the reference's printf / exit(EXIT_FAILURE) (helper_cuda.h:583-590);
+ * octpipe_last_error() gives the text.  Not re-entrant per handle (the reference is not either:
+ * all entry points are called from the single processing thread, processing.cpp:136-229).
+ */
+#ifndef OCTPIPE_H
+#define OCTPIPE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCTPIPE_ABI_VERSION 1
+
+enum {
+	OCTPIPE_OK = 0,
+	OCTPIPE_ERR_INVALID_ARGUMENT = 1,
+	OCTPIPE_ERR_NOT_INITIALIZED = 2,   /* reference: "Cuda: Device buffers are not initialized!" cu:1391-1394 */
+	OCTPIPE_ERR_OUT_OF_MEMORY = 3,     /* reference: initializeCuda returns false, cu:975-1015 */
+	OCTPIPE_ERR_DEVICE = 4,            /* any HIP runtime error (reference: checkCudaErrors -> exit) */
+	OCTPIPE_ERR_UNSUPPORTED = 5,       /* e.g. samplesPerLine that the fused FFT does not cover */
+	OCTPIPE_ERR_NO_DEVICE = 6          /* no HIP device: the product path never falls back to a CPU */
+};
+
+/* OctAlgorithmParameters::INTERPOLATION, octalgorithmparameters.h:55-59 */
+enum { OCTPIPE_INTERP_LINEAR = 0, OCTPIPE_INTERP_CUBIC = 1, OCTPIPE_INTERP_LANCZOS = 2 };
+/* WindowFunction::WindowType, windowfunction.h:41-48 */
+enum { OCTPIPE_WINDOW_HANNING = 0, OCTPIPE_WINDOW_GAUSS = 1, OCTPIPE_WINDOW_SINE = 2,
+       OCTPIPE_WINDOW_LANCZOS = 3, OCTPIPE_WINDOW_RECTANGULAR = 4, OCTPIPE_WINDOW_FLATTOP = 5 };
+/* OctAlgorithmParameters::DISPLAY_FUNCTION, octalgorithmparameters.h:166-169 */
+enum { OCTPIPE_DISPLAY_AVERAGING = 0, OCTPIPE_DISPLAY_MIP = 1 };
+
+/* AcquisitionParams, octproz_devkit/src/acquisitionparameter.h:31-37 (same field order). */
+typedef struct OctPipeAcquisitionParams {
+	uint32_t samplesPerLine;    /* N: raw samples per A-scan */
+	uint32_t ascansPerBscan;    /* A */
+	uint32_t bscansPerBuffer;   /* B */
+	uint32_t buffersPerVolume;
+	uint32_t bitDepth;          /* bytes per sample = ceil(bitDepth/8), cu:1077 */
+} OctPipeAcquisitionParams;
+
+/* POD mirror of the OctAlgorithmParameters fields read by octCudaPipeline (cu:1389-1605);
+ * defaults = octalgorithmparameters.cpp:36-112 (octpipe_default_params).  Flags are int32
+ * (0/1).  The three "one-shot" flags are consumed (cleared) inside octpipe_process exactly where
+ * the reference clears them, the caller's struct is never written. */
+typedef struct OctPipeParams {
+	int32_t bitshift;                                  /* cu:1409 */
+	int32_t bscanFlip;                                 /* cu:1546 */
+	int32_t signalLogScaling;                          /* cu:1538 */
+	int32_t sinusoidalScanCorrection;                  /* cu:1551 */
+	float   signalGrayscaleMin;
+	float   signalGrayscaleMax;
+	float   signalMultiplicator;
+	float   signalAddend;
+	int32_t backgroundRemoval;                         /* rolling-average DC removal, cu:1423 */
+	int32_t rollingAverageWindowSize;
+	int32_t resampling;                                /* cu:1448-1511 */
+	int32_t resamplingInterpolation;                   /* OCTPIPE_INTERP_* */
+	int32_t dispersionCompensation;
+	int32_t windowing;
+	int32_t fixedPatternNoiseRemoval;                  /* cu:1518 */
+	int32_t continuousFixedPatternNoiseDetermination;
+	int32_t redetermineFixedPatternNoise;              /* one-shot, cu:1524 */
+	uint32_t bscansForNoiseDetermination;
+	int32_t postProcessBackgroundRemoval;              /* cu:1557 */
+	int32_t postProcessBackgroundRecordingRequested;   /* one-shot, cu:1561 */
+	float   postProcessBackgroundWeight;
+	float   postProcessBackgroundOffset;
+	/* result delivery (cu:1595-1604) */
+	int32_t streamToHost;                              /* quantised u8/u16/u32 D2H + callback */
+	uint32_t streamingBuffersToSkip;
+	int32_t streamFloatToHost;                         /* recParams.saveAs32bitFloat leg, cu:1596 */
+	/* display-frame extraction (cu:1571-1582); plain device buffers instead of GL interop */
+	int32_t bscanViewEnabled;
+	int32_t enFaceViewEnabled;
+	uint32_t frameNr;
+	uint32_t functionFramesBscan;
+	int32_t displayFunctionBscan;
+	uint32_t frameNrEnFaceView;
+	uint32_t functionFramesEnFaceView;
+	int32_t displayFunctionEnFaceView;
+} OctPipeParams;
+
+typedef struct octpipe octpipe_t; /* all state the reference keeps in cu:39-105 */
+
+/* Gpu2HostNotifier callbacks (gpu2hostnotifier.h:47-52, .cpp:45-53,75-86): the 7 arguments of
+ * newGpuDataAvailable / newGpuFloatDataAvailable, plus a user pointer.  Fired from the HIP
+ * runtime's callback thread (hipLaunchHostFunc), like cudaLaunchHostFunc cu:1369,1385. */
+typedef void (*octpipe_data_callback)(void* buffer, unsigned bitDepth, unsigned samplesPerLine,
+                                      unsigned linesPerFrame, unsigned framesPerBuffer,
+                                      unsigned buffersPerVolume, unsigned currentBufferNr, void* user);
+typedef void (*octpipe_event_callback)(void* user); /* backgroundRecorded, gpu2hostnotifier.cpp:57 */
+
+/* ------------------------------------------------------------------ library */
+int         octpipe_abi_version(void);
+const char* octpipe_last_error(void);             /* thread-local text of the last failure */
+int         octpipe_device_count(int* count);     /* OCTPIPE_ERR_NO_DEVICE when none */
+void        octpipe_default_params(OctPipeParams* p); /* octalgorithmparameters.cpp:36-112 */
+
+/* ------------------------------------------------------------------ host curve generators
+ * (OctAlgorithmParameters::update*Curve + Polynomial + WindowFunction; bit-exact contract) */
+int octpipe_polynomial_curve(const float* coeffs, unsigned order, unsigned size, float* out);            /* polynomial.cpp:108-145 */
+int octpipe_resample_curve(float c0, float c1, float c2, float c3, unsigned size, float* out);            /* octalgorithmparameters.cpp:141-168 */
+int octpipe_custom_resample_curve(const float* curve, unsigned curveLength, unsigned size, float* out);   /* :153-159,167 + resizeCurve :263 */
+int octpipe_dispersion_curve(float d0, float d1, float d2, float d3, unsigned size, float* out);          /* :206-222 */
+int octpipe_window_curve(int windowType, float center, float fillFactor, unsigned size, float* out);      /* :234-249, windowfunction.cpp */
+
+/* ------------------------------------------------------------------ lifecycle */
+/* initializeCuda(h_buffer1, h_buffer2, params), kernels.h:63 / cu:1067-1162.  h_buffer1/2 are the
+ * two acquisition ring slots (may be NULL for device-resident use); they are pinned
+ * (hipHostRegister) here and unpinned in octpipe_destroy, ownership stays with the caller. */
+int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq,
+                   const OctPipeParams* params, void* h_buffer1, void* h_buffer2);
+/* cleanupCuda + releaseBuffers + destroyStreamsAndEvents, kernels.h:65-67 / cu:1164-1212 */
+int octpipe_destroy(octpipe_t* h);
+/* parameter snapshot taken per call in the reference (params-> reads in cu:1409-1604) */
+int octpipe_set_params(octpipe_t* h, const OctPipeParams* params);
+int octpipe_get_acquisition_params(const octpipe_t* h, OctPipeAcquisitionParams* out);
+
+/* cuda_updateResampleCurve cu:969, cuda_updateDispersionCurve cu:636 (+ fillDispersivePhase
+ * cu:624, call cu:1439), cuda_updateWindowCurve cu:641, cuda_updatePostProcessBackground cu:646,
+ * cuda_copyPostProcessBackgroundToHost cu:652.  Device LUTs are zero until first update (cu:1082-1085). */
+int octpipe_update_resample_curve(octpipe_t* h, const float* curve, int size);
+int octpipe_update_dispersion_curve(octpipe_t* h, const float* curve, int size);
+int octpipe_update_window_curve(octpipe_t* h, const float* curve, int size);
+int octpipe_update_postprocess_background(octpipe_t* h, const float* background, int size);
+int octpipe_copy_postprocess_background_to_host(octpipe_t* h, float* background, int size);
+
+/* Calibration blob for multi-GPU: everything a second GPU needs to produce the same output
+ * (curves, phasor LUT, mean A-line, post-process background, FPN state).  The host side moves it
+ * between ranks (RCCL broadcast); there is no reference counterpart (single GPU, README.md:27). */
+size_t octpipe_calibration_size(const octpipe_t* h);
+int    octpipe_export_calibration(octpipe_t* h, void* blob, size_t size);
+int    octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size);
+
+/* ------------------------------------------------------------------ processing */
+/* octCudaPipeline(h_inputSignal), kernels.h:64 / cu:1389-1605.  Returns once the H2D copy of the
+ * raw buffer has completed (the reference's event wait cu:1418-1419), so the caller may hand the
+ * ring slot back (processing.cpp:191); the rest of the chain is merely enqueued. */
+int octpipe_process(octpipe_t* h, const void* h_inputSignal);
+/* Same chain with the raw buffer already resident in HBM (d_raw: device pointer, S*bytesPerSample
+ * bytes).  No reference counterpart: it is what the roofline measurement times. */
+int octpipe_process_device(octpipe_t* h, const void* d_raw);
+int octpipe_synchronize(octpipe_t* h);
+
+/* Device pointer to the processed volume (d_processedBuffer, cu:1118: float32
+ * [buffersPerVolume][B][A][N/2]) and the index of the slot the last call wrote (cu:1535). */
+int octpipe_get_processed_device(octpipe_t* h, void** d_processed, size_t* bytes, unsigned* bufferNumberInVolume);
+int octpipe_copy_processed_to_host(octpipe_t* h, float* dst, size_t count, size_t offset);
+/* the HIP stream all work of this handle is enqueued on (as void*), and a way to replace it */
+int octpipe_get_stream(octpipe_t* h, void** stream);
+int octpipe_set_stream(octpipe_t* h, void* stream);
+
+/* test / calibration hooks (no reference counterpart; used to pin the ill-conditioned FPN stage) */
+int octpipe_get_mean_line(octpipe_t* h, float* meanLineComplex /* 2*N floats */);
+int octpipe_set_mean_line(octpipe_t* h, const float* meanLineComplex /* 2*N floats */, int pin);
+/* run only getMinimumVarianceMean (cu:523-565) on a caller-supplied complex buffer [height][width] */
+int octpipe_min_variance_mean(octpipe_t* h, const float* d_or_h_complex, int isDevice, int width, int height, float* meanOutComplex);
+/* complex spectrum after IDFT of the first `lines` A-scans of the last processed raw buffer */
+int octpipe_debug_spectrum(octpipe_t* h, const void* d_raw, int lines, float* hostComplexOut);
+
+/* ------------------------------------------------------------------ result delivery
+ * cuda_registerStreamingBuffers / cuda_unregisterStreamingBuffers (kernels.h:69-70, cu:659-675)
+ * and the float variants (kernels.h:71-72, cu:677-695): two host buffers, filled alternately
+ * starting with the second (cu:1360-1361), each completion announced through the callback. */
+int octpipe_register_streaming_buffers(octpipe_t* h, void* h_buf1, void* h_buf2, size_t bytesPerBuffer);
+int octpipe_unregister_streaming_buffers(octpipe_t* h);
+int octpipe_register_float_streaming_buffers(octpipe_t* h, void* h_buf1, void* h_buf2, size_t bytesPerBuffer);
+int octpipe_unregister_float_streaming_buffers(octpipe_t* h);
+int octpipe_set_callbacks(octpipe_t* h, octpipe_data_callback onStreamingData,
+                          octpipe_data_callback onFloatStreamingData,
+                          octpipe_event_callback onBackgroundRecorded, void* user);
+
+/* ------------------------------------------------------------------ display frames
+ * changeDisplayedBscanFrame / changeDisplayedEnFaceFrame (kernels.h:81-82, cu:1223-1265) write
+ * into plain device buffers owned by the handle (A*N/2 resp. A*B*buffersPerVolume floats);
+ * cuda_registerGlBuffer{Bscan,EnFaceView,VolumeView} (kernels.h:73-75) have no meaning on a
+ * headless MI355X node and always report failure. */
+int octpipe_change_displayed_bscan_frame(octpipe_t* h, unsigned frameNr, unsigned displayFunctionFrames, int displayFunction);
+int octpipe_change_displayed_enface_frame(octpipe_t* h, unsigned frameNr, unsigned displayFunctionFrames, int displayFunction);
+int octpipe_get_display_buffers(octpipe_t* h, void** d_bscanFrame, size_t* bscanCount, void** d_enFaceFrame, size_t* enFaceCount);
+int octpipe_register_gl_buffer_bscan(unsigned buf);       /* always OCTPIPE_ERR_UNSUPPORTED */
+int octpipe_register_gl_buffer_enface_view(unsigned buf); /* always OCTPIPE_ERR_UNSUPPORTED */
+int octpipe_register_gl_buffer_volume_view(unsigned buf); /* always OCTPIPE_ERR_UNSUPPORTED */
+
+/* ------------------------------------------------------------------ measurement helper
+ * Average duration in ms of the dominant (fused) kernel since the last reset, measured with HIP
+ * events recorded on the handle's own stream around each launch when timing is enabled. */
+int octpipe_enable_kernel_timing(octpipe_t* h, int enable);
+int octpipe_kernel_timing(octpipe_t* h, double* avgMs, unsigned* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTPIPE_H */

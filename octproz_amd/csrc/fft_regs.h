@@ -1,0 +1,133 @@
+// fft_regs.h -- in-register small DFTs for the fused A-scan kernel (gfx950, wave64).
+//
+// Unnormalised INVERSE transforms, X[u] = sum_t v[t] * exp(+2*pi*i*t*u/R), matching
+// cufftExecC2C(..., CUFFT_INVERSE) of the reference (cuda_code.cu:1514-1515).
+// Everything is fully unrolled on compile-time indices so the arrays live in VGPRs
+// (runtime-indexed arrays would go to scratch).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define OCT_DEV __device__ __forceinline__
+
+namespace octfft {
+
+// exp(+2*pi*i*m/16), m = 0..15
+__device__ constexpr float kCos16[16] = {
+	1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+	0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
+	-1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f,
+	0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+__device__ constexpr float kSin16[16] = {
+	0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+	1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+	0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
+	-1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+
+OCT_DEV f2 cmul(f2 a, f2 w) { return f2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+OCT_DEV f2 mul_i(f2 a) { return f2{-a.y, a.x}; }   // a * (+i)
+
+// z * exp(+2*pi*i*M/16) with the cheap cases special-cased
+template <int M>
+OCT_DEV f2 mul_w16(f2 z) {
+	constexpr int m = ((M % 16) + 16) % 16;
+	constexpr float h = 0.70710678118654752f;
+	if constexpr (m == 0) return z;
+	else if constexpr (m == 4) return f2{-z.y, z.x};
+	else if constexpr (m == 8) return f2{-z.x, -z.y};
+	else if constexpr (m == 12) return f2{z.y, -z.x};
+	else if constexpr (m == 2) return f2{h * (z.x - z.y), h * (z.x + z.y)};
+	else if constexpr (m == 6) return f2{-h * (z.x + z.y), h * (z.x - z.y)};
+	else if constexpr (m == 10) return f2{-h * (z.x - z.y), -h * (z.x + z.y)};
+	else if constexpr (m == 14) return f2{h * (z.x + z.y), -h * (z.x - z.y)};
+	else return f2{z.x * kCos16[m] - z.y * kSin16[m], z.x * kSin16[m] + z.y * kCos16[m]};
+}
+
+// ---- radix 2 / 4 on named values -------------------------------------------------
+template <bool PRUNE>
+OCT_DEV void dft2(f2& a, f2& b) {
+	f2 s = a + b;
+	if constexpr (!PRUNE) { b = a - b; }
+	a = s;
+}
+
+// outputs natural order in (a,b,c,d) = X[0..3]; PRUNE: only X[0], X[1] valid
+template <bool PRUNE>
+OCT_DEV void dft4(f2& a, f2& b, f2& c, f2& d) {
+	f2 s02 = a + c, d02 = a - c, s13 = b + d, d13 = mul_i(b - d);
+	a = s02 + s13;
+	b = d02 + d13;
+	if constexpr (!PRUNE) {
+		c = s02 - s13;
+		d = d02 - d13;
+	}
+}
+
+// ---- generic in-place DFT of R values with stride ST inside array v ----------------
+// v[t*ST], t = 0..R-1, natural order in and out.  PRUNE: only outputs u < R/2 are valid.
+template <int R, int ST, bool PRUNE>
+struct Dft;
+
+template <int ST, bool PRUNE>
+struct Dft<1, ST, PRUNE> { static OCT_DEV void run(f2*) {} };
+
+template <int ST, bool PRUNE>
+struct Dft<2, ST, PRUNE> { static OCT_DEV void run(f2* v) { dft2<PRUNE>(v[0], v[ST]); } };
+
+template <int ST, bool PRUNE>
+struct Dft<4, ST, PRUNE> { static OCT_DEV void run(f2* v) { dft4<PRUNE>(v[0], v[ST], v[2 * ST], v[3 * ST]); } };
+
+// R = 4 * 2:  t = 2*t1 + t0,  u = u1 + 4*u0
+template <int ST, bool PRUNE>
+struct Dft<8, ST, PRUNE> {
+	static OCT_DEV void run(f2* v) {
+		f2 a[2][4];
+#pragma unroll
+		for (int t0 = 0; t0 < 2; t0++) {
+			a[t0][0] = v[(0 + t0) * ST]; a[t0][1] = v[(2 + t0) * ST];
+			a[t0][2] = v[(4 + t0) * ST]; a[t0][3] = v[(6 + t0) * ST];
+			dft4<false>(a[t0][0], a[t0][1], a[t0][2], a[t0][3]);
+		}
+		a[1][1] = mul_w16<2>(a[1][1]);
+		a[1][2] = mul_w16<4>(a[1][2]);
+		a[1][3] = mul_w16<6>(a[1][3]);
+#pragma unroll
+		for (int u1 = 0; u1 < 4; u1++) {
+			dft2<PRUNE>(a[0][u1], a[1][u1]);
+			v[u1 * ST] = a[0][u1];
+			if constexpr (!PRUNE) v[(u1 + 4) * ST] = a[1][u1];
+		}
+	}
+};
+
+// R = 4 * 4:  t = 4*t1 + t0,  u = u1 + 4*u0
+template <int ST, bool PRUNE>
+struct Dft<16, ST, PRUNE> {
+	template <int T0, int U1>
+	static OCT_DEV void tw(f2 (&a)[4][4]) { a[T0][U1] = mul_w16<T0 * U1>(a[T0][U1]); }
+	static OCT_DEV void run(f2* v) {
+		f2 a[4][4];
+#pragma unroll
+		for (int t0 = 0; t0 < 4; t0++) {
+			a[t0][0] = v[(0 + t0) * ST]; a[t0][1] = v[(4 + t0) * ST];
+			a[t0][2] = v[(8 + t0) * ST]; a[t0][3] = v[(12 + t0) * ST];
+			dft4<false>(a[t0][0], a[t0][1], a[t0][2], a[t0][3]);
+		}
+		tw<1, 1>(a); tw<1, 2>(a); tw<1, 3>(a);
+		tw<2, 1>(a); tw<2, 2>(a); tw<2, 3>(a);
+		tw<3, 1>(a); tw<3, 2>(a); tw<3, 3>(a);
+#pragma unroll
+		for (int u1 = 0; u1 < 4; u1++) {
+			dft4<PRUNE>(a[0][u1], a[1][u1], a[2][u1], a[3][u1]);
+			v[u1 * ST] = a[0][u1];
+			v[(u1 + 4) * ST] = a[1][u1];
+			if constexpr (!PRUNE) {
+				v[(u1 + 8) * ST] = a[2][u1];
+				v[(u1 + 12) * ST] = a[3][u1];
+			}
+		}
+	}
+};
+
+}  // namespace octfft

@@ -1,0 +1,84 @@
+// fused_inst.hip -- instantiates the fused A-scan kernel for ONE transform length
+// (compiled once per OCT_LOG2N so the lengths build in parallel).
+#include "kernels.h"
+#include "launch.h"
+
+#ifndef OCT_LOG2N
+#error "compile with -DOCT_LOG2N=<8..12>"
+#endif
+
+namespace oct {
+
+namespace {
+constexpr int kLog2N = OCT_LOG2N;
+constexpr int kN = 1 << kLog2N;
+
+template <int INTYPE, int RS, bool ROLL, bool SPECTRUM>
+hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t stream, int* blocksUsed) {
+	auto kernel = oct_fused_kernel<kLog2N, INTYPE, RS, ROLL, SPECTRUM>;
+	constexpr int waves = fused_waves_per_block(kLog2N);
+	constexpr int threads = waves * 64;
+	constexpr size_t lds = block_lds_bytes<kLog2N>();
+	static int blocksPerCU = 0, numCU = 0;
+	if (blocksPerCU == 0) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+		int dev = 0;
+		if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+		if ((e = hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+		int occ = 0;
+		if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds)) != hipSuccess) return e;
+		blocksPerCU = occ > 0 ? occ : 1;
+	}
+	const unsigned need = (a.numLines + waves - 1) / waves;
+	unsigned blocks = requestedBlocks > 0 ? (unsigned)requestedBlocks : (unsigned)(numCU * blocksPerCU);
+	if (blocks > need) blocks = need;
+	if (blocks == 0) return hipSuccess;
+	if (blocksUsed) *blocksUsed = (int)blocks;
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, a);
+	return hipGetLastError();
+}
+
+template <int INTYPE, int RS, bool ROLL>
+hipError_t launch_sp(bool spectrum, const FusedArgs& a, int rb, hipStream_t st, int* bu) {
+	return spectrum ? launch_one<INTYPE, RS, ROLL, true>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLL, false>(a, rb, st, bu);
+}
+}  // namespace
+
+#define OCT_CAT2(a, b) a##b
+#define OCT_CAT(a, b) OCT_CAT2(a, b)
+
+// intype: IN_U16 or IN_F32; rs: RS_*; roll: in-kernel rolling average (IN_U16 only)
+hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool spectrum, const FusedArgs& a,
+                                             int requestedBlocks, hipStream_t stream, int* blocksUsed) {
+	if (intype == IN_U16) {
+		if (rs == RS_LANCZOS) return hipErrorInvalidValue;
+		if (roll) {
+			switch (rs) {
+			case RS_NONE: return launch_sp<IN_U16, RS_NONE, true>(spectrum, a, requestedBlocks, stream, blocksUsed);
+			case RS_LINEAR: return launch_sp<IN_U16, RS_LINEAR, true>(spectrum, a, requestedBlocks, stream, blocksUsed);
+			default: return launch_sp<IN_U16, RS_CUBIC, true>(spectrum, a, requestedBlocks, stream, blocksUsed);
+			}
+		}
+		switch (rs) {
+		case RS_NONE: return launch_sp<IN_U16, RS_NONE, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+		case RS_LINEAR: return launch_sp<IN_U16, RS_LINEAR, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+		default: return launch_sp<IN_U16, RS_CUBIC, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+		}
+	}
+	if (roll) return hipErrorInvalidValue;
+	switch (rs) {
+	case RS_NONE: return launch_sp<IN_F32, RS_NONE, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+	case RS_LINEAR: return launch_sp<IN_F32, RS_LINEAR, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+	case RS_CUBIC: return launch_sp<IN_F32, RS_CUBIC, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+	default: return launch_sp<IN_F32, RS_LANCZOS, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+	}
+}
+
+// host-side description of the per-pass twiddle tables the kernel expects in FusedArgs::twiddle
+int OCT_CAT(fused_twiddle_plan_, OCT_LOG2N)(int* radices) {
+	radices[0] = Plan<kLog2N>::R0; radices[1] = Plan<kLog2N>::R1; radices[2] = Plan<kLog2N>::R2; radices[3] = Plan<kLog2N>::R3;
+	return twiddle_count<kLog2N>();
+}
+
+}  // namespace oct

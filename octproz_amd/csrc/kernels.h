@@ -1,0 +1,356 @@
+// kernels.h -- HIP kernels of the OCT processing path for gfx950 (MI355X, wave64).
+//
+// One fused kernel does, per A-scan and without touching HBM in between, what the reference
+// does in 5-7 full-volume passes (cuda_code.cu "cu:"):
+//   raw unpack            cu:109-147   (inputToCufftComplex[_and_bitshift])
+//   rolling-average DC    cu:165-211   (rollingAverageBackgroundRemoval)
+//   k-linearisation       cu:213-326   (linear / cubic / Lanczos)  x window x phasor  cu:341-489
+//   inverse FFT           cu:1514-1515 (cufftExecC2C, CUFFT_INVERSE, unnormalised)
+//   mean A-line subtract  cu:567-584   (meanALineSubtraction)
+//   truncate + log / lin  cu:699-741   (postProcessTruncateLog / Lin)
+//   B-scan flip           cu:787-807   (cuda_bscanFlip, folded into the store address)
+//
+// Mapping: ONE wave64 per A-scan, N/64 complex points per lane kept in VGPRs.  The FFT is a
+// Stockham autosort with in-register radix-16/8/4 butterflies; between passes the wave
+// exchanges data through its private LDS slice (no workgroup barrier: wave-synchronous).
+// The raw row is staged in the same LDS slice for the resampling gather.  Only bins
+// 0..N/2-1 are produced (last pass pruned).  Algorithmic HBM traffic: 2*N bytes in (uint16),
+// 2*N bytes out (N/2 float32) per A-scan.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_regs.h"
+
+namespace oct {
+
+enum { IN_U8 = 0, IN_U16 = 1, IN_U32 = 2, IN_F32 = 3 };
+enum { RS_NONE = 0, RS_LINEAR = 1, RS_CUBIC = 2, RS_LANCZOS = 3 };
+
+struct FusedArgs {
+	const void* raw;         // device: raw samples of the buffer (or prepared float32 samples for IN_F32)
+	float* out;              // processed slot, [lines][N/2] float32
+	f2* spectrum;            // SPECTRUM mode: [lines][N] complex
+	const float4* lut;       // [N] {rho, window, phasor.x, phasor.y}
+	const f2* twiddle;       // per-pass tables [t-1][k] = exp(+2*pi*i*t*k/(NS*R)), see twiddle_count()
+	const f2* meanLine;      // [N] (first N/2 used)
+	unsigned numLines;       // A-scans to process in this launch
+	unsigned linesInBuffer;  // A-scans in the whole buffer (bounds for the Lanczos halo)
+	unsigned ascansPerBscan;
+	int bitshift;
+	int rollingW;            // 0 = off
+	int flip;
+	int logScale;
+	int subtractMean;
+	float sA, sB;            // out = sA * log2(P) + sB   (log)   |   sA * sqrt(P) + sB   (lin)
+};
+
+// waves (= A-scans in flight) per workgroup; bounded by the 160 KiB LDS of a CU
+constexpr int fused_waves_per_block(int log2n) { return log2n >= 12 ? 2 : 4; }
+
+#ifndef OCT_MIN_WAVES_PER_SIMD
+#define OCT_MIN_WAVES_PER_SIMD 3
+#endif
+
+constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
+
+template <int N> constexpr int wave_lds_bytes() {
+	constexpr int fft = (N + N / 16) * 8;
+	constexpr int row = (N + 2 * ROW_OFF) * 4;
+	constexpr int m = fft > row ? fft : row;
+	return (m + 15) & ~15;
+}
+
+OCT_DEV int pad16(int j) { return j + (j >> 4); }
+
+OCT_DEV void wave_sync_lds() {
+	// LDS operations of one wave execute in issue order; this only stops the compiler from
+	// moving LDS accesses across the point (cross-lane dependencies are invisible to it).
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------ raw chunk = 4 consecutive samples
+template <int INTYPE> struct Chunk;
+template <> struct Chunk<IN_U8>  { typedef uint32_t T; };
+template <> struct Chunk<IN_U16> { typedef uint2 T; };
+template <> struct Chunk<IN_U32> { typedef uint4 T; };
+template <> struct Chunk<IN_F32> { typedef float4 T; };
+
+template <int INTYPE>
+OCT_DEV typename Chunk<INTYPE>::T load_chunk(const void* base, size_t sampleIdx) {
+	typedef typename Chunk<INTYPE>::T T;
+	return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + sampleIdx * (sizeof(T) / 4));
+}
+
+// cu:109-147: unsigned integer -> float (exact below 2^24; uint32 rounds toward -inf like
+// __uint2float_rd), optional >> 4 (uint32: value / 2^32 evaluated in double).
+template <int INTYPE>
+OCT_DEV float4 chunk_to_float(typename Chunk<INTYPE>::T c, int bitshift) {
+	if constexpr (INTYPE == IN_U8) {
+		uint32_t s = bitshift ? 4u : 0u;
+		return float4{(float)((c & 0xffu) >> s), (float)(((c >> 8) & 0xffu) >> s),
+		              (float)(((c >> 16) & 0xffu) >> s), (float)((c >> 24) >> s)};
+	} else if constexpr (INTYPE == IN_U16) {
+		uint32_t s = bitshift ? 4u : 0u;
+		return float4{(float)((c.x & 0xffffu) >> s), (float)((c.x >> 16) >> s),
+		              (float)((c.y & 0xffffu) >> s), (float)((c.y >> 16) >> s)};
+	} else if constexpr (INTYPE == IN_U32) {
+		if (bitshift) {
+			const double k = 1.0 / 4294967296.0;
+			return float4{(float)((double)c.x * k), (float)((double)c.y * k), (float)((double)c.z * k), (float)((double)c.w * k)};
+		}
+		return float4{__uint2float_rd(c.x), __uint2float_rd(c.y), __uint2float_rd(c.z), __uint2float_rd(c.w)};
+	} else {
+		return c;
+	}
+}
+
+// cu:258-271
+OCT_DEV float cubic_hermite(float y0, float y1, float y2, float y3, float pos) {
+	float a = -y0 + 3.0f * (y1 - y2) + y3;
+	float b = 2.0f * y0 - 5.0f * y1 + 4.0f * y2 - y3;
+	float c = -y0 + y2;
+	float pos2 = pos * pos;
+	return 0.5f * pos * (a * pos2 + b * pos + c) + y1;
+}
+
+// cu:297-302
+OCT_DEV float lanczos8(float x) {
+	const float PI_F = 3.141592654f, PI_OVER_8 = 0.3926990817f;
+	float ax = fabsf(x);
+	float s1 = sinf(PI_F * ax) / (PI_F * ax);
+	float s8 = sinf(PI_OVER_8 * ax) / (PI_OVER_8 * ax);
+	return (ax < 0.00001f) ? 1.0f : (s1 * s8);
+}
+
+// ------------------------------------------------------------------ one Stockham pass
+// v[q] holds element (lane + 64*q) of the current sequence.  Butterfly b = lane + 64*m
+// (m < P/R) combines elements b + t*N/R, i.e. v[m + t*(P/R)]; its outputs go to
+// j0 + u*NS with j0 = (b/NS)*NS*R + b%NS.  The exchange buffer is padded by one element per
+// 16 (pad16) so that both the strided writes and the unit-stride reads are conflict-free;
+// all LDS addresses are "per-lane base + compile-time offset" so they fold into the
+// instructions' immediate fields instead of living in VGPRs.
+constexpr int pad16c(int j) { return j + (j >> 4); }
+
+template <int N, int R, int NS, bool LAST, bool PRUNE>
+OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
+	constexpr int P = N / 64, NB = P / R;
+	static_assert(NB >= 1, "radix larger than points per lane");
+	if constexpr (NS > 1) {
+#pragma unroll
+		for (int m = 0; m < NB; m++) {
+			const f2* tk = twp + ((lane + 64 * m) & (NS - 1));  // table layout [t-1][k]
+#pragma unroll
+			for (int t = 1; t < R; t++) v[m + t * NB] = octfft::cmul(v[m + t * NB], tk[(t - 1) * NS]);
+		}
+	}
+#pragma unroll
+	for (int m = 0; m < NB; m++) octfft::Dft<R, NB, LAST && PRUNE>::run(&v[m]);
+	if constexpr (!LAST) {
+#pragma unroll
+		for (int m = 0; m < NB; m++) {
+			const int b = lane + 64 * m;
+			const int j0 = (b / NS) * (NS * R) + (b & (NS - 1));
+			f2* wb = xbuf + (j0 + (j0 >> 4));
+#pragma unroll
+			for (int u = 0; u < R; u++) wb[pad16c(u * NS)] = v[m + u * NB];
+		}
+		wave_sync_lds();
+		const f2* rb = xbuf + (lane + (lane >> 4));
+#pragma unroll
+		for (int q = 0; q < P; q++) v[q] = rb[68 * q];
+		wave_sync_lds();
+	}
+}
+
+template <int LOG2N> struct Plan;
+template <> struct Plan<8>  { static constexpr int R0 = 4,  R1 = 4,  R2 = 4,  R3 = 4; };
+template <> struct Plan<9>  { static constexpr int R0 = 8,  R1 = 8,  R2 = 8,  R3 = 1; };
+template <> struct Plan<10> { static constexpr int R0 = 16, R1 = 16, R2 = 4,  R3 = 1; };
+template <> struct Plan<11> { static constexpr int R0 = 16, R1 = 16, R2 = 8,  R3 = 1; };
+template <> struct Plan<12> { static constexpr int R0 = 16, R1 = 16, R2 = 16, R3 = 1; };
+
+// entries of the per-pass twiddle tables: sum over passes with NS > 1 of (R-1)*NS
+template <int LOG2N> constexpr int twiddle_count() {
+	typedef Plan<LOG2N> PL;
+	int n = 0, ns = PL::R0;
+	n += (PL::R1 - 1) * ns; ns *= PL::R1;
+	n += (PL::R2 - 1) * ns; ns *= PL::R2;
+	if (PL::R3 > 1) n += (PL::R3 - 1) * ns;
+	return n;
+}
+
+// natural-order inverse FFT of v (element lane+64q); result bin (lane + 64*m + u*N/RL) in
+// v[m + u*NB], RL = radix of the last pass, NB = P/RL.  PRUNE: only u < RL/2 valid.
+template <int LOG2N, bool PRUNE>
+OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane) {
+	constexpr int N = 1 << LOG2N;
+	typedef Plan<LOG2N> PL;
+	constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
+	static_assert(R0 * R1 * R2 * R3 == N, "plan");
+	constexpr int T1 = 0, T2 = T1 + (R1 - 1) * R0, T3 = T2 + (R2 - 1) * R0 * R1;
+	fft_pass<N, R0, 1, false, PRUNE>(v, xbuf, tw, lane);
+	fft_pass<N, R1, R0, false, PRUNE>(v, xbuf, tw + T1, lane);
+	if constexpr (R3 == 1) {
+		fft_pass<N, R2, R0 * R1, true, PRUNE>(v, xbuf, tw + T2, lane);
+	} else {
+		fft_pass<N, R2, R0 * R1, false, PRUNE>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R3, R0 * R1 * R2, true, PRUNE>(v, xbuf, tw + T3, lane);
+	}
+}
+template <int LOG2N> struct LastRadix { static constexpr int value = Plan<LOG2N>::R3 == 1 ? Plan<LOG2N>::R2 : Plan<LOG2N>::R3; };
+
+// ------------------------------------------------------------------ the fused kernel
+template <int LOG2N> constexpr int tw_lds_bytes() { return (twiddle_count<LOG2N>() * 8 + 15) & ~15; }
+template <int LOG2N> constexpr int block_lds_bytes() {
+	return tw_lds_bytes<LOG2N>() + fused_waves_per_block(LOG2N) * wave_lds_bytes<(1 << LOG2N)>();
+}
+
+// INTYPE: IN_U16 (raw, the hot configuration) or IN_F32 (samples prepared by oct_prepare_kernel:
+// uint8 / uint32 input and everything in front of the Lanczos variant).
+// RS: resampling mode (RS_*); ROLL: rolling-average DC removal inside the kernel (IN_U16 only);
+// SPECTRUM: write the full complex spectrum instead of the processed half A-scan.
+template <int LOG2N, int INTYPE, int RS, bool ROLL, bool SPECTRUM>
+__global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, OCT_MIN_WAVES_PER_SIMD) void oct_fused_kernel(const FusedArgs a) {
+	constexpr int N = 1 << LOG2N, P = N / 64, NL = N / 256;
+	constexpr int WAVES = fused_waves_per_block(LOG2N), THREADS = WAVES * 64;
+	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
+	static_assert(!(RS == RS_LANCZOS && INTYPE != IN_F32), "Lanczos needs the prepared float buffer");
+	static_assert(!(ROLL && INTYPE == IN_F32), "prepared input is already DC-corrected");
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	f2* tw = reinterpret_cast<f2*>(smem);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + wave * wave_lds_bytes<N>();
+	float* row = reinterpret_cast<float*>(wbase);
+	f2* xbuf = reinterpret_cast<f2*>(wbase);
+
+	for (int i = tid; i < twiddle_count<LOG2N>(); i += THREADS) tw[i] = a.twiddle[i];
+	__syncthreads();
+
+	const unsigned wavesTotal = gridDim.x * (unsigned)WAVES;
+	unsigned line = blockIdx.x * (unsigned)WAVES + wave;
+	typedef typename Chunk<INTYPE>::T ChunkT;
+	ChunkT pre[NL];
+	if constexpr (RS != RS_LANCZOS) {
+		if (line < a.numLines) {
+#pragma unroll
+			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(a.raw, (size_t)line * N + 4u * (lane + 64 * i));
+		}
+	}
+	const float4* lutp = a.lut + lane;
+	float* rowl = row + ROW_OFF + lane;
+
+	for (; line < a.numLines; line += wavesTotal) {
+		// ---- stage the raw row in LDS as float32
+		if constexpr (RS != RS_LANCZOS) {
+#pragma unroll
+			for (int i = 0; i < NL; i++) {
+				float4 f = chunk_to_float<INTYPE>(pre[i], a.bitshift);
+				*reinterpret_cast<float4*>(&row[ROW_OFF + 4 * lane + 256 * i]) = f;
+			}
+			const unsigned next = line + wavesTotal;  // prefetch the next row of this wave
+			if (next < a.numLines) {
+#pragma unroll
+				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(a.raw, (size_t)next * N + 4u * (lane + 64 * i));
+			}
+		} else {
+			// Lanczos taps cross line borders (cu:313-321): stage [off-8, off+N+8) of the prepared
+			// float buffer, off = clamp(line*N, 8, S-9) (the reference's first-line quirk), 0 outside.
+			const long long S = (long long)a.linesInBuffer * N;
+			long long off = (long long)line * N;
+			if (off < 8) off = 8;
+			if (off > S - 9) off = S - 9;
+			const float* g = reinterpret_cast<const float*>(a.raw);
+			for (int t = lane; t < N + 16; t += 64) {
+				long long gi = off - 8 + t;
+				row[ROW_OFF - 8 + t] = (gi >= 0 && gi < S) ? g[gi] : 0.0f;
+			}
+		}
+		wave_sync_lds();
+
+		// ---- rolling-average DC removal (cu:165-211), values summed in index order
+		if constexpr (ROLL) {
+			const int W = a.rollingW;
+			float r[P];
+#pragma unroll
+			for (int q = 0; q < P; q++) {
+				const int j = lane + 64 * q;
+				const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
+				float sum = 0.0f;
+				for (int t = lo; t <= hi; t++) sum += row[ROW_OFF + t];
+				r[q] = rowl[64 * q] - __fdiv_rn(sum, (float)(hi - lo + 1));
+			}
+			wave_sync_lds();
+#pragma unroll
+			for (int q = 0; q < P; q++) rowl[64 * q] = r[q];
+			wave_sync_lds();
+		}
+		if constexpr (RS == RS_CUBIC) {
+			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
+			wave_sync_lds();
+		}
+
+		// ---- k-linearisation x window x dispersion phasor -> complex points in registers
+		f2 v[P];
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+			const float4 L = lutp[64 * q];  // {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
+			float y;
+			if constexpr (RS == RS_CUBIC) {
+				const int n1 = (int)L.x;
+				const float* t = &row[ROW_OFF - 1 + n1];
+				y = cubic_hermite(t[0], t[1], t[2], t[3], L.x - (float)n1);
+			} else if constexpr (RS == RS_LINEAR) {
+				const int n1 = (int)L.x;
+				const float* t = &row[ROW_OFF + n1];
+				y = t[0] + (t[1] - t[0]) * (L.x - (float)n1);
+			} else if constexpr (RS == RS_NONE) {
+				y = rowl[64 * q];
+			} else {
+				const int n0 = (int)L.x;
+				const float* t = &row[ROW_OFF + n0];
+				float sum = 0.0f;
+#pragma unroll
+				for (int i = -7; i <= 8; i++) sum += t[i] * lanczos8(L.x - (float)(n0 + i));
+				y = sum;
+			}
+			const float yw = y * L.y;
+			v[q] = f2{yw * L.z, yw * L.w};
+		}
+		wave_sync_lds();  // the row is dead from here on; its LDS is reused by the FFT
+
+		// ---- inverse FFT
+		fft_wave<LOG2N, !SPECTRUM>(v, xbuf, tw, lane);
+
+		if constexpr (SPECTRUM) {
+			f2* dst = a.spectrum + (size_t)line * N + lane;
+#pragma unroll
+			for (int m = 0; m < NBL; m++)
+#pragma unroll
+				for (int u = 0; u < RL; u++) dst[64 * m + u * (N / RL)] = v[m + u * NBL];
+		} else {
+			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
+			unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
+			if (a.flip && (b & 1u) == 0u) as = a.ascansPerBscan - 1u - as;
+			float* dst = a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2) + lane;
+			const f2* ml = a.meanLine + lane;
+#pragma unroll
+			for (int m = 0; m < NBL; m++) {
+#pragma unroll
+				for (int u = 0; u < RL / 2; u++) {
+					constexpr int dummy = 0; (void)dummy;
+					const int r = 64 * m + u * (N / RL);
+					f2 z = v[m + u * NBL];
+					if (a.subtractMean) z = z - ml[r];
+					const float p = z.x * z.x + z.y * z.y;
+					const float s = a.logScale ? __log2f(p) : __fsqrt_rn(p);
+					dst[r] = a.sA * s + a.sB;
+				}
+			}
+		}
+		wave_sync_lds();
+	}
+}
+
+}  // namespace oct

@@ -1,0 +1,783 @@
+// octpipe_api.hip -- implementation of the C ABI in include/octpipe.h on top of the HIP kernels.
+//
+// Orchestration mirrors octCudaPipeline (cuda_code.cu:1389-1605, "cu:") stage for stage, but the
+// steady state is ONE fused kernel per buffer instead of 5-7 passes + cuFFT, all state lives in
+// the handle instead of module globals (cu:39-105), and every failure is a status code instead
+// of exit(EXIT_FAILURE) (helper_cuda.h:583-590).  There is no CPU fallback: without a HIP device
+// octpipe_create fails with OCTPIPE_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/octpipe.h"
+#include "host_luts.h"
+#include "launch.h"
+#include "side_kernels.h"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg) {
+	g_lastError = msg;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+	do {                                                                                                      \
+		hipError_t _e = (expr);                                                                               \
+		if (_e != hipSuccess) {                                                                               \
+			return fail(_e == hipErrorOutOfMemory ? OCTPIPE_ERR_OUT_OF_MEMORY : OCTPIPE_ERR_DEVICE,           \
+			            std::string(#expr) + ": " + hipGetErrorString(_e));                                   \
+		}                                                                                                     \
+	} while (0)
+
+struct CalibrationHeader {  // layout of the calibration blob (octpipe_export_calibration)
+	uint32_t magic, version, samplesPerLine, fixedPatternNoiseDetermined;
+};
+constexpr uint32_t kCalibMagic = 0x4F435443u;  // "OCTC"
+
+struct TimedLaunch { hipEvent_t start, stop; };
+
+}  // namespace
+
+struct octpipe {
+	int device = 0;
+	OctPipeAcquisitionParams acq{};
+	OctPipeParams params{};
+	int N = 0, A = 0, B = 0, log2n = 0, bytesPerSample = 0;
+	size_t S = 0;  // samplesPerBuffer
+
+	hipStream_t stream = nullptr;      // compute stream (all kernels)
+	hipStream_t copyStream = nullptr;  // H2D of the raw buffer
+	bool ownStream = true;
+	hipEvent_t h2dDone[2] = {nullptr, nullptr};   // raw slot filled
+	hipEvent_t slotFree[2] = {nullptr, nullptr};  // fused kernel finished reading the raw slot
+	bool slotUsed[2] = {false, false};
+	int slot = 0;
+
+	void* d_raw[2] = {nullptr, nullptr};
+	float* d_prepared = nullptr;   // S floats (uint8/uint32 input, Lanczos): lazily allocated
+	float* d_processed = nullptr;  // S/2 * buffersPerVolume
+	float* d_sinusTmp = nullptr;   // S/2, lazily
+	void* d_output = nullptr;      // quantised output, lazily
+	float4* d_lut = nullptr;
+	f2* d_twiddle = nullptr;
+	f2* d_meanLine = nullptr;
+	float* d_postBg = nullptr;
+	float* d_sinusCurve = nullptr;
+	f2* d_spectrum = nullptr;  // FPN / debug scratch, lazily
+	size_t spectrumLines = 0;
+	float4* d_segs = nullptr;
+	float* d_dispBscan = nullptr;
+	float* d_dispEnFace = nullptr;
+
+	std::vector<float> resample, dispersion, window, phase;  // host copies (N each, phase 2N); zero like cu:1082-1085
+	std::vector<float> h_postBg;                             // host shadow of the recorded background
+	bool lutDirty = true;
+
+	unsigned bufferNumberInVolume = 0;
+	bool fpnDetermined = false;
+	bool pinMean = false;
+	unsigned streamedBuffers = 0, streamingBufferNumber = 0, floatStreamingBufferNumber = 0;
+
+	void* h_buffer[2] = {nullptr, nullptr};
+	bool h_bufferRegistered[2] = {false, false};
+	void* h_stream[2] = {nullptr, nullptr};
+	void* h_floatStream[2] = {nullptr, nullptr};
+	bool floatStreamingRegistered = false;
+	size_t streamBytes = 0, floatStreamBytes = 0;
+
+	octpipe_data_callback onStreaming = nullptr, onFloatStreaming = nullptr;
+	octpipe_event_callback onBackground = nullptr;
+	void* user = nullptr;
+
+	bool timing = false;
+	std::vector<TimedLaunch> timed;
+	double timedMs = 0.0;
+	unsigned timedLaunches = 0;
+};
+
+namespace {
+
+struct CallbackCtx {  // heap object handed to hipLaunchHostFunc; freed by the callback
+	octpipe* h;
+	void* buffer;
+	unsigned bufferNr;
+	int kind;  // 0 streaming, 1 float streaming, 2 background
+};
+
+void hostCallback(void* p) {
+	CallbackCtx* c = static_cast<CallbackCtx*>(p);
+	octpipe* h = c->h;
+	// argument list of Gpu2HostNotifier::emitCurrentStreamingBuffer (gpu2hostnotifier.cpp:45-53)
+	if (c->kind == 0 && h->onStreaming)
+		h->onStreaming(c->buffer, h->acq.bitDepth, h->acq.samplesPerLine / 2, h->acq.ascansPerBscan, h->acq.bscansPerBuffer, h->acq.buffersPerVolume, c->bufferNr, h->user);
+	else if (c->kind == 1 && h->onFloatStreaming)
+		h->onFloatStreaming(c->buffer, h->acq.bitDepth, h->acq.samplesPerLine / 2, h->acq.ascansPerBscan, h->acq.bscansPerBuffer, h->acq.buffersPerVolume, c->bufferNr, h->user);
+	else if (c->kind == 2 && h->onBackground)
+		h->onBackground(h->user);
+	delete c;
+}
+
+int gridFor(size_t n, int block = 256) {
+	size_t g = (n + block - 1) / block;
+	const size_t cap = 256 * 16;
+	return (int)(g > cap ? cap : (g == 0 ? 1 : g));
+}
+
+// {rho, window, phasor} per sample; a disabled stage contributes its neutral element, which is
+// exactly what the reference's 8-way kernel selection does (cu:1448-1511): x*1.0f == x.
+int uploadLut(octpipe* h) {
+	const int N = h->N;
+	std::vector<float4> lut(N);
+	const OctPipeParams& p = h->params;
+	for (int j = 0; j < N; ++j) {
+		float rho = p.resampling ? h->resample[j] : (float)j;
+		// memory safety only: a curve outside [0, N-3] is undefined behaviour in the reference
+		// (octalgorithmparameters.cpp:167 clamps on the host for exactly this reason)
+		if (!(rho >= 0.0f)) rho = 0.0f;
+		if (rho > (float)(N - 3)) rho = (float)(N - 3);
+		float4 e;
+		e.x = rho;
+		e.y = p.windowing ? h->window[j] : 1.0f;
+		e.z = p.dispersionCompensation ? h->phase[2 * j] : 1.0f;
+		e.w = p.dispersionCompensation ? h->phase[2 * j + 1] : 0.0f;
+		lut[j] = e;
+	}
+	HIP_TRY(hipMemcpyAsync(h->d_lut, lut.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));  // lut is a stack vector
+	h->lutDirty = false;
+	return OCTPIPE_OK;
+}
+
+int uploadTwiddles(octpipe* h) {
+	int radices[4];
+	const int count = oct::fused_twiddle_plan(h->log2n, radices);
+	if (count < 0) return fail(OCTPIPE_ERR_UNSUPPORTED, "no FFT plan for this samplesPerLine");
+	std::vector<f2> tw((size_t)count);
+	size_t pos = 0;
+	int ns = radices[0];
+	for (int pass = 1; pass < 4; ++pass) {
+		const int R = radices[pass];
+		if (R <= 1) break;
+		for (int t = 1; t < R; ++t)
+			for (int k = 0; k < ns; ++k) {
+				const double ang = 2.0 * 3.14159265358979323846 * (double)t * (double)k / ((double)ns * R);
+				tw[pos++] = f2{(float)cos(ang), (float)sin(ang)};
+			}
+		ns *= R;
+	}
+	HIP_TRY(hipMalloc(&h->d_twiddle, sizeof(f2) * (size_t)count));
+	HIP_TRY(hipMemcpy(h->d_twiddle, tw.data(), sizeof(f2) * (size_t)count, hipMemcpyHostToDevice));
+	return OCTPIPE_OK;
+}
+
+int ensure(void** p, size_t bytes) {
+	if (*p) return OCTPIPE_OK;
+	HIP_TRY(hipMalloc(p, bytes));
+	HIP_TRY(hipMemset(*p, 0, bytes));
+	return OCTPIPE_OK;
+}
+
+bool needsPrepared(const octpipe* h) {
+	return h->bytesPerSample != 2 || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
+}
+
+// one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
+int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt) {
+	const OctPipeParams& p = h->params;
+	oct::FusedArgs a{};
+	int intype = oct::IN_U16;
+	bool roll = p.backgroundRemoval != 0;
+	int rs = oct::RS_NONE;
+	if (p.resampling) {
+		rs = p.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC
+		   : p.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS ? oct::RS_LANCZOS : oct::RS_LINEAR;
+	}
+	a.raw = d_raw;
+	if (needsPrepared(h)) {
+		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
+		if (rc) return rc;
+		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(h->S)), dim3(256), 0, h->stream, d_raw, h->d_prepared,
+		                   (int)h->acq.bitDepth, p.bitshift, roll ? p.rollingAverageWindowSize : 0, h->N, h->S);
+		HIP_TRY(hipGetLastError());
+		a.raw = h->d_prepared;
+		intype = oct::IN_F32;
+		roll = false;
+	}
+	a.out = out;
+	a.spectrum = spectrumOut;
+	a.lut = h->d_lut;
+	a.twiddle = h->d_twiddle;
+	a.meanLine = h->d_meanLine;
+	a.numLines = lines;
+	a.linesInBuffer = (unsigned)(h->A * h->B);
+	a.ascansPerBscan = (unsigned)h->A;
+	a.bitshift = p.bitshift;
+	a.rollingW = p.rollingAverageWindowSize;
+	a.flip = p.bscanFlip;
+	a.logScale = p.signalLogScaling;
+	a.subtractMean = p.fixedPatternNoiseRemoval;
+	// cu:718 / cu:739 rewritten as one multiply-add on log2(P) resp. sqrt(P); constants in double
+	const double half = (double)(h->N / 2), range = (double)p.signalGrayscaleMax - (double)p.signalGrayscaleMin;
+	const double coeff = p.signalMultiplicator, addend = p.signalAddend, mn = p.signalGrayscaleMin;
+	if (p.signalLogScaling) {
+		a.sA = (float)(coeff * 10.0 * log10(2.0) / range);
+		a.sB = (float)(coeff * ((-10.0 * log10(half) - mn) / range + addend));
+	} else {
+		a.sA = (float)(coeff / (half * range));
+		a.sB = (float)(coeff * (-mn / range + addend));
+	}
+	TimedLaunch t{};
+	if (timeIt && h->timing) {
+		HIP_TRY(hipEventCreate(&t.start));
+		HIP_TRY(hipEventCreate(&t.stop));
+		HIP_TRY(hipEventRecord(t.start, h->stream));
+	}
+	HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, a, 0, h->stream, nullptr));
+	if (timeIt && h->timing) {
+		HIP_TRY(hipEventRecord(t.stop, h->stream));
+		h->timed.push_back(t);
+	}
+	return OCTPIPE_OK;
+}
+
+int foldTimings(octpipe* h) {
+	if (h->timed.empty()) return OCTPIPE_OK;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	for (auto& t : h->timed) {
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+		h->timedMs += ms;
+		h->timedLaunches++;
+		hipEventDestroy(t.start);
+		hipEventDestroy(t.stop);
+	}
+	h->timed.clear();
+	return OCTPIPE_OK;
+}
+
+int minVarianceMean(octpipe* h, const f2* d_in, int width, int height, f2* d_meanOut) {
+	const int segs = 9;  // FIXED_PATTERN_NOISE_REMOVAL_SEGMENTS, octalgorithmparameters.h:35
+	const int segWidth = height / segs;
+	int rc = ensure((void**)&h->d_segs, sizeof(float4) * (size_t)segs * (size_t)std::max(width, h->N));
+	if (rc) return rc;
+	hipLaunchKernelGGL(oct::oct_minvar_segments_kernel, dim3((width * segs + 255) / 256), dim3(256), 0, h->stream, d_in, width, segWidth, segs, h->d_segs);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(oct::oct_minvar_select_kernel, dim3((width + 255) / 256), dim3(256), 0, h->stream, h->d_segs, width, segs, d_meanOut);
+	HIP_TRY(hipGetLastError());
+	return OCTPIPE_OK;
+}
+
+int updateBscanDisplay(octpipe* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1267-1284
+	const unsigned depth = (unsigned)(h->B * (int)h->acq.buffersPerVolume);
+	const unsigned n = (unsigned)(h->N * h->A / 2);
+	frameNr = frameNr < depth ? frameNr : 0;
+	hipLaunchKernelGGL(oct::oct_display_bscan_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_dispBscan, h->d_processed, depth, n, frameNr, frames, fn);
+	HIP_TRY(hipGetLastError());
+	return OCTPIPE_OK;
+}
+int updateEnFaceDisplay(octpipe* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1286-1308
+	const unsigned n = (unsigned)(h->B * (int)h->acq.buffersPerVolume * h->A);
+	frameNr = frameNr < (unsigned)(h->N / 2) ? frameNr : 0;
+	hipLaunchKernelGGL(oct::oct_display_enface_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_dispEnFace, h->d_processed, (unsigned)(h->N / 2), n, frameNr, frames, fn);
+	HIP_TRY(hipGetLastError());
+	return OCTPIPE_OK;
+}
+
+// everything of octCudaPipeline after the raw buffer is on the device (cu:1408-1604)
+int processDeviceRaw(octpipe* h, const void* d_raw) {
+	OctPipeParams& p = h->params;
+	const size_t S = h->S;
+	const int N = h->N, A = h->A, B = h->B;
+	if (h->lutDirty) { int rc = uploadLut(h); if (rc) return rc; }
+
+	// fixed-pattern-noise estimate (cu:1518-1525): spectrum of the first H A-scans -> min-variance mean
+	if (p.fixedPatternNoiseRemoval && !h->pinMean &&
+	    ((!p.continuousFixedPatternNoiseDetermination && !h->fpnDetermined) || p.continuousFixedPatternNoiseDetermination || p.redetermineFixedPatternNoise)) {
+		size_t H = (size_t)p.bscansForNoiseDetermination * (size_t)A;
+		if (H > (size_t)A * B) H = (size_t)A * B;  // the reference would read past its buffer here
+		if (h->spectrumLines < H) {
+			if (h->d_spectrum) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->d_spectrum)); h->d_spectrum = nullptr; }
+			HIP_TRY(hipMalloc((void**)&h->d_spectrum, sizeof(f2) * H * (size_t)N));
+			h->spectrumLines = H;
+		}
+		int rc = launchFused(h, d_raw, (unsigned)H, true, h->d_spectrum, nullptr, false);
+		if (rc) return rc;
+		rc = minVarianceMean(h, h->d_spectrum, N, (int)H, h->d_meanLine);
+		if (rc) return rc;
+		h->fpnDetermined = true;
+		p.redetermineFixedPatternNoise = 0;
+	}
+
+	if (h->acq.buffersPerVolume > 1) h->bufferNumberInVolume = (h->bufferNumberInVolume + 1) % h->acq.buffersPerVolume;  // cu:1530-1532
+	float* d_curr = h->d_processed + (S / 2) * h->bufferNumberInVolume;                                                   // cu:1535
+
+	int rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_curr, true);
+	if (rc) return rc;
+
+	if (p.sinusoidalScanCorrection) {  // cu:1551-1554
+		rc = ensure((void**)&h->d_sinusTmp, sizeof(float) * (S / 2));
+		if (rc) return rc;
+		HIP_TRY(hipMemcpyAsync(h->d_sinusTmp, d_curr, sizeof(float) * (S / 2), hipMemcpyDeviceToDevice, h->stream));
+		hipLaunchKernelGGL(oct::oct_sinusoidal_kernel, dim3(gridFor(S / 2)), dim3(256), 0, h->stream, d_curr, h->d_sinusTmp, h->d_sinusCurve, N / 2, A, S / 2);
+		HIP_TRY(hipGetLastError());
+	}
+
+	if (p.postProcessBackgroundRemoval) {  // cu:1557-1568
+		if (p.postProcessBackgroundRecordingRequested) {
+			hipLaunchKernelGGL(oct::oct_get_postproc_background_kernel, dim3((N / 2 + 255) / 256), dim3(256), 0, h->stream, h->d_postBg, d_curr, N / 2, A);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(h->h_postBg.data(), h->d_postBg, sizeof(float) * (N / 2), hipMemcpyDeviceToHost, h->stream));
+			if (h->onBackground) HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, nullptr, 0, 2}));
+			p.postProcessBackgroundRecordingRequested = 0;
+		}
+		hipLaunchKernelGGL(oct::oct_postproc_background_removal_kernel, dim3(gridFor(S / 2)), dim3(256), 0, h->stream, d_curr, h->d_postBg,
+		                   p.postProcessBackgroundWeight, p.postProcessBackgroundOffset, N / 2, S / 2);
+		HIP_TRY(hipGetLastError());
+	}
+
+	if (p.bscanViewEnabled) { rc = updateBscanDisplay(h, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan); if (rc) return rc; }              // cu:1571-1574
+	if (p.enFaceViewEnabled) { rc = updateEnFaceDisplay(h, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView); if (rc) return rc; }  // cu:1575-1578
+
+	if (p.streamFloatToHost && h->floatStreamingRegistered) {  // streamProcessedFloatData, cu:1374-1386
+		h->floatStreamingBufferNumber = (h->floatStreamingBufferNumber + 1) % 2;
+		void* dst = h->floatStreamingBufferNumber == 0 ? h->h_floatStream[0] : h->h_floatStream[1];
+		HIP_TRY(hipMemcpyAsync(dst, d_curr, (S / 2) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, dst, h->bufferNumberInVolume, 1}));
+	}
+	if (p.streamToHost && h->h_stream[0] && h->h_stream[1]) {  // streamProcessedData, cu:1357-1372
+		if (h->streamedBuffers % (p.streamingBuffersToSkip + 1) == 0) {
+			h->streamedBuffers = 0;
+			h->streamingBufferNumber = (h->streamingBufferNumber + 1) % 2;
+			void* dst = h->streamingBufferNumber == 0 ? h->h_stream[0] : h->h_stream[1];
+			rc = ensure(&h->d_output, (S / 2) * (size_t)h->bytesPerSample);
+			if (rc) return rc;
+			hipLaunchKernelGGL(oct::oct_float_to_output_kernel, dim3(gridFor(S / 2)), dim3(256), 0, h->stream, h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(dst, h->d_output, (S / 2) * (size_t)h->bytesPerSample, hipMemcpyDeviceToHost, h->stream));
+			HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, dst, h->bufferNumberInVolume, 0}));
+		}
+		h->streamedBuffers++;
+	}
+	return OCTPIPE_OK;
+}
+
+int setDevice(const octpipe* h) {
+	HIP_TRY(hipSetDevice(h->device));
+	return OCTPIPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int octpipe_abi_version(void) { return OCTPIPE_ABI_VERSION; }
+const char* octpipe_last_error(void) { return g_lastError.c_str(); }
+
+int octpipe_device_count(int* count) {
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (count) *count = (e == hipSuccess) ? n : 0;
+	if (e != hipSuccess || n == 0) return fail(OCTPIPE_ERR_NO_DEVICE, "no HIP device available");
+	return OCTPIPE_OK;
+}
+
+int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
+                   void* h_buffer1, void* h_buffer2) {
+	if (!out || !acq || !params) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*out = nullptr;
+	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
+		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
+	if (!oct::fused_supported(acq->samplesPerLine))
+		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must be 256, 512, 1024, 2048 or 4096 in this build");
+	int count = 0;
+	int rc = octpipe_device_count(&count);
+	if (rc) return rc;
+	if (device < 0 || device >= count) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "device index out of range");
+	if ((size_t)acq->ascansPerBscan * acq->bscansPerBuffer > 0xFFFFFFF0ull) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "too many A-scans per buffer");
+
+	octpipe* h = new octpipe();
+	h->device = device;
+	h->acq = *acq;
+	h->params = *params;
+	h->N = (int)acq->samplesPerLine;
+	h->A = (int)acq->ascansPerBscan;
+	h->B = (int)acq->bscansPerBuffer;
+	h->S = (size_t)h->N * h->A * h->B;
+	h->bytesPerSample = (int)((acq->bitDepth + 7) / 8);  // ceil(bitDepth/8), cu:1077
+	if (h->bytesPerSample == 3) h->bytesPerSample = 4;    // 17..24 bit live in uint32 (cu:122-124)
+	h->log2n = 0;
+	while ((1 << h->log2n) < h->N) h->log2n++;
+	h->resample.assign(h->N, 0.0f);
+	h->dispersion.assign(h->N, 0.0f);
+	h->window.assign(h->N, 0.0f);
+	h->phase.assign(2 * (size_t)h->N, 0.0f);
+	h->h_postBg.assign(h->N / 2, 0.0f);
+	h->bufferNumberInVolume = acq->buffersPerVolume - 1;  // cu:1146
+	*out = h;  // from here on failures leave a handle the caller must destroy
+
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
+	for (int i = 0; i < 2; ++i) {
+		HIP_TRY(hipEventCreateWithFlags(&h->h2dDone[i], hipEventBlockingSync | hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&h->slotFree[i], hipEventDisableTiming));
+	}
+	const size_t S = h->S;
+	if ((rc = ensure((void**)&h->d_processed, sizeof(float) * (S / 2) * acq->buffersPerVolume))) return rc;
+	if ((rc = ensure((void**)&h->d_lut, sizeof(float4) * h->N))) return rc;
+	if ((rc = ensure((void**)&h->d_meanLine, sizeof(f2) * h->N))) return rc;
+	if ((rc = ensure((void**)&h->d_postBg, sizeof(float) * (h->N / 2)))) return rc;
+	if ((rc = ensure((void**)&h->d_sinusCurve, sizeof(float) * h->A))) return rc;
+	if ((rc = ensure((void**)&h->d_dispBscan, sizeof(float) * ((size_t)h->N * h->A / 2)))) return rc;
+	if ((rc = ensure((void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
+	if ((rc = uploadTwiddles(h))) return rc;
+	hipLaunchKernelGGL(oct::oct_fill_sinus_curve_kernel, dim3((h->A + 255) / 256), dim3(256), 0, h->stream, h->d_sinusCurve, h->A);  // cu:1093
+	HIP_TRY(hipGetLastError());
+	// ring slots: pinned here, unpinned in octpipe_destroy (cu:1135-1136, 1200-1207)
+	void* hb[2] = {h_buffer1, h_buffer2};
+	for (int i = 0; i < 2; ++i) {
+		h->h_buffer[i] = hb[i];
+		if (hb[i]) {
+			HIP_TRY(hipHostRegister(hb[i], S * (size_t)h->bytesPerSample, hipHostRegisterPortable));
+			h->h_bufferRegistered[i] = true;
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return OCTPIPE_OK;
+}
+
+int octpipe_destroy(octpipe_t* h) {
+	if (!h) return OCTPIPE_OK;
+	hipSetDevice(h->device);
+	if (h->stream) hipStreamSynchronize(h->stream);
+	if (h->copyStream) hipStreamSynchronize(h->copyStream);
+	for (auto& t : h->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+	for (int i = 0; i < 2; ++i) {
+		if (h->h_bufferRegistered[i]) hipHostUnregister(h->h_buffer[i]);
+		if (h->d_raw[i]) hipFree(h->d_raw[i]);
+		if (h->h2dDone[i]) hipEventDestroy(h->h2dDone[i]);
+		if (h->slotFree[i]) hipEventDestroy(h->slotFree[i]);
+	}
+	octpipe_unregister_streaming_buffers(h);
+	octpipe_unregister_float_streaming_buffers(h);
+	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
+	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace};
+	for (void* b : bufs) if (b) hipFree(b);
+	if (h->copyStream) hipStreamDestroy(h->copyStream);
+	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);
+	delete h;
+	return OCTPIPE_OK;
+}
+
+int octpipe_set_params(octpipe_t* h, const OctPipeParams* params) {
+	if (!h || !params) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	const OctPipeParams& o = h->params;
+	if (o.resampling != params->resampling || o.windowing != params->windowing || o.dispersionCompensation != params->dispersionCompensation)
+		h->lutDirty = true;
+	h->params = *params;
+	return OCTPIPE_OK;
+}
+
+int octpipe_get_acquisition_params(const octpipe_t* h, OctPipeAcquisitionParams* out) {
+	if (!h || !out) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*out = h->acq;
+	return OCTPIPE_OK;
+}
+
+int octpipe_update_resample_curve(octpipe_t* h, const float* curve, int size) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	if (curve && size > 0 && size <= h->N) {  // the reference's own guard, cu:970
+		std::memcpy(h->resample.data(), curve, sizeof(float) * (size_t)size);
+		h->lutDirty = true;
+	}
+	return OCTPIPE_OK;
+}
+int octpipe_update_dispersion_curve(octpipe_t* h, const float* curve, int size) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	if (curve && size > 0 && size <= h->N) {
+		std::memcpy(h->dispersion.data(), curve, sizeof(float) * (size_t)size);
+		octhost::dispersive_phase(h->dispersion.data(), (unsigned)h->N, h->phase.data());  // fillDispersivePhase, cu:1439
+		h->lutDirty = true;
+	}
+	return OCTPIPE_OK;
+}
+int octpipe_update_window_curve(octpipe_t* h, const float* curve, int size) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	if (curve && size > 0 && size <= h->N) {
+		std::memcpy(h->window.data(), curve, sizeof(float) * (size_t)size);
+		h->lutDirty = true;
+	}
+	return OCTPIPE_OK;
+}
+int octpipe_update_postprocess_background(octpipe_t* h, const float* background, int size) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	if (background && size > 0 && size <= h->N / 2) {
+		int rc = setDevice(h); if (rc) return rc;
+		std::memcpy(h->h_postBg.data(), background, sizeof(float) * (size_t)size);
+		HIP_TRY(hipMemcpyAsync(h->d_postBg, h->h_postBg.data(), sizeof(float) * (size_t)size, hipMemcpyHostToDevice, h->stream));
+		HIP_TRY(hipStreamSynchronize(h->stream));
+	}
+	return OCTPIPE_OK;
+}
+int octpipe_copy_postprocess_background_to_host(octpipe_t* h, float* background, int size) {
+	if (!h || !background || size <= 0 || size > h->N / 2) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(background, h->d_postBg, sizeof(float) * (size_t)size, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return OCTPIPE_OK;
+}
+
+size_t octpipe_calibration_size(const octpipe_t* h) {
+	if (!h) return 0;
+	const size_t N = (size_t)h->N;
+	return sizeof(CalibrationHeader) + sizeof(float) * (N /*resample*/ + N /*dispersion*/ + N /*window*/ + 2 * N /*mean line*/ + N / 2 /*post bg*/);
+}
+int octpipe_export_calibration(octpipe_t* h, void* blob, size_t size) {
+	if (!h || !blob || size < octpipe_calibration_size(h)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "calibration blob too small");
+	int rc = setDevice(h); if (rc) return rc;
+	const size_t N = (size_t)h->N;
+	char* p = static_cast<char*>(blob);
+	CalibrationHeader hd{kCalibMagic, 1u, (uint32_t)h->N, h->fpnDetermined ? 1u : 0u};
+	std::memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
+	std::memcpy(p, h->resample.data(), sizeof(float) * N); p += sizeof(float) * N;
+	std::memcpy(p, h->dispersion.data(), sizeof(float) * N); p += sizeof(float) * N;
+	std::memcpy(p, h->window.data(), sizeof(float) * N); p += sizeof(float) * N;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipMemcpy(p, h->d_meanLine, sizeof(float) * 2 * N, hipMemcpyDeviceToHost)); p += sizeof(float) * 2 * N;
+	HIP_TRY(hipMemcpy(p, h->d_postBg, sizeof(float) * (N / 2), hipMemcpyDeviceToHost));
+	return OCTPIPE_OK;
+}
+int octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size) {
+	if (!h || !blob || size < octpipe_calibration_size(h)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "calibration blob too small");
+	int rc = setDevice(h); if (rc) return rc;
+	const size_t N = (size_t)h->N;
+	const char* p = static_cast<const char*>(blob);
+	CalibrationHeader hd;
+	std::memcpy(&hd, p, sizeof(hd)); p += sizeof(hd);
+	if (hd.magic != kCalibMagic || hd.samplesPerLine != (uint32_t)h->N) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "calibration blob does not match this pipeline");
+	std::memcpy(h->resample.data(), p, sizeof(float) * N); p += sizeof(float) * N;
+	std::memcpy(h->dispersion.data(), p, sizeof(float) * N); p += sizeof(float) * N;
+	std::memcpy(h->window.data(), p, sizeof(float) * N); p += sizeof(float) * N;
+	octhost::dispersive_phase(h->dispersion.data(), (unsigned)h->N, h->phase.data());
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipMemcpy(h->d_meanLine, p, sizeof(float) * 2 * N, hipMemcpyHostToDevice)); p += sizeof(float) * 2 * N;
+	HIP_TRY(hipMemcpy(h->d_postBg, p, sizeof(float) * (N / 2), hipMemcpyHostToDevice));
+	std::memcpy(h->h_postBg.data(), p, sizeof(float) * (N / 2));
+	h->fpnDetermined = hd.fixedPatternNoiseDetermined != 0;
+	h->lutDirty = true;
+	return OCTPIPE_OK;
+}
+
+int octpipe_process(octpipe_t* h, const void* h_inputSignal) {
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	if (!h_inputSignal) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null input buffer");
+	int rc = setDevice(h); if (rc) return rc;
+	const size_t bytes = h->S * (size_t)h->bytesPerSample;
+	const int s = h->slot;
+	h->slot ^= 1;
+	if ((rc = ensure(&h->d_raw[s], bytes))) return rc;
+	// the copy may not overwrite a raw slot the previous fused kernel is still reading
+	if (h->slotUsed[s]) HIP_TRY(hipStreamWaitEvent(h->copyStream, h->slotFree[s], 0));
+	HIP_TRY(hipMemcpyAsync(h->d_raw[s], h_inputSignal, bytes, hipMemcpyHostToDevice, h->copyStream));  // cu:1404
+	HIP_TRY(hipEventRecord(h->h2dDone[s], h->copyStream));
+	HIP_TRY(hipStreamWaitEvent(h->stream, h->h2dDone[s], 0));
+	rc = processDeviceRaw(h, h->d_raw[s]);
+	if (rc) return rc;
+	HIP_TRY(hipEventRecord(h->slotFree[s], h->stream));
+	h->slotUsed[s] = true;
+	// completion contract of the reference (cu:1416-1419): the host buffer is no longer read on return
+	HIP_TRY(hipEventSynchronize(h->h2dDone[s]));
+	return OCTPIPE_OK;
+}
+
+int octpipe_process_device(octpipe_t* h, const void* d_raw) {
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	if (!d_raw) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null input buffer");
+	int rc = setDevice(h); if (rc) return rc;
+	return processDeviceRaw(h, d_raw);
+}
+
+int octpipe_synchronize(octpipe_t* h) {
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->copyStream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return OCTPIPE_OK;
+}
+
+int octpipe_get_processed_device(octpipe_t* h, void** d_processed, size_t* bytes, unsigned* bufferNumberInVolume) {
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	if (d_processed) *d_processed = h->d_processed;
+	if (bytes) *bytes = sizeof(float) * (h->S / 2) * h->acq.buffersPerVolume;
+	if (bufferNumberInVolume) *bufferNumberInVolume = h->bufferNumberInVolume;
+	return OCTPIPE_OK;
+}
+
+int octpipe_copy_processed_to_host(octpipe_t* h, float* dst, size_t count, size_t offset) {
+	if (!h || !dst) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	if (offset + count > (h->S / 2) * h->acq.buffersPerVolume) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "range outside the processed volume");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(dst, h->d_processed + offset, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return OCTPIPE_OK;
+}
+
+int octpipe_get_stream(octpipe_t* h, void** stream) {
+	if (!h || !stream) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*stream = (void*)h->stream;
+	return OCTPIPE_OK;
+}
+int octpipe_set_stream(octpipe_t* h, void* stream) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	if (h->ownStream) HIP_TRY(hipStreamDestroy(h->stream));
+	h->stream = (hipStream_t)stream;
+	h->ownStream = false;
+	return OCTPIPE_OK;
+}
+
+int octpipe_get_mean_line(octpipe_t* h, float* m) {
+	if (!h || !m) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(m, h->d_meanLine, sizeof(f2) * h->N, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return OCTPIPE_OK;
+}
+int octpipe_set_mean_line(octpipe_t* h, const float* m, int pin) {
+	if (!h || !m) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(h->d_meanLine, m, sizeof(f2) * h->N, hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	h->fpnDetermined = true;
+	h->pinMean = pin != 0;
+	return OCTPIPE_OK;
+}
+
+int octpipe_min_variance_mean(octpipe_t* h, const float* data, int isDevice, int width, int height, float* meanOut) {
+	if (!h || !data || !meanOut || width <= 0 || height <= 0) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
+	int rc = setDevice(h); if (rc) return rc;
+	f2* d_in = nullptr;
+	f2* d_out = nullptr;
+	const size_t bytes = sizeof(f2) * (size_t)width * height;
+	if (!isDevice) {
+		HIP_TRY(hipMalloc((void**)&d_in, bytes));
+		HIP_TRY(hipMemcpy(d_in, data, bytes, hipMemcpyHostToDevice));
+	}
+	HIP_TRY(hipMalloc((void**)&d_out, sizeof(f2) * width));
+	if (h->d_segs) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->d_segs)); h->d_segs = nullptr; }
+	rc = ensure((void**)&h->d_segs, sizeof(float4) * 9 * (size_t)std::max(width, h->N));
+	if (!rc) rc = minVarianceMean(h, isDevice ? reinterpret_cast<const f2*>(data) : d_in, width, height, d_out);
+	if (!rc) {
+		hipError_t e = hipMemcpyAsync(meanOut, d_out, sizeof(f2) * width, hipMemcpyDeviceToHost, h->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		if (e != hipSuccess) rc = fail(OCTPIPE_ERR_DEVICE, hipGetErrorString(e));
+	}
+	if (d_in) hipFree(d_in);
+	hipFree(d_out);
+	return rc;
+}
+
+int octpipe_debug_spectrum(octpipe_t* h, const void* d_raw, int lines, float* hostComplexOut) {
+	if (!h || !d_raw || !hostComplexOut || lines <= 0 || lines > h->A * h->B) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
+	int rc = setDevice(h); if (rc) return rc;
+	if (h->lutDirty && (rc = uploadLut(h))) return rc;
+	f2* d_spec = nullptr;
+	HIP_TRY(hipMalloc((void**)&d_spec, sizeof(f2) * (size_t)lines * h->N));
+	rc = launchFused(h, d_raw, (unsigned)lines, true, d_spec, nullptr, false);
+	if (!rc) {
+		hipError_t e = hipMemcpyAsync(hostComplexOut, d_spec, sizeof(f2) * (size_t)lines * h->N, hipMemcpyDeviceToHost, h->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		if (e != hipSuccess) rc = fail(OCTPIPE_ERR_DEVICE, hipGetErrorString(e));
+	}
+	hipFree(d_spec);
+	return rc;
+}
+
+int octpipe_register_streaming_buffers(octpipe_t* h, void* b1, void* b2, size_t bytesPerBuffer) {  // cu:659-666
+	if (!h || !b1 || !b2) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	if (bytesPerBuffer < (h->S / 2) * (size_t)h->bytesPerSample) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "streaming buffers too small");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipHostRegister(b1, bytesPerBuffer, hipHostRegisterPortable));
+	HIP_TRY(hipHostRegister(b2, bytesPerBuffer, hipHostRegisterPortable));
+	h->h_stream[0] = b1; h->h_stream[1] = b2; h->streamBytes = bytesPerBuffer;
+	return OCTPIPE_OK;
+}
+int octpipe_unregister_streaming_buffers(octpipe_t* h) {  // cu:668-675
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	if (h->stream) hipStreamSynchronize(h->stream);
+	for (int i = 0; i < 2; ++i) if (h->h_stream[i]) { hipHostUnregister(h->h_stream[i]); h->h_stream[i] = nullptr; }
+	return OCTPIPE_OK;
+}
+int octpipe_register_float_streaming_buffers(octpipe_t* h, void* b1, void* b2, size_t bytesPerBuffer) {  // cu:677-685
+	if (!h || !b1 || !b2) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	if (bytesPerBuffer < (h->S / 2) * sizeof(float)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "float streaming buffers too small");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipHostRegister(b1, bytesPerBuffer, hipHostRegisterPortable));
+	HIP_TRY(hipHostRegister(b2, bytesPerBuffer, hipHostRegisterPortable));
+	h->h_floatStream[0] = b1; h->h_floatStream[1] = b2; h->floatStreamBytes = bytesPerBuffer;
+	h->floatStreamingRegistered = true;
+	return OCTPIPE_OK;
+}
+int octpipe_unregister_float_streaming_buffers(octpipe_t* h) {  // cu:687-695
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	if (h->stream) hipStreamSynchronize(h->stream);
+	for (int i = 0; i < 2; ++i) if (h->h_floatStream[i]) { hipHostUnregister(h->h_floatStream[i]); h->h_floatStream[i] = nullptr; }
+	h->floatStreamingRegistered = false;
+	return OCTPIPE_OK;
+}
+int octpipe_set_callbacks(octpipe_t* h, octpipe_data_callback onStreamingData, octpipe_data_callback onFloatStreamingData,
+                          octpipe_event_callback onBackgroundRecorded, void* user) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	h->onStreaming = onStreamingData;
+	h->onFloatStreaming = onFloatStreamingData;
+	h->onBackground = onBackgroundRecorded;
+	h->user = user;
+	return OCTPIPE_OK;
+}
+
+int octpipe_change_displayed_bscan_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1223-1240
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	int rc = setDevice(h); if (rc) return rc;
+	return updateBscanDisplay(h, frameNr, frames, fn);
+}
+int octpipe_change_displayed_enface_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1243-1265
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	int rc = setDevice(h); if (rc) return rc;
+	return updateEnFaceDisplay(h, frameNr, frames, fn);
+}
+int octpipe_get_display_buffers(octpipe_t* h, void** d_bscanFrame, size_t* bscanCount, void** d_enFaceFrame, size_t* enFaceCount) {
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	if (d_bscanFrame) *d_bscanFrame = h->d_dispBscan;
+	if (bscanCount) *bscanCount = (size_t)h->N * h->A / 2;
+	if (d_enFaceFrame) *d_enFaceFrame = h->d_dispEnFace;
+	if (enFaceCount) *enFaceCount = (size_t)h->A * h->B * h->acq.buffersPerVolume;
+	return OCTPIPE_OK;
+}
+int octpipe_register_gl_buffer_bscan(unsigned) { return fail(OCTPIPE_ERR_UNSUPPORTED, "no OpenGL interop on a headless MI355X node"); }
+int octpipe_register_gl_buffer_enface_view(unsigned) { return fail(OCTPIPE_ERR_UNSUPPORTED, "no OpenGL interop on a headless MI355X node"); }
+int octpipe_register_gl_buffer_volume_view(unsigned) { return fail(OCTPIPE_ERR_UNSUPPORTED, "no OpenGL interop on a headless MI355X node"); }
+
+int octpipe_enable_kernel_timing(octpipe_t* h, int enable) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	h->timing = enable != 0;
+	return OCTPIPE_OK;
+}
+int octpipe_kernel_timing(octpipe_t* h, double* avgMs, unsigned* launches, int reset) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	int rc = setDevice(h); if (rc) return rc;
+	if ((rc = foldTimings(h))) return rc;
+	if (avgMs) *avgMs = h->timedLaunches ? h->timedMs / h->timedLaunches : 0.0;
+	if (launches) *launches = h->timedLaunches;
+	if (reset) { h->timedMs = 0.0; h->timedLaunches = 0; }
+	return OCTPIPE_OK;
+}
+
+}  // extern "C"

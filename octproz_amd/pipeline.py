@@ -1,0 +1,201 @@
+"""Thin Python handle around the C ABI of the pipeline (include/octpipe.h).
+
+The three calls a user of the reference knows are kept by name:
+    initializeCuda(h_buffer1, h_buffer2, params)   kernels.h:63  -> Pipeline(...)/initializeCuda
+    octCudaPipeline(h_inputSignal)                 kernels.h:64  -> Pipeline.octCudaPipeline
+    cleanupCuda()                                  kernels.h:67  -> Pipeline.cleanupCuda
+Dirty-flag handling follows cu:1433-1445: a curve is pushed to the device when its
+`*Updated` flag is set and the stage is enabled, then the flag is cleared.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .params import OctAlgorithmParameters
+
+
+class Pipeline:
+    def __init__(self, params: OctAlgorithmParameters, device=0, h_buffer1=None, h_buffer2=None):
+        self.params = params
+        self._h = C.c_void_p()
+        self._lib = _lib.lib()
+        acq = params.acquisition()
+        pod = params.pod()
+        self._keep = (h_buffer1, h_buffer2)
+        b1 = h_buffer1.ctypes.data if h_buffer1 is not None else None
+        b2 = h_buffer2.ctypes.data if h_buffer2 is not None else None
+        rc = self._lib.octpipe_create(C.byref(self._h), device, C.byref(acq), C.byref(pod), b1, b2)
+        if rc != 0:
+            msg = self._lib.octpipe_last_error()
+            if self._h:
+                self._lib.octpipe_destroy(self._h)
+                self._h = C.c_void_p()
+            raise _lib.OctPipeError(rc, msg.decode() if msg else "")
+        self.N = int(params.samplesPerLine)
+        self.S = params.samplesPerBuffer
+        self._callbacks = None
+        self._sync_params(force_curves=True)
+
+    # reference-named entry points ------------------------------------------------------------
+    @classmethod
+    def initializeCuda(cls, h_buffer1, h_buffer2, params, device=0):
+        return cls(params, device, h_buffer1, h_buffer2)
+
+    def octCudaPipeline(self, h_inputSignal):
+        self._sync_params()
+        a = np.ascontiguousarray(h_inputSignal)
+        check(self._lib.octpipe_process(self._h, a.ctypes.data))
+
+    def cleanupCuda(self):
+        if self._h:
+            self._lib.octpipe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    close = cleanupCuda
+
+    def __del__(self):
+        try:
+            self.cleanupCuda()
+        except Exception:
+            pass
+
+    # -------------------------------------------------------------------------------------------
+    def _sync_params(self, force_curves=False):
+        p = self.params
+        if p.resampling and (p.resamplingUpdated or force_curves) and p.resampleCurve is not None:
+            c = np.ascontiguousarray(p.resampleCurve, dtype=np.float32)
+            check(self._lib.octpipe_update_resample_curve(self._h, c.ctypes.data, len(c)))
+            p.resamplingUpdated = False
+        if p.dispersionCompensation and (p.dispersionUpdated or force_curves) and p.dispersionCurve is not None:
+            c = np.ascontiguousarray(p.dispersionCurve, dtype=np.float32)
+            check(self._lib.octpipe_update_dispersion_curve(self._h, c.ctypes.data, len(c)))
+            p.dispersionUpdated = False
+        if p.windowing and (p.windowUpdated or force_curves) and p.windowCurve is not None:
+            c = np.ascontiguousarray(p.windowCurve, dtype=np.float32)
+            check(self._lib.octpipe_update_window_curve(self._h, c.ctypes.data, len(c)))
+            p.windowUpdated = False
+        if p.postProcessBackgroundRemoval and p.postProcessBackgroundUpdated and p.postProcessBackground is not None:
+            c = np.ascontiguousarray(p.postProcessBackground, dtype=np.float32)
+            check(self._lib.octpipe_update_postprocess_background(self._h, c.ctypes.data, len(c)))
+            p.postProcessBackgroundUpdated = False
+        pod = p.pod()
+        check(self._lib.octpipe_set_params(self._h, C.byref(pod)))
+        # one-shot requests are consumed by the pipeline (cu:1524, cu:1561)
+        p.redetermineFixedPatternNoise = 0
+        p.postProcessBackgroundRecordingRequested = 0
+
+    def process_device(self, d_raw_ptr, sync_params=True):
+        """Run the chain on a raw buffer already resident in HBM (plain device pointer)."""
+        if sync_params:
+            self._sync_params()
+        check(self._lib.octpipe_process_device(self._h, C.c_void_p(d_raw_ptr)))
+
+    def synchronize(self):
+        check(self._lib.octpipe_synchronize(self._h))
+
+    def processed_device(self):
+        ptr, nbytes, nr = C.c_void_p(), C.c_size_t(), C.c_uint()
+        check(self._lib.octpipe_get_processed_device(self._h, C.byref(ptr), C.byref(nbytes), C.byref(nr)))
+        return ptr.value, nbytes.value, nr.value
+
+    def processed_host(self, slot=None):
+        """float32 [B*A, N/2] of the slot written last (or of `slot`)."""
+        _, _, nr = self.processed_device()
+        if slot is None:
+            slot = nr
+        n = self.S // 2
+        out = np.empty(n, dtype=np.float32)
+        check(self._lib.octpipe_copy_processed_to_host(self._h, out.ctypes.data, n, n * slot))
+        return out
+
+    def stream_ptr(self):
+        s = C.c_void_p()
+        check(self._lib.octpipe_get_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def set_stream(self, stream_ptr):
+        check(self._lib.octpipe_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def mean_line(self):
+        m = np.empty(self.N, dtype=np.complex64)
+        check(self._lib.octpipe_get_mean_line(self._h, m.ctypes.data))
+        return m
+
+    def set_mean_line(self, m, pin=True):
+        m = np.ascontiguousarray(m, dtype=np.complex64)
+        assert m.size == self.N
+        check(self._lib.octpipe_set_mean_line(self._h, m.ctypes.data, 1 if pin else 0))
+
+    def min_variance_mean(self, z, width, height):
+        z = np.ascontiguousarray(z, dtype=np.complex64)
+        out = np.empty(width, dtype=np.complex64)
+        check(self._lib.octpipe_min_variance_mean(self._h, z.ctypes.data, 0, width, height, out.ctypes.data))
+        return out
+
+    def debug_spectrum(self, d_raw_ptr, lines):
+        self._sync_params()
+        out = np.empty(lines * self.N, dtype=np.complex64)
+        check(self._lib.octpipe_debug_spectrum(self._h, C.c_void_p(d_raw_ptr), lines, out.ctypes.data))
+        return out
+
+    def postprocess_background(self):
+        out = np.empty(self.N // 2, dtype=np.float32)
+        check(self._lib.octpipe_copy_postprocess_background_to_host(self._h, out.ctypes.data, self.N // 2))
+        return out
+
+    def export_calibration(self):
+        n = self._lib.octpipe_calibration_size(self._h)
+        blob = np.empty(n, dtype=np.uint8)
+        check(self._lib.octpipe_export_calibration(self._h, blob.ctypes.data, n))
+        return blob
+
+    def import_calibration(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(self._lib.octpipe_import_calibration(self._h, blob.ctypes.data, blob.size))
+
+    def register_streaming_buffers(self, b1, b2):
+        self._stream_keep = (b1, b2)
+        check(self._lib.octpipe_register_streaming_buffers(self._h, b1.ctypes.data, b2.ctypes.data, b1.nbytes))
+
+    def unregister_streaming_buffers(self):
+        check(self._lib.octpipe_unregister_streaming_buffers(self._h))
+
+    def register_float_streaming_buffers(self, b1, b2):
+        self._fstream_keep = (b1, b2)
+        check(self._lib.octpipe_register_float_streaming_buffers(self._h, b1.ctypes.data, b2.ctypes.data, b1.nbytes))
+
+    def unregister_float_streaming_buffers(self):
+        check(self._lib.octpipe_unregister_float_streaming_buffers(self._h))
+
+    def set_callbacks(self, on_streaming=None, on_float_streaming=None, on_background=None):
+        noop_d = lambda *a: None
+        noop_e = lambda *a: None
+        cbs = (_lib.DATA_CALLBACK(on_streaming or noop_d), _lib.DATA_CALLBACK(on_float_streaming or noop_d),
+               _lib.EVENT_CALLBACK(on_background or noop_e))
+        self._callbacks = cbs  # keep alive
+        check(self._lib.octpipe_set_callbacks(self._h, cbs[0], cbs[1], cbs[2], None))
+
+    def change_displayed_bscan_frame(self, frame_nr, frames, fn):
+        check(self._lib.octpipe_change_displayed_bscan_frame(self._h, frame_nr, frames, fn))
+
+    def change_displayed_enface_frame(self, frame_nr, frames, fn):
+        check(self._lib.octpipe_change_displayed_enface_frame(self._h, frame_nr, frames, fn))
+
+    def display_buffers(self):
+        pb, nb, pe, ne = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        check(self._lib.octpipe_get_display_buffers(self._h, C.byref(pb), C.byref(nb), C.byref(pe), C.byref(ne)))
+        return (pb.value, nb.value), (pe.value, ne.value)
+
+    def enable_kernel_timing(self, on=True):
+        check(self._lib.octpipe_enable_kernel_timing(self._h, 1 if on else 0))
+
+    def kernel_timing(self, reset=True):
+        ms, n = C.c_double(), C.c_uint()
+        check(self._lib.octpipe_kernel_timing(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    @property
+    def handle(self):
+        return self._h

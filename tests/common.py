@@ -1,0 +1,95 @@
+"""Shared helpers of the test-suite: build the oracle's parameter block from the product's one,
+drive both pipelines on the same input, and the tolerance policy.
+
+Tolerances (DESIGN.md "Parity policy"; BASELINE.json: 1e-4 relative float tolerance, bit-exact
+integer stages):
+  * integer / index stages (unpack, flip map, quantised output given identical float input): exact
+  * host curves: bit-exact
+  * complex spectrum after the inverse FFT: |delta| <= SPECTRUM_RTOL * max|spectrum of that A-scan|
+  * final image, linear-power domain: |delta P| <= POWER_RTOL * max(P of that A-scan)
+  * final image, normalised-dB domain (log scaling): checked on bins whose power is above
+    DB_FLOOR * line maximum, |delta| <= DB_ATOL
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import octref  # noqa: E402  (test infrastructure)
+
+SPECTRUM_RTOL = 1e-5
+POWER_RTOL = 1e-4
+DB_ATOL = 5e-4
+DB_FLOOR = 1e-6
+
+
+def oracle_params(p):
+    """octref.Params from an octproz_amd.OctAlgorithmParameters"""
+    o = octref.Params()
+    for name, _ in octref.Params._fields_:
+        setattr(o, name, type(getattr(o, name))(getattr(p, name)))
+    return o
+
+
+def make_oracle(p):
+    """Oracle pipeline initialised like initializeCuda + the dirty-flag uploads of cu:1433-1445."""
+    o = octref.Pipeline(oracle_params(p))
+    if p.resampling and p.resampleCurve is not None:
+        o.update_resample_curve(p.resampleCurve)
+    if p.dispersionCompensation and p.dispersionCurve is not None:
+        o.update_dispersion_curve(p.dispersionCurve)
+    if p.windowing and p.windowCurve is not None:
+        o.update_window_curve(p.windowCurve)
+    if p.postProcessBackgroundRemoval and p.postProcessBackground is not None:
+        o.update_postproc_background(p.postProcessBackground)
+    return o
+
+
+def image_to_power(v, p):
+    """Invert the grayscale mapping of cu:718 / cu:739 back to |z|^2 (float64)."""
+    v = v.astype(np.float64)
+    half = p.samplesPerLine / 2
+    rng = float(p.signalGrayscaleMax) - float(p.signalGrayscaleMin)
+    t = (v / float(p.signalMultiplicator) - float(p.signalAddend)) * rng + float(p.signalGrayscaleMin)
+    if p.signalLogScaling:
+        return half * 10.0 ** (t / 10.0)
+    return (t * half) ** 2
+
+
+def compare_images(got, want, p, what=""):
+    """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima."""
+    half = int(p.samplesPerLine) // 2
+    g = got.reshape(-1, half)
+    w = want.reshape(-1, half)
+    assert g.shape == w.shape
+    # identical non-finite pattern (log(0) = -inf must appear in the same places)
+    assert np.array_equal(np.isfinite(g), np.isfinite(w)), what + ": non-finite pattern differs"
+    fin = np.isfinite(w)
+    pg = np.where(fin, image_to_power(np.where(fin, g, 0), p), 0.0)
+    pw = np.where(fin, image_to_power(np.where(fin, w, 0), p), 0.0)
+    line_max = pw.max(axis=1, keepdims=True)
+    line_max[line_max == 0] = 1.0
+    rel = np.abs(pg - pw) / line_max
+    max_rel = float(rel.max())
+    assert max_rel <= POWER_RTOL, "%s: linear-power error %.3e > %.1e" % (what, max_rel, POWER_RTOL)
+    max_db = 0.0
+    if p.signalLogScaling:
+        strong = fin & (pw > DB_FLOOR * line_max)
+        if strong.any():
+            max_db = float(np.abs(g[strong].astype(np.float64) - w[strong]).max())
+            assert max_db <= DB_ATOL, "%s: normalised-dB error %.3e > %.1e" % (what, max_db, DB_ATOL)
+    return max_rel, max_db
+
+
+def compare_spectra(got, want, n, what=""):
+    g = got.reshape(-1, n).astype(np.complex128)
+    w = want.reshape(-1, n).astype(np.complex128)
+    scale = np.abs(w).max(axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    err = float((np.abs(g - w) / scale).max())
+    assert err <= SPECTRUM_RTOL, "%s: spectrum error %.3e > %.1e" % (what, err, SPECTRUM_RTOL)
+    return err
