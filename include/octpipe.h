@@ -175,8 +175,14 @@ int octpipe_get_mean_line(octpipe_t* h, float* meanLineComplex /* 2*N floats */)
 int octpipe_set_mean_line(octpipe_t* h, const float* meanLineComplex /* 2*N floats */, int pin);
 /* run only getMinimumVarianceMean (cu:523-565) on a caller-supplied complex buffer [height][width] */
 int octpipe_min_variance_mean(octpipe_t* h, const float* d_or_h_complex, int isDevice, int width, int height, float* meanOutComplex);
-/* complex spectrum after IDFT of the first `lines` A-scans of the last processed raw buffer */
+/* complex spectrum after IDFT (before mean subtraction) of the first `lines` A-scans of d_raw */
 int octpipe_debug_spectrum(octpipe_t* h, const void* d_raw, int lines, float* hostComplexOut);
+/* raw unpack (+ bitshift, + rolling average when enabled) of the first `count` samples of d_raw as
+ * float32: the stage of cu:109-211 in isolation, for the bit-exactness test */
+int octpipe_debug_unpack(octpipe_t* h, const void* d_raw, size_t count, float* hostOut);
+/* route uint16 input through the float32 "prepared" path as well (normally only uint8/uint32 input
+ * and the Lanczos variant take it); lets a test prove fused-unpack == standalone unpack bit-for-bit */
+int octpipe_debug_force_prepared(octpipe_t* h, int enable);
 
 /* ------------------------------------------------------------------ result delivery
  * cuda_registerStreamingBuffers / cuda_unregisterStreamingBuffers (kernels.h:69-70, cu:659-675)

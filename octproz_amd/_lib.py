@@ -78,6 +78,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_process", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
     "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_debug_spectrum",
+    "octpipe_debug_unpack", "octpipe_debug_force_prepared",
     "octpipe_register_streaming_buffers", "octpipe_unregister_streaming_buffers",
     "octpipe_register_float_streaming_buffers", "octpipe_unregister_float_streaming_buffers",
     "octpipe_set_callbacks",
@@ -154,6 +155,8 @@ def lib():
         L.octpipe_copy_processed_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.octpipe_min_variance_mean.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.octpipe_debug_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.octpipe_debug_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.octpipe_debug_force_prepared.argtypes = [C.c_void_p, C.c_int]
         L.octpipe_register_streaming_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.octpipe_register_float_streaming_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.octpipe_set_callbacks.argtypes = [C.c_void_p, DATA_CALLBACK, DATA_CALLBACK, EVENT_CALLBACK, C.c_void_p]

@@ -332,7 +332,9 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, OCT_MIN_WAVES_PE
 		} else {
 			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
 			unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
-			if (a.flip && (b & 1u) == 0u) as = a.ascansPerBscan - 1u - as;
+			// even buffer-local B-scans are mirrored; the reference's launch covers S/4 indices
+			// (cu:1547), so with an odd B-scan count the last one is left as it is
+			if (a.flip && (b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) as = a.ascansPerBscan - 1u - as;
 			float* dst = a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2) + lane;
 			const f2* ml = a.meanLine + lane;
 #pragma unroll

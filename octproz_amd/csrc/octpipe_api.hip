@@ -83,6 +83,7 @@ struct octpipe {
 	unsigned bufferNumberInVolume = 0;
 	bool fpnDetermined = false;
 	bool pinMean = false;
+	bool forcePrepared = false;
 	unsigned streamedBuffers = 0, streamingBufferNumber = 0, floatStreamingBufferNumber = 0;
 
 	void* h_buffer[2] = {nullptr, nullptr};
@@ -185,7 +186,7 @@ int ensure(void** p, size_t bytes) {
 }
 
 bool needsPrepared(const octpipe* h) {
-	return h->bytesPerSample != 2 || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
+	return h->forcePrepared || h->bytesPerSample != 2 || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
 }
 
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
@@ -481,7 +482,12 @@ int octpipe_set_params(octpipe_t* h, const OctPipeParams* params) {
 	const OctPipeParams& o = h->params;
 	if (o.resampling != params->resampling || o.windowing != params->windowing || o.dispersionCompensation != params->dispersionCompensation)
 		h->lutDirty = true;
+	// one-shot requests stay pending until the pipeline has consumed them (cu:1524, cu:1561),
+	// even if the caller's next snapshot no longer carries them
+	const int pendingRedetermine = o.redetermineFixedPatternNoise, pendingRecord = o.postProcessBackgroundRecordingRequested;
 	h->params = *params;
+	h->params.redetermineFixedPatternNoise |= pendingRedetermine;
+	h->params.postProcessBackgroundRecordingRequested |= pendingRecord;
 	return OCTPIPE_OK;
 }
 
@@ -699,6 +705,27 @@ int octpipe_debug_spectrum(octpipe_t* h, const void* d_raw, int lines, float* ho
 	}
 	hipFree(d_spec);
 	return rc;
+}
+
+int octpipe_debug_unpack(octpipe_t* h, const void* d_raw, size_t count, float* hostOut) {
+	if (!h || !d_raw || !hostOut || count == 0 || count > h->S || count % (size_t)h->N) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
+	int rc = setDevice(h); if (rc) return rc;
+	float* d_tmp = nullptr;
+	HIP_TRY(hipMalloc((void**)&d_tmp, sizeof(float) * count));
+	const OctPipeParams& p = h->params;
+	hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(count)), dim3(256), 0, h->stream, d_raw, d_tmp, (int)h->acq.bitDepth,
+	                   p.bitshift, p.backgroundRemoval ? p.rollingAverageWindowSize : 0, h->N, count);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(hostOut, d_tmp, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	hipFree(d_tmp);
+	if (e != hipSuccess) return fail(OCTPIPE_ERR_DEVICE, hipGetErrorString(e));
+	return OCTPIPE_OK;
+}
+int octpipe_debug_force_prepared(octpipe_t* h, int enable) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	h->forcePrepared = enable != 0;
+	return OCTPIPE_OK;
 }
 
 int octpipe_register_streaming_buffers(octpipe_t* h, void* b1, void* b2, size_t bytesPerBuffer) {  // cu:659-666

@@ -140,6 +140,15 @@ class Pipeline:
         check(self._lib.octpipe_debug_spectrum(self._h, C.c_void_p(d_raw_ptr), lines, out.ctypes.data))
         return out
 
+    def debug_unpack(self, d_raw_ptr, count):
+        self._sync_params()
+        out = np.empty(count, dtype=np.float32)
+        check(self._lib.octpipe_debug_unpack(self._h, C.c_void_p(d_raw_ptr), count, out.ctypes.data))
+        return out
+
+    def debug_force_prepared(self, on=True):
+        check(self._lib.octpipe_debug_force_prepared(self._h, 1 if on else 0))
+
     def postprocess_background(self):
         out = np.empty(self.N // 2, dtype=np.float32)
         check(self._lib.octpipe_copy_postprocess_background_to_host(self._h, out.ctypes.data, self.N // 2))

@@ -1,0 +1,80 @@
+"""The C ABI: liboctpipe.so loads on a machine without a GPU, exports every symbol the public
+headers declare, and fails loudly (no CPU fallback) when asked to compute without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from octproz_amd import _lib
+from octproz_amd.params import OctAlgorithmParameters, v180_benchmark_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s_[a-z0-9_]+)\s*\(" % prefix, txt)))
+
+
+def test_library_loads_and_reports_abi_version():
+    L = _lib.lib()
+    assert L.octpipe_abi_version() == 1
+
+
+@pytest.mark.parametrize("header,prefix,listed", [("octpipe.h", "octpipe", _lib.OCTPIPE_SYMBOLS),
+                                                  ("octhost.h", "octhost", _lib.OCTHOST_SYMBOLS)])
+def test_every_declared_symbol_is_exported(header, prefix, listed):
+    L = _lib.lib()
+    names = declared(header, prefix)
+    names = [n for n in names if not n.endswith("_callback") and not n.endswith("_fn") and not n.endswith("_t")]
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "declared in include/%s but not exported: %s" % (header, n)
+    assert sorted(listed) == names, "python symbol list out of date with include/%s" % header
+
+
+def test_struct_layouts_match_header_sizes():
+    # 33 x 4-byte fields, no padding; 5 x uint32
+    assert C.sizeof(_lib.PipeParams) == 33 * 4
+    assert C.sizeof(_lib.AcquisitionParams) == 5 * 4
+
+
+def test_gl_interop_entry_points_always_fail():
+    L = _lib.lib()
+    for f in (L.octpipe_register_gl_buffer_bscan, L.octpipe_register_gl_buffer_enface_view, L.octpipe_register_gl_buffer_volume_view):
+        assert f(3) == 5  # OCTPIPE_ERR_UNSUPPORTED
+
+
+def test_invalid_arguments_are_status_codes_not_crashes():
+    L = _lib.lib()
+    assert L.octpipe_resample_curve(0.0, 1.0, 0.0, 0.0, 1024, None) == 1
+    assert L.octpipe_window_curve(9, 0.5, 0.9, 16, np.zeros(16, np.float32).ctypes.data) == 1
+    assert L.octpipe_process(None, None) == 2  # NOT_INITIALIZED, cf. cu:1391-1394
+    assert L.octpipe_destroy(None) == 0
+
+
+def _gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_gpu(), reason="only meaningful without a GPU")
+def test_no_cpu_fallback_without_device():
+    """The product path must fail loudly when no HIP device exists."""
+    from octproz_amd import OctPipeError, Pipeline
+    with pytest.raises(OctPipeError) as e:
+        Pipeline(v180_benchmark_params(1024, 8, 2))
+    assert e.value.code in (6, 4)  # NO_DEVICE (or a HIP runtime error)
+
+
+def test_unsupported_length_is_reported():
+    L = _lib.lib()
+    h = C.c_void_p()
+    acq = _lib.AcquisitionParams(1000, 8, 2, 1, 12)
+    p = OctAlgorithmParameters().pod()
+    rc = L.octpipe_create(C.byref(h), 0, C.byref(acq), C.byref(p), None, None)
+    assert rc == 5 and not h.value
+    assert b"samplesPerLine" in L.octpipe_last_error()

@@ -1,0 +1,475 @@
+"""Parity of the HIP path (through the C ABI of liboctpipe.so) against the CPU oracle.
+Every test here needs a real MI355X:  python -m pytest tests -m gpu
+
+The fixed-pattern-noise mean line is ill-conditioned in float32 (hard part 2):
+end-to-end comparisons pin it (oracle's mean line is given to both sides); the estimator itself is
+tested separately on identical complex input, where it must agree bit-for-bit.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import common
+from oracle import octref
+from octproz_amd import INTERPOLATION, Pipeline, WindowType, synthetic_raw, v180_benchmark_params
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_oracle.npz"))
+
+
+def to_device(raw):
+    import torch
+    a = np.ascontiguousarray(raw)
+    view = {np.dtype(np.uint8): np.uint8, np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}[a.dtype]
+    return torch.from_numpy(a.view(view)).to("cuda:0")
+
+
+def run_both(p, raw, pin=True):
+    """oracle image, gpu image (+ handles still open)"""
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    pipe = Pipeline(p, device=0)
+    if pin and p.fixedPatternNoiseRemoval:
+        pipe.set_mean_line(o.mean_line(), pin=True)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    got = pipe.processed_host()
+    return o, pipe, d, want, got
+
+
+# ------------------------------------------------------------------ integer stages: bit-exact
+@pytest.mark.parametrize("bits,dtype", [(8, np.uint8), (12, np.uint16), (16, np.uint16), (24, np.uint32), (32, np.uint32)])
+@pytest.mark.parametrize("bitshift", [0, 1])
+def test_unpack_bit_exact(bits, dtype, bitshift):
+    N, A, B = 256, 8, 2
+    rng = np.random.default_rng(bits + bitshift)
+    hi = min(2 ** bits, 2 ** 32) - 1
+    raw = rng.integers(0, hi, size=(B, A, N), endpoint=True, dtype=np.uint64).astype(dtype)
+    raw.reshape(-1)[:3] = [0, hi, 1]
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth, p.bitshift = bits, bitshift
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    got = pipe.debug_unpack(d.data_ptr(), raw.size)
+    want = octref.unpack(raw, bits, bitshift).real
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    pipe.close()
+
+
+def test_fused_unpack_equals_standalone_unpack_bitwise():
+    """the uint16 -> float conversion inside the fused kernel is the same map as the standalone
+    unpack kernel (pinned bit-exactly above): both routes must give identical images"""
+    N, A, B = 1024, 12, 2
+    raw = synthetic_raw(N, A, B, seed=4)
+    raw[0, 0, :8] = [0, 1, 4095, 65535, 32768, 2, 3, 4]
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth = 16
+    o, pipe, d, want, got = run_both(p, raw)
+    pipe.debug_force_prepared(True)
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    got2 = pipe.processed_host()
+    assert np.array_equal(got.view(np.uint32), got2.view(np.uint32))
+    common.compare_images(got, want, p, "u16 full range")
+    pipe.close(); o.close()
+
+
+@pytest.mark.parametrize("B", [2, 5, 6])
+def test_flip_index_map_bit_exact(B):
+    """flip is folded into the store address: flipped output == index-mapped unflipped output, exactly"""
+    N, A = 512, 10
+    raw = synthetic_raw(N, A, B, seed=B)
+    p = v180_benchmark_params(N, A, B)
+    o, pipe, d, want0, got0 = run_both(p, raw)
+    p.bscanFlip = 1
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    got1 = pipe.processed_host()
+    assert np.array_equal(got1, octref.bscan_flip(got0, N // 2, A))
+    pipe.close(); o.close()
+
+
+# ------------------------------------------------------------------ whole chain vs oracle
+def mutate(**kw):
+    def f(p):
+        for k, v in kw.items():
+            setattr(p, k, v)
+    return f
+
+
+CASES = {
+    "v180": mutate(),
+    "linear": mutate(resamplingInterpolation=INTERPOLATION.LINEAR),
+    "lanczos": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS),
+    "no_dispersion": mutate(dispersionCompensation=0),
+    "no_window": mutate(windowing=0),
+    "resample_only": mutate(windowing=0, dispersionCompensation=0),
+    "window_dispersion_only": mutate(resampling=0),
+    "nothing": mutate(windowing=0, dispersionCompensation=0, resampling=0),
+    "rolling8": mutate(backgroundRemoval=1, rollingAverageWindowSize=8),
+    "rolling64_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=64, resamplingInterpolation=INTERPOLATION.LINEAR),
+    "rolling_lanczos": mutate(backgroundRemoval=1, rollingAverageWindowSize=5, resamplingInterpolation=INTERPOLATION.LANCZOS),
+    "lin_scale": mutate(signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
+    "scale_coeff_addend": mutate(signalMultiplicator=2.5, signalAddend=-0.25, signalGrayscaleMax=80.0, signalGrayscaleMin=10.0),
+    "flip": mutate(bscanFlip=1),
+    "flip_sinus": mutate(bscanFlip=1, sinusoidalScanCorrection=1),
+    "no_fpn": mutate(fixedPatternNoiseRemoval=0),
+    "gauss_window": mutate(window=WindowType.Gauss, windowFillFactor=0.4, windowCenter=0.45),
+    "flattop_window": mutate(window=WindowType.FlatTop, windowFillFactor=0.8),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_chain_matches_oracle(case):
+    N, A, B = 1024, 24, 3
+    p = v180_benchmark_params(N, A, B)
+    CASES[case](p)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=31)
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, case)
+    if not p.bscanFlip and not p.sinusoidalScanCorrection:
+        spec = pipe.debug_spectrum(d.data_ptr(), A * B)
+        # oracle spectrum = after mean subtraction; add the mean back on the half it touched
+        ospec = o.last_spectrum().reshape(-1, N).copy()
+        if p.fixedPatternNoiseRemoval:
+            ospec[:, :N // 2] += o.mean_line()[:N // 2]
+        common.compare_spectra(spec, ospec, N, case)
+    pipe.close(); o.close()
+
+
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+def test_every_supported_length(N):
+    A, B = 7, 3  # ragged: 21 A-scans, not a multiple of the waves per workgroup
+    p = v180_benchmark_params(N, A, B)
+    raw = synthetic_raw(N, A, B, seed=N)
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "N=%d" % N)
+    pipe.close(); o.close()
+
+
+@pytest.mark.parametrize("bits,dtype", [(8, np.uint8), (32, np.uint32)])
+def test_other_container_types(bits, dtype):
+    N, A, B = 512, 8, 2
+    rng = np.random.default_rng(bits)
+    base = synthetic_raw(N, A, B, seed=2).astype(np.float64) / 4095.0
+    raw = (base * (255 if bits == 8 else 2 ** 20)).astype(dtype)
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth = bits
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "bits=%d" % bits)
+    pipe.close(); o.close()
+
+
+@pytest.mark.parametrize("tag", ["v180", "linear", "lanczos", "lin_scale", "v100", "rolling_flip_sinus"])
+def test_committed_golden_vectors(tag):
+    N, A, B = 1024, 16, 2
+    raw = GOLD["raw"]
+    p = v180_benchmark_params(N, A, B)
+    if tag == "linear":
+        p.resamplingInterpolation = INTERPOLATION.LINEAR
+    elif tag == "lanczos":
+        p.resamplingInterpolation = INTERPOLATION.LANCZOS
+    elif tag == "lin_scale":
+        p.signalLogScaling, p.signalGrayscaleMax, p.signalGrayscaleMin = 0, 900.0, 0.0
+    elif tag == "v100":
+        p.bitshift, p.bscanFlip, p.resamplingInterpolation = 1, 1, INTERPOLATION.LINEAR
+        raw = (raw << 4).astype(np.uint16)
+    elif tag == "rolling_flip_sinus":
+        p.backgroundRemoval, p.rollingAverageWindowSize, p.sinusoidalScanCorrection, p.bscanFlip = 1, 8, 1, 1
+    p.update_all_curves()
+    pipe = Pipeline(p, device=0)
+    pipe.set_mean_line(GOLD["mean_" + tag], pin=True)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    common.compare_images(pipe.processed_host(), GOLD["img_" + tag], p, tag)
+    pipe.close()
+
+
+def test_zero_input_gives_minus_infinity_like_the_reference():
+    p = v180_benchmark_params(256, 4, 2)
+    p.fixedPatternNoiseRemoval = 0
+    raw = np.zeros((2, 4, 256), dtype=np.uint16)
+    o, pipe, d, want, got = run_both(p, raw)
+    assert np.all(np.isneginf(got)) and np.all(np.isneginf(want))
+    pipe.close(); o.close()
+
+
+# ------------------------------------------------------------------ fixed-pattern-noise estimator
+@pytest.mark.parametrize("width,height", [(1024, 512), (512, 36), (256, 20), (64, 7)])
+def test_min_variance_mean_bit_exact_on_identical_input(width, height):
+    rng = np.random.default_rng(width + height)
+    z = (rng.normal(size=(height, width)) * 50 + 1000 * np.cos(np.arange(width) * 0.01)[None, :]
+         + 1j * rng.normal(size=(height, width)) * 50).astype(np.complex64)
+    p = v180_benchmark_params(1024, 8, 2)
+    pipe = Pipeline(p, device=0)
+    got = pipe.min_variance_mean(z, width, height)
+    want = octref.min_variance_mean(z, width, height)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    pipe.close()
+
+
+def test_fpn_determination_end_to_end():
+    """unpinned: the GPU determines its own mean line from its own spectrum.  It must agree with the
+    oracle's wherever the selection is well conditioned, and the 'once' / 'redetermine' /
+    'continuous' state machine (cu:1521-1525) must behave like the oracle's."""
+    N, A, B = 1024, 64, 2
+    p = v180_benchmark_params(N, A, B)
+    raw1 = synthetic_raw(N, A, B, seed=8)
+    raw2 = synthetic_raw(N, A, B, seed=9)
+    o = common.make_oracle(p)
+    o.process(raw1)
+    pipe = Pipeline(p, device=0)
+    d1, d2 = to_device(raw1), to_device(raw2)
+    pipe.process_device(d1.data_ptr())
+    m_gpu, m_cpu = pipe.mean_line(), o.mean_line()
+    scale = np.abs(o.last_spectrum().reshape(-1, N)[:A] + 0).max(axis=0)[:N // 2] + np.abs(m_cpu[:N // 2])
+    close = np.abs(m_gpu[:N // 2] - m_cpu[:N // 2]) <= 1e-4 * scale
+    assert close.mean() > 0.97, "mean line differs in %.1f%% of the bins" % (100 * (1 - close.mean()))
+    # 'once': a second buffer must not change the mean line
+    pipe.process_device(d2.data_ptr())
+    assert np.array_equal(pipe.mean_line().view(np.uint32), m_gpu.view(np.uint32))
+    # one-shot redetermination
+    p.redetermineFixedPatternNoise = 1
+    pipe.process_device(d2.data_ptr())
+    m2 = pipe.mean_line()
+    assert not np.array_equal(m2.view(np.uint32), m_gpu.view(np.uint32))
+    pipe.process_device(d1.data_ptr())  # flag was consumed: unchanged again
+    assert np.array_equal(pipe.mean_line().view(np.uint32), m2.view(np.uint32))
+    # continuous
+    p.continuousFixedPatternNoiseDetermination = 1
+    pipe.process_device(d1.data_ptr())
+    assert np.array_equal(pipe.mean_line().view(np.uint32), m_gpu.view(np.uint32))
+    pipe.close(); o.close()
+
+
+# ------------------------------------------------------------------ post-processing legs
+def test_postprocess_background_record_and_remove():
+    N, A, B = 512, 16, 2
+    p = v180_benchmark_params(N, A, B)
+    p.signalGrayscaleMax, p.signalGrayscaleMin = 110.0, 20.0
+    p.postProcessBackgroundRemoval, p.postProcessBackgroundRecordingRequested = 1, 1
+    p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 0.9, 0.01
+    raw = synthetic_raw(N, A, B, seed=12)
+    fired = threading.Event()
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    pipe = Pipeline(p, device=0)
+    pipe.set_callbacks(on_background=lambda user: fired.set())
+    pipe.set_mean_line(o.mean_line(), pin=True)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    got = pipe.processed_host()
+    assert fired.wait(5.0), "backgroundRecorded callback (gpu2hostnotifier.cpp:57) did not fire"
+    bg_gpu, bg_cpu = pipe.postprocess_background(), o.postproc_background()
+    assert np.abs(bg_gpu - bg_cpu).max() < 5e-4
+    assert got.min() >= 0.0 and got.max() <= 1.0  # the only clamp of the float path (cu:765)
+    assert np.abs(got - want).max() < 1e-3
+    # an uploaded background replaces the recorded one
+    p.loadPostProcessingBackground(np.linspace(0, 0.5, N // 2, dtype=np.float32))
+    oo = common.make_oracle(p); oo.set_mean_line(o.mean_line())
+    want2 = oo.process(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    assert np.abs(pipe.processed_host() - want2).max() < 1e-3
+    pipe.close(); o.close(); oo.close()
+
+
+@pytest.mark.parametrize("bits", [8, 12, 16])
+def test_streaming_quantised_and_float_with_callbacks(bits):
+    """host-loop entry point octpipe_process + streamProcessedData / streamProcessedFloatData
+    (cu:1357-1386): alternating host buffers starting with the second, 7-argument callback,
+    quantisation == oracle's floatToOutput of the GPU's own float image (integer-exact)."""
+    N, A, B = 512, 8, 2
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth = bits
+    p.signalGrayscaleMax, p.signalGrayscaleMin = 110.0, 20.0
+    p.streamToHost, p.streamFloatToHost, p.streamingBuffersToSkip = 1, 1, 0
+    dtype = np.uint8 if bits <= 8 else np.uint16
+    raw = (synthetic_raw(N, A, B, seed=5) >> (4 if bits == 8 else 0)).astype(dtype)
+    pipe = Pipeline(p, device=0)
+    S2 = N * A * B // 2
+    qb = [np.zeros(S2, dtype=dtype), np.zeros(S2, dtype=dtype)]
+    fb = [np.zeros(S2, dtype=np.float32), np.zeros(S2, dtype=np.float32)]
+    pipe.register_streaming_buffers(qb[0], qb[1])
+    pipe.register_float_streaming_buffers(fb[0], fb[1])
+    events = []
+    lock = threading.Lock()
+
+    def on_q(buf, bit_depth, spl, lines, frames, bpv, nr, user):
+        with lock:
+            events.append(("q", buf, bit_depth, spl, lines, frames, bpv, nr))
+
+    def on_f(buf, bit_depth, spl, lines, frames, bpv, nr, user):
+        with lock:
+            events.append(("f", buf, bit_depth, spl, lines, frames, bpv, nr))
+    pipe.set_callbacks(on_streaming=on_q, on_float_streaming=on_f)
+    for _ in range(3):
+        pipe.octCudaPipeline(raw)
+    pipe.synchronize()
+    q_ev = [e for e in events if e[0] == "q"]
+    f_ev = [e for e in events if e[0] == "f"]
+    assert len(q_ev) == 3 and len(f_ev) == 3
+    assert [e[1] for e in q_ev] == [qb[1].ctypes.data, qb[0].ctypes.data, qb[1].ctypes.data]  # cu:1360-1361
+    assert q_ev[0][2:] == (bits, N // 2, A, B, 1, 0)
+    img = pipe.processed_host()
+    assert np.array_equal(fb[1], img)
+    assert np.array_equal(qb[1], octref.float_to_output(img, bits))
+    pipe.unregister_streaming_buffers(); pipe.unregister_float_streaming_buffers()
+    pipe.close()
+
+
+def test_streaming_skip_counter():
+    N, A, B = 256, 4, 2
+    p = v180_benchmark_params(N, A, B)
+    p.streamToHost, p.streamingBuffersToSkip = 1, 2
+    raw = synthetic_raw(N, A, B, seed=6)
+    pipe = Pipeline(p, device=0)
+    S2 = N * A * B // 2
+    b1, b2 = np.zeros(S2, np.uint16), np.zeros(S2, np.uint16)
+    pipe.register_streaming_buffers(b1, b2)
+    n = []
+    pipe.set_callbacks(on_streaming=lambda *a: n.append(1))
+    for _ in range(7):
+        pipe.octCudaPipeline(raw)
+    pipe.synchronize()
+    assert len(n) == 3  # buffers 0, 3, 6 (cu:1358)
+    pipe.unregister_streaming_buffers()
+    pipe.close()
+
+
+def test_display_frames_match_oracle_given_same_volume():
+    import torch
+    N, A, B = 256, 6, 4
+    p = v180_benchmark_params(N, A, B)
+    p.bscanViewEnabled, p.enFaceViewEnabled = 1, 1
+    p.frameNr, p.frameNrEnFaceView = 2, 17
+    raw = synthetic_raw(N, A, B, seed=3)
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    vol = pipe.processed_host()
+    (pb, nb), (pe, ne) = pipe.display_buffers()
+
+    def fetch(ptr, n):
+        out = np.empty(n, dtype=np.float32)
+        import ctypes
+        from octproz_amd import _lib
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(4 * n), 2) == 0
+        return out
+    assert nb == N // 2 * A and ne == A * B
+    assert np.array_equal(fetch(pb, nb), octref.display_bscan(vol, B, nb, 2, 0, 0))
+    assert np.array_equal(fetch(pe, ne), octref.display_enface(vol, N // 2, ne, 17, 0, 0))
+    for frames, fn in ((3, 0), (3, 1), (9, 0)):
+        pipe.change_displayed_bscan_frame(1, frames, fn)
+        pipe.change_displayed_enface_frame(120, frames, fn)
+        pipe.synchronize()
+        np.testing.assert_allclose(fetch(pb, nb), octref.display_bscan(vol, B, nb, 1, frames, fn), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(fetch(pe, ne), octref.display_enface(vol, N // 2, ne, 120, frames, fn), rtol=1e-6, atol=1e-6)
+    pipe.close()
+
+
+def test_buffers_per_volume_slot_rotation():
+    N, A, B = 256, 4, 2
+    p = v180_benchmark_params(N, A, B, buffers_per_volume=3)
+    raws = [synthetic_raw(N, A, B, seed=40 + i) for i in range(4)]
+    o = common.make_oracle(p)
+    pipe = Pipeline(p, device=0)
+    first = o.process(raws[0])
+    pipe.set_mean_line(o.mean_line(), pin=True)
+    for i, r in enumerate(raws):
+        d = to_device(r)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        _, _, nr = pipe.processed_device()
+        assert nr == i % 3  # starts at buffersPerVolume-1, incremented before use (cu:1146, cu:1530-1535)
+        want = first if i == 0 else o.process(r)
+        common.compare_images(pipe.processed_host(), want, p, "buffer %d" % i)
+    pipe.close(); o.close()
+
+
+def test_host_entry_point_equals_device_entry_point():
+    N, A, B = 1024, 8, 2
+    p = v180_benchmark_params(N, A, B)
+    raw = synthetic_raw(N, A, B, seed=77)
+    ring = [raw.copy(), raw.copy()]
+    pipe = Pipeline.initializeCuda(ring[0], ring[1], p)  # pins both ring slots like cu:1135-1136
+    pipe.octCudaPipeline(ring[0]); pipe.synchronize()
+    a = pipe.processed_host()
+    m = pipe.mean_line()
+    d = to_device(raw)
+    pipe2 = Pipeline(p, device=0)
+    pipe2.set_mean_line(m, pin=True)
+    pipe2.process_device(d.data_ptr()); pipe2.synchronize()
+    assert np.array_equal(a.view(np.uint32), pipe2.processed_host().view(np.uint32))
+    pipe.cleanupCuda(); pipe2.cleanupCuda()
+
+
+def test_calibration_blob_round_trip():
+    N, A, B = 512, 16, 2
+    p = v180_benchmark_params(N, A, B)
+    raw = synthetic_raw(N, A, B, seed=13)
+    d = to_device(raw)
+    a = Pipeline(p, device=0)
+    a.process_device(d.data_ptr()); a.synchronize()
+    blob = a.export_calibration()
+    q = v180_benchmark_params(N, A, B)
+    q.c0 = q.c1 = q.c2 = q.c3 = 0.0  # second pipeline starts with different curves
+    q.update_all_curves()
+    b = Pipeline(q, device=0)
+    b.import_calibration(blob)
+    b.process_device(d.data_ptr(), sync_params=False); b.synchronize()
+    assert np.array_equal(a.processed_host().view(np.uint32), b.processed_host().view(np.uint32))
+    a.close(); b.close()
+
+
+# ------------------------------------------------------------------ full size (BASELINE configs 2 and 3)
+def _full_size(N, A, B, sample_lines=192):
+    """size-independent properties at full size + the oracle on a sample of whole B-scans"""
+    import torch
+    from octproz_amd.virtual_oct import synthetic_raw_torch
+    p = v180_benchmark_params(N, A, B)
+    d = synthetic_raw_torch(N, A, B, torch.device("cuda:0"), seed=99)
+    pipe = Pipeline(p, device=0)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    mean = pipe.mean_line()
+    full = pipe.processed_host().reshape(B, A, N // 2)
+    assert np.isfinite(full).all()
+    # (1) sharded == unsharded, bit for bit: process the two halves as separate buffers (even slab size
+    #     keeps the flip parity; mean line pinned) -- this is the multi-GPU partitioning property
+    ph = v180_benchmark_params(N, A, B // 2)
+    half = Pipeline(ph, device=0)
+    half.set_mean_line(mean, pin=True)
+    for k in range(2):
+        half.process_device(d.data_ptr() + k * (B // 2) * A * N * 2); half.synchronize()
+        assert np.array_equal(half.processed_host().view(np.uint32), full[k * B // 2:(k + 1) * B // 2].reshape(-1).view(np.uint32))
+    half.close()
+    # (2) idempotence: same input, same bits
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    assert np.array_equal(pipe.processed_host().view(np.uint32), full.reshape(-1).view(np.uint32))
+    # (3) the oracle on the first, a middle and the last B-scan
+    raw = d.cpu().numpy().view(np.uint16)
+    for b in (0, B // 2 - 1, B - 1):
+        nb = max(1, sample_lines // A)
+        b0 = min(b, B - nb)
+        ps = v180_benchmark_params(N, A, nb)
+        o = common.make_oracle(ps)
+        o.set_mean_line(mean)
+        want = o.process(raw[b0:b0 + nb])
+        common.compare_images(full[b0:b0 + nb].reshape(-1), want, ps, "B-scan %d" % b0)
+        o.close()
+    pipe.close()
+
+
+def test_full_size_config2_1024x512x256():
+    _full_size(1024, 512, 256)
+
+
+def test_full_size_config3_2048x1024x512_in_slabs():
+    """config 3 is 2 GiB of raw data; one 2048 x 1024 x 128 slab (512 MiB) exercises the 64-bit indexing"""
+    _full_size(2048, 1024, 128, sample_lines=1024)
