@@ -181,7 +181,10 @@ int uploadTwiddles(octpipe* h) {
 int ensure(void** p, size_t bytes) {
 	if (*p) return OCTPIPE_OK;
 	HIP_TRY(hipMalloc(p, bytes));
+	// hipMemset runs on the NULL stream and is asynchronous to the host; the handle's streams are
+	// non-blocking, so without this wait the zero-fill could land after the first kernel's writes
 	HIP_TRY(hipMemset(*p, 0, bytes));
+	HIP_TRY(hipStreamSynchronize(nullptr));
 	return OCTPIPE_OK;
 }
 

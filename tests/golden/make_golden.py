@@ -65,7 +65,7 @@ def make_e2e():
     import common
     from octproz_amd import INTERPOLATION, synthetic_raw, v180_benchmark_params
     out = {}
-    N, A, B = 1024, 16, 2
+    N, A, B = 1024, 24, 2
     raw = synthetic_raw(N, A, B, seed=21)
     out["raw"] = raw
 

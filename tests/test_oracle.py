@@ -120,7 +120,7 @@ def test_idft_matches_numpy_for_non_power_of_two():
 # ------------------------------------------------------------------ 3. committed vectors
 @pytest.mark.parametrize("tag", ["v180", "linear", "lanczos", "lin_scale", "v100", "rolling_flip_sinus"])
 def test_golden_end_to_end_vectors(tag):
-    N, A, B = 1024, 16, 2
+    N, A, B = 1024, 24, 2
     raw = GOLD["raw"]
     p = v180_benchmark_params(N, A, B)
     if tag == "linear":
