@@ -13,9 +13,9 @@ namespace {
 constexpr int kLog2N = OCT_LOG2N;
 constexpr int kN = 1 << kLog2N;
 
-template <int INTYPE, int RS, bool ROLL, bool SPECTRUM>
+template <int INTYPE, int RS, int MODE>
 hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t stream, int* blocksUsed) {
-	auto kernel = oct_fused_kernel<kLog2N, INTYPE, RS, ROLL, SPECTRUM>;
+	auto kernel = oct_fused_kernel<kLog2N, INTYPE, RS, MODE>;
 	constexpr int waves = fused_waves_per_block(kLog2N);
 	constexpr int threads = waves * 64;
 	constexpr size_t lds = block_lds_bytes<kLog2N>();
@@ -39,9 +39,12 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 	return hipGetLastError();
 }
 
-template <int INTYPE, int RS, bool ROLL>
-hipError_t launch_sp(bool spectrum, const FusedArgs& a, int rb, hipStream_t st, int* bu) {
-	return spectrum ? launch_one<INTYPE, RS, ROLL, true>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLL, false>(a, rb, st, bu);
+// the output flavour: complex spectrum, log-scaled image or linearly scaled image
+template <int INTYPE, int RS, int ROLLBIT>
+hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, hipStream_t st, int* bu) {
+	if (spectrum) return launch_one<INTYPE, RS, ROLLBIT | MODE_SPECTRUM>(a, rb, st, bu);
+	if (logScale) return launch_one<INTYPE, RS, ROLLBIT | MODE_LOG>(a, rb, st, bu);
+	return launch_one<INTYPE, RS, ROLLBIT>(a, rb, st, bu);
 }
 }  // namespace
 
@@ -49,29 +52,29 @@ hipError_t launch_sp(bool spectrum, const FusedArgs& a, int rb, hipStream_t st, 
 #define OCT_CAT(a, b) OCT_CAT2(a, b)
 
 // intype: IN_U16 or IN_F32; rs: RS_*; roll: in-kernel rolling average (IN_U16 only)
-hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool spectrum, const FusedArgs& a,
+hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,
                                              int requestedBlocks, hipStream_t stream, int* blocksUsed) {
 	if (intype == IN_U16) {
 		if (rs == RS_LANCZOS) return hipErrorInvalidValue;
 		if (roll) {
 			switch (rs) {
-			case RS_NONE: return launch_sp<IN_U16, RS_NONE, true>(spectrum, a, requestedBlocks, stream, blocksUsed);
-			case RS_LINEAR: return launch_sp<IN_U16, RS_LINEAR, true>(spectrum, a, requestedBlocks, stream, blocksUsed);
-			default: return launch_sp<IN_U16, RS_CUBIC, true>(spectrum, a, requestedBlocks, stream, blocksUsed);
+			case RS_NONE: return launch_out<IN_U16, RS_NONE, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+			case RS_LINEAR: return launch_out<IN_U16, RS_LINEAR, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+			default: return launch_out<IN_U16, RS_CUBIC, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 			}
 		}
 		switch (rs) {
-		case RS_NONE: return launch_sp<IN_U16, RS_NONE, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
-		case RS_LINEAR: return launch_sp<IN_U16, RS_LINEAR, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
-		default: return launch_sp<IN_U16, RS_CUBIC, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+		case RS_NONE: return launch_out<IN_U16, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		case RS_LINEAR: return launch_out<IN_U16, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		default: return launch_out<IN_U16, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 		}
 	}
 	if (roll) return hipErrorInvalidValue;
 	switch (rs) {
-	case RS_NONE: return launch_sp<IN_F32, RS_NONE, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
-	case RS_LINEAR: return launch_sp<IN_F32, RS_LINEAR, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
-	case RS_CUBIC: return launch_sp<IN_F32, RS_CUBIC, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
-	default: return launch_sp<IN_F32, RS_LANCZOS, false>(spectrum, a, requestedBlocks, stream, blocksUsed);
+	case RS_NONE: return launch_out<IN_F32, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	case RS_LINEAR: return launch_out<IN_F32, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	case RS_CUBIC: return launch_out<IN_F32, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	default: return launch_out<IN_F32, RS_LANCZOS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	}
 }
 

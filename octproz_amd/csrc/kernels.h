@@ -1,7 +1,7 @@
-// kernels.h -- HIP kernels of the OCT processing path for gfx950 (MI355X, wave64).
+// kernels.h -- the fused A-scan kernel of the OCT processing path for gfx950 (MI355X, wave64).
 //
-// One fused kernel does, per A-scan and without touching HBM in between, what the reference
-// does in 5-7 full-volume passes (cuda_code.cu "cu:"):
+// One kernel does, per A-scan and without touching HBM in between, what the reference does in
+// 5-7 full-volume passes (cuda_code.cu "cu:"):
 //   raw unpack            cu:109-147   (inputToCufftComplex[_and_bitshift])
 //   rolling-average DC    cu:165-211   (rollingAverageBackgroundRemoval)
 //   k-linearisation       cu:213-326   (linear / cubic / Lanczos)  x window x phasor  cu:341-489
@@ -14,8 +14,10 @@
 // Stockham autosort with in-register radix-16/8/4 butterflies; between passes the wave
 // exchanges data through its private LDS slice (no workgroup barrier: wave-synchronous).
 // The raw row is staged in the same LDS slice for the resampling gather.  Only bins
-// 0..N/2-1 are produced (last pass pruned).  Algorithmic HBM traffic: 2*N bytes in (uint16),
-// 2*N bytes out (N/2 float32) per A-scan.
+// 0..N/2-1 are produced (last pass pruned).  Global memory is reached through buffer
+// descriptors (SGPR base + per-lane offset + immediate), so no per-access 64-bit address
+// arithmetic is spent in the VALU.  Algorithmic HBM traffic: 2*N bytes in (uint16), 2*N bytes out
+// (N/2 float32) per A-scan.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,22 +37,23 @@ struct FusedArgs {
 	const f2* twiddle;       // per-pass tables [t-1][k] = exp(+2*pi*i*t*k/(NS*R)), see twiddle_count()
 	const f2* meanLine;      // [N] (first N/2 used)
 	unsigned numLines;       // A-scans to process in this launch
-	unsigned linesInBuffer;  // A-scans in the whole buffer (bounds for the Lanczos halo)
+	unsigned linesInBuffer;  // A-scans in the whole buffer (bounds for the Lanczos halo, flip rule)
 	unsigned ascansPerBscan;
 	int bitshift;
-	int rollingW;            // 0 = off
+	int rollingW;            // window half-size of the rolling average (ROLL variants)
 	int flip;
-	int logScale;
 	int subtractMean;
-	float sA, sB;            // out = sA * log2(P) + sB   (log)   |   sA * sqrt(P) + sB   (lin)
+	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
 };
 
-// waves (= A-scans in flight) per workgroup; bounded by the 160 KiB LDS of a CU
-constexpr int fused_waves_per_block(int log2n) { return log2n >= 12 ? 2 : 4; }
+// waves (= A-scans in flight) per workgroup.  All waves of a workgroup share one copy of the
+// twiddle tables in LDS; 8 waves keep 2 workgroups = 16 waves resident per CU at N = 1024.
+constexpr int fused_waves_per_block(int log2n) { return log2n <= 10 ? 8 : (log2n == 11 ? 4 : 2); }
 
 #ifndef OCT_MIN_WAVES_PER_SIMD
-#define OCT_MIN_WAVES_PER_SIMD 3
+#define OCT_MIN_WAVES_PER_SIMD 4
 #endif
+constexpr int fused_min_waves_per_simd(int log2n) { return log2n <= 10 ? OCT_MIN_WAVES_PER_SIMD : (log2n == 11 ? 2 : 1); }
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
 
@@ -61,8 +64,6 @@ template <int N> constexpr int wave_lds_bytes() {
 	return (m + 15) & ~15;
 }
 
-OCT_DEV int pad16(int j) { return j + (j >> 4); }
-
 OCT_DEV void wave_sync_lds() {
 	// LDS operations of one wave execute in issue order; this only stops the compiler from
 	// moving LDS accesses across the point (cross-lane dependencies are invisible to it).
@@ -70,39 +71,46 @@ OCT_DEV void wave_sync_lds() {
 	__builtin_amdgcn_wave_barrier();
 }
 
-// ------------------------------------------------------------------ raw chunk = 4 consecutive samples
-template <int INTYPE> struct Chunk;
-template <> struct Chunk<IN_U8>  { typedef uint32_t T; };
-template <> struct Chunk<IN_U16> { typedef uint2 T; };
-template <> struct Chunk<IN_U32> { typedef uint4 T; };
-template <> struct Chunk<IN_F32> { typedef float4 T; };
+// ------------------------------------------------------------------ buffer addressing
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int INTYPE>
-OCT_DEV typename Chunk<INTYPE>::T load_chunk(const void* base, size_t sampleIdx) {
-	typedef typename Chunk<INTYPE>::T T;
-	return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + sampleIdx * (sizeof(T) / 4));
+OCT_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// byte offset = per-lane VGPR part + compile-time constant c; the constant is split into the
+// 12-bit immediate of the instruction and a 4 KiB-granular scalar offset, so no VALU add is needed
+OCT_DEV f32x4 buf_load128(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
+	return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vbase + (c & 4095), c & ~4095, 0));
+}
+OCT_DEV u32x2 buf_load64(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
+	return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, vbase + (c & 4095), c & ~4095, 0));
+}
+OCT_DEV void buf_store32(float v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
+	__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, vbase + (c & 4095), c & ~4095, 0);
 }
 
-// cu:109-147: unsigned integer -> float (exact below 2^24; uint32 rounds toward -inf like
-// __uint2float_rd), optional >> 4 (uint32: value / 2^32 evaluated in double).
+// ------------------------------------------------------------------ raw chunk = 4 consecutive samples
+template <int INTYPE> struct Chunk;
+template <> struct Chunk<IN_U16> { typedef u32x2 T; static constexpr int BYTES = 8; };
+template <> struct Chunk<IN_F32> { typedef f32x4 T; static constexpr int BYTES = 16; };
+
+template <int INTYPE>
+OCT_DEV typename Chunk<INTYPE>::T load_chunk(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
+	if constexpr (INTYPE == IN_U16) return buf_load64(r, voff, imm);
+	else return buf_load128(r, voff, imm);
+}
+
+// cu:119-121 / cu:139-141: uint16 -> float (exact), optional >> 4
 template <int INTYPE>
 OCT_DEV float4 chunk_to_float(typename Chunk<INTYPE>::T c, int bitshift) {
-	if constexpr (INTYPE == IN_U8) {
-		uint32_t s = bitshift ? 4u : 0u;
-		return float4{(float)((c & 0xffu) >> s), (float)(((c >> 8) & 0xffu) >> s),
-		              (float)(((c >> 16) & 0xffu) >> s), (float)((c >> 24) >> s)};
-	} else if constexpr (INTYPE == IN_U16) {
-		uint32_t s = bitshift ? 4u : 0u;
+	if constexpr (INTYPE == IN_U16) {
+		const uint32_t s = bitshift ? 4u : 0u;
 		return float4{(float)((c.x & 0xffffu) >> s), (float)((c.x >> 16) >> s),
 		              (float)((c.y & 0xffffu) >> s), (float)((c.y >> 16) >> s)};
-	} else if constexpr (INTYPE == IN_U32) {
-		if (bitshift) {
-			const double k = 1.0 / 4294967296.0;
-			return float4{(float)((double)c.x * k), (float)((double)c.y * k), (float)((double)c.z * k), (float)((double)c.w * k)};
-		}
-		return float4{__uint2float_rd(c.x), __uint2float_rd(c.y), __uint2float_rd(c.z), __uint2float_rd(c.w)};
 	} else {
-		return c;
+		return float4{c.x, c.y, c.z, c.w};
 	}
 }
 
@@ -128,9 +136,9 @@ OCT_DEV float lanczos8(float x) {
 // v[q] holds element (lane + 64*q) of the current sequence.  Butterfly b = lane + 64*m
 // (m < P/R) combines elements b + t*N/R, i.e. v[m + t*(P/R)]; its outputs go to
 // j0 + u*NS with j0 = (b/NS)*NS*R + b%NS.  The exchange buffer is padded by one element per
-// 16 (pad16) so that both the strided writes and the unit-stride reads are conflict-free;
-// all LDS addresses are "per-lane base + compile-time offset" so they fold into the
-// instructions' immediate fields instead of living in VGPRs.
+// 16 so that both the strided writes and the unit-stride reads are conflict-free; all LDS
+// addresses are "per-lane base + compile-time offset" so they fold into the instructions'
+// immediate fields instead of living in VGPRs.
 constexpr int pad16c(int j) { return j + (j >> 4); }
 
 template <int N, int R, int NS, bool LAST, bool PRUNE>
@@ -207,20 +215,27 @@ template <int LOG2N> constexpr int block_lds_bytes() {
 	return tw_lds_bytes<LOG2N>() + fused_waves_per_block(LOG2N) * wave_lds_bytes<(1 << LOG2N)>();
 }
 
+// MODE bits of the kernel template
+enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4 };
+
 // INTYPE: IN_U16 (raw, the hot configuration) or IN_F32 (samples prepared by oct_prepare_kernel:
 // uint8 / uint32 input and everything in front of the Lanczos variant).
-// RS: resampling mode (RS_*); ROLL: rolling-average DC removal inside the kernel (IN_U16 only);
-// SPECTRUM: write the full complex spectrum instead of the processed half A-scan.
-template <int LOG2N, int INTYPE, int RS, bool ROLL, bool SPECTRUM>
-__global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, OCT_MIN_WAVES_PER_SIMD) void oct_fused_kernel(const FusedArgs a) {
+// RS: resampling mode (RS_*).  MODE: MODE_ROLL = rolling-average DC removal inside the kernel
+// (IN_U16 only); MODE_SPECTRUM = write the full complex spectrum instead of the processed half
+// A-scan; MODE_LOG = logarithmic grey-scale mapping (cu:718) instead of the linear one (cu:739).
+template <int LOG2N, int INTYPE, int RS, int MODE>
+__global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, fused_min_waves_per_simd(LOG2N)) void oct_fused_kernel(const FusedArgs a) {
 	constexpr int N = 1 << LOG2N, P = N / 64, NL = N / 256;
 	constexpr int WAVES = fused_waves_per_block(LOG2N), THREADS = WAVES * 64;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
+	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
+	constexpr int CB = Chunk<INTYPE>::BYTES;  // bytes of 4 samples
 	static_assert(!(RS == RS_LANCZOS && INTYPE != IN_F32), "Lanczos needs the prepared float buffer");
 	static_assert(!(ROLL && INTYPE == IN_F32), "prepared input is already DC-corrected");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* tw = reinterpret_cast<f2*>(smem);
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
 	char* wbase = smem + tw_lds_bytes<LOG2N>() + wave * wave_lds_bytes<N>();
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
@@ -229,16 +244,19 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, OCT_MIN_WAVES_PE
 	__syncthreads();
 
 	const unsigned wavesTotal = gridDim.x * (unsigned)WAVES;
-	unsigned line = blockIdx.x * (unsigned)WAVES + wave;
+	unsigned line = blockIdx.x * (unsigned)WAVES + (unsigned)wave;
+	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16u);
+	const __amdgpu_buffer_rsrc_t meanR = make_rsrc(a.meanLine, N * 8u);
+	const unsigned rowBytes = (unsigned)(N / 4) * CB;
 	typedef typename Chunk<INTYPE>::T ChunkT;
 	ChunkT pre[NL];
 	if constexpr (RS != RS_LANCZOS) {
 		if (line < a.numLines) {
+			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
 #pragma unroll
-			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(a.raw, (size_t)line * N + 4u * (lane + 64 * i));
+			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(rawR, lane * CB, i * 64 * CB);
 		}
 	}
-	const float4* lutp = a.lut + lane;
 	float* rowl = row + ROW_OFF + lane;
 
 	for (; line < a.numLines; line += wavesTotal) {
@@ -251,8 +269,9 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, OCT_MIN_WAVES_PE
 			}
 			const unsigned next = line + wavesTotal;  // prefetch the next row of this wave
 			if (next < a.numLines) {
+				const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
 #pragma unroll
-				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(a.raw, (size_t)next * N + 4u * (lane + 64 * i));
+				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(rawR, lane * CB, i * 64 * CB);
 			}
 		} else {
 			// Lanczos taps cross line borders (cu:313-321): stage [off-8, off+N+8) of the prepared
@@ -295,7 +314,8 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, OCT_MIN_WAVES_PE
 		f2 v[P];
 #pragma unroll
 		for (int q = 0; q < P; q++) {
-			const float4 L = lutp[64 * q];  // {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
+			// {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
+			const f32x4 L = buf_load128(lutR, lane * 16, q * 1024);
 			float y;
 			if constexpr (RS == RS_CUBIC) {
 				const int n1 = (int)L.x;
@@ -335,19 +355,17 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, OCT_MIN_WAVES_PE
 			// even buffer-local B-scans are mirrored; the reference's launch covers S/4 indices
 			// (cu:1547), so with an odd B-scan count the last one is left as it is
 			if (a.flip && (b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) as = a.ascansPerBscan - 1u - as;
-			float* dst = a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2) + lane;
-			const f2* ml = a.meanLine + lane;
+			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2), N * 2u);
 #pragma unroll
 			for (int m = 0; m < NBL; m++) {
 #pragma unroll
 				for (int u = 0; u < RL / 2; u++) {
-					constexpr int dummy = 0; (void)dummy;
-					const int r = 64 * m + u * (N / RL);
+					const int r = 64 * m + u * (N / RL);  // bin = lane + r
 					f2 z = v[m + u * NBL];
-					if (a.subtractMean) z = z - ml[r];
+					if (a.subtractMean) z = z - __builtin_bit_cast(f2, buf_load64(meanR, lane * 8, r * 8));
 					const float p = z.x * z.x + z.y * z.y;
-					const float s = a.logScale ? __log2f(p) : __fsqrt_rn(p);
-					dst[r] = a.sA * s + a.sB;
+					const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
+					buf_store32(a.sA * s + a.sB, outR, lane * 4, r * 4);
 				}
 			}
 		}

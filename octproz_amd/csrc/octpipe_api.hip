@@ -225,7 +225,6 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	a.bitshift = p.bitshift;
 	a.rollingW = p.rollingAverageWindowSize;
 	a.flip = p.bscanFlip;
-	a.logScale = p.signalLogScaling;
 	a.subtractMean = p.fixedPatternNoiseRemoval;
 	// cu:718 / cu:739 rewritten as one multiply-add on log2(P) resp. sqrt(P); constants in double
 	const double half = (double)(h->N / 2), range = (double)p.signalGrayscaleMax - (double)p.signalGrayscaleMin;
@@ -243,7 +242,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, a, 0, h->stream, nullptr));
+	HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, nullptr));
 	if (timeIt && h->timing) {
 		HIP_TRY(hipEventRecord(t.stop, h->stream));
 		h->timed.push_back(t);
