@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--bscans", type=int, default=256)
     ap.add_argument("--volumes", type=int, default=4, help="distinct raw buffers rotated (defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
     args = ap.parse_args()
 
     import numpy as np
@@ -73,10 +74,13 @@ def main():
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group(backend=args.backend)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     N, A, B = args.samples, args.ascans, args.bscans
     p = v180_benchmark_params(N, A, B)
@@ -90,13 +94,9 @@ def main():
     if rank == 0:
         pipe.process_device(vols[0].data_ptr())
         pipe.synchronize()
-        blob = torch.from_numpy(pipe.export_calibration()).to(dev)
-    else:
-        blob = torch.empty(pipe._lib.octpipe_calibration_size(pipe.handle), dtype=torch.uint8, device=dev)
     if distributed:
-        dist.broadcast(blob, src=0)  # RCCL over xGMI: ~26 KB, latency bound
-        if rank != 0:
-            pipe.import_calibration(blob.cpu().numpy())
+        from octproz_amd import dist as odist
+        odist.share_calibration(pipe, device=comm_dev, src=0)  # RCCL broadcast over xGMI: ~23 KB, latency bound
 
     def step(i):
         pipe.process_device(vols[i % len(vols)].data_ptr(), sync_params=False)
@@ -119,7 +119,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_ms, launches = pipe.kernel_timing(reset=True)

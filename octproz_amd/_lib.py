@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboctpipe.so")
+LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")  # override: A/B builds only
 
 OCTPIPE_OK = 0
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE"}

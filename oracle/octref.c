@@ -173,7 +173,8 @@ void octref_unpack(const void* raw, int bitDepth, int bitshift, size_t samples, 
 		for (size_t i = 0; i < samples; i++) { out[i].x = (float)(bitshift ? (in[i] >> 4) : in[i]); out[i].y = 0.0f; }
 	} else if (bitDepth <= 16) {
 		const uint16_t* in = (const uint16_t*)raw;
-		for (size_t i = 0; i < samples; i++) { out[i].x = (float)(bitshift ? (in[i] >> 4) : in[i]); out[i].y = 0.0f; }
+#pragma omp parallel for schedule(static)
+		for (long i = 0; i < (long)samples; i++) { out[i].x = (float)(bitshift ? (in[i] >> 4) : in[i]); out[i].y = 0.0f; }
 	} else {
 		const uint32_t* in = (const uint32_t*)raw;
 		for (size_t i = 0; i < samples; i++) {
@@ -379,8 +380,9 @@ void octref_min_variance_mean(const octref_c32* in, int width, int height, int s
 
 /* cu:567-584: subtract from the positive-depth half of every line (halfWidth = N/2). */
 void octref_mean_subtract(octref_c32* io, const octref_c32* meanLine, int halfWidth, size_t halfSamples) {
-	for (size_t i = 0; i < halfSamples; i++) {
-		size_t r = i % (size_t)halfWidth, line = i / (size_t)halfWidth;
+#pragma omp parallel for schedule(static)
+	for (long i = 0; i < (long)halfSamples; i++) {
+		size_t r = (size_t)i % (size_t)halfWidth, line = (size_t)i / (size_t)halfWidth;
 		size_t idx = line * halfWidth + i; /* = line*N + r */
 		io[idx].x -= meanLine[r].x;
 		io[idx].y -= meanLine[r].y;

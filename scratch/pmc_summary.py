@@ -1,9 +1,10 @@
-import csv, collections, sys, glob
-for f in sys.argv[1:]:
+import csv, collections, sys
+pat = sys.argv[1]
+for f in sys.argv[2:]:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "oct_fused_kernel" in k and "false>" in k.split("oct_fused_kernel")[1][:40]:
+        if pat in k:
             acc[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         print(k)
