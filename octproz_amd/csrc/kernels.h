@@ -46,14 +46,18 @@ struct FusedArgs {
 	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
 };
 
-// waves (= A-scans in flight) per workgroup.  All waves of a workgroup share one copy of the
-// twiddle tables in LDS; 8 waves keep 2 workgroups = 16 waves resident per CU at N = 1024.
-constexpr int fused_waves_per_block(int log2n) { return log2n <= 10 ? 8 : (log2n == 11 ? 4 : 2); }
-
-#ifndef OCT_MIN_WAVES_PER_SIMD
-#define OCT_MIN_WAVES_PER_SIMD 4
-#endif
-constexpr int fused_min_waves_per_simd(int log2n) { return log2n <= 10 ? OCT_MIN_WAVES_PER_SIMD : (log2n == 11 ? 2 : 1); }
+// Per-length launch shape.  WAVES = A-scans in flight per workgroup; all waves of a workgroup share
+// one LDS copy of the twiddle tables, the mean A-line and (LDS_LUT) the resampling/window/phasor LUT.
+// N = 1024: 12 waves + 28 KiB of tables = 132 KiB -> one workgroup per CU, 3 waves per SIMD.
+template <int LOG2N> struct Cfg;
+template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
+template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
+template <> struct Cfg<10> { static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; };
+template <> struct Cfg<11> { static constexpr int WAVES = 4,  MINW = 2; static constexpr bool LDS_LUT = false; };
+template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; };
+constexpr int fused_waves_per_block(int log2n) {
+	return log2n == 8 ? Cfg<8>::WAVES : log2n == 9 ? Cfg<9>::WAVES : log2n == 10 ? Cfg<10>::WAVES : log2n == 11 ? Cfg<11>::WAVES : Cfg<12>::WAVES;
+}
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
 
@@ -90,27 +94,37 @@ OCT_DEV u32x2 buf_load64(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 OCT_DEV void buf_store32(float v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, vbase + (c & 4095), c & ~4095, 0);
 }
-
-// ------------------------------------------------------------------ raw chunk = 4 consecutive samples
-template <int INTYPE> struct Chunk;
-template <> struct Chunk<IN_U16> { typedef u32x2 T; static constexpr int BYTES = 8; };
-template <> struct Chunk<IN_F32> { typedef f32x4 T; static constexpr int BYTES = 16; };
-
-template <int INTYPE>
-OCT_DEV typename Chunk<INTYPE>::T load_chunk(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
-	if constexpr (INTYPE == IN_U16) return buf_load64(r, voff, imm);
-	else return buf_load128(r, voff, imm);
+OCT_DEV void buf_store128(f32x4 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
+	__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, vbase + (c & 4095), c & ~4095, 0);
 }
 
-// cu:119-121 / cu:139-141: uint16 -> float (exact), optional >> 4
+// ------------------------------------------------------------------ raw chunk = SPL consecutive samples per lane
+// uint16 rows are fetched 16 bytes per lane (8 samples, one buffer_load_dwordx4 per KiB): the
+// texture-address unit spends ~16 cycles per wave instruction whatever its width, so the number of
+// vector-memory instructions per A-scan is what bounds this kernel, not the bytes.
+template <int INTYPE, int N> struct Chunk;
+template <int N> struct Chunk<IN_U16, N> {
+	static constexpr int SPL = N >= 512 ? 8 : 4, BYTES = SPL * 2;
+	typedef u32x4 T;  // SPL = 4 uses .x/.y only
+};
+template <int N> struct Chunk<IN_F32, N> { static constexpr int SPL = 4, BYTES = 16; typedef u32x4 T; };
+
+template <int INTYPE, int N>
+OCT_DEV u32x4 load_chunk(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
+	if constexpr (Chunk<INTYPE, N>::BYTES == 8) { const u32x2 t = buf_load64(r, voff, imm); return u32x4{t.x, t.y, 0u, 0u}; }
+	else return __builtin_bit_cast(u32x4, buf_load128(r, voff, imm));
+}
+
+// cu:119-121 / cu:139-141: uint16 -> float (exact), optional >> 4; samples 4h..4h+3 of the chunk
 template <int INTYPE>
-OCT_DEV float4 chunk_to_float(typename Chunk<INTYPE>::T c, int bitshift) {
+OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 	if constexpr (INTYPE == IN_U16) {
-		const uint32_t s = bitshift ? 4u : 0u;
-		return float4{(float)((c.x & 0xffffu) >> s), (float)((c.x >> 16) >> s),
-		              (float)((c.y & 0xffffu) >> s), (float)((c.y >> 16) >> s)};
+		const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
+		return float4{(float)((a & 0xffffu) >> s), (float)((a >> 16) >> s), (float)((b & 0xffffu) >> s), (float)((b >> 16) >> s)};
 	} else {
-		return float4{c.x, c.y, c.z, c.w};
+		// (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)
+		const f32x4 f = __builtin_bit_cast(f32x4, c);
+		return float4{f.x, f.y, f.z, f.w};
 	}
 }
 
@@ -132,23 +146,41 @@ OCT_DEV float lanczos8(float x) {
 	return (ax < 0.00001f) ? 1.0f : (s1 * s8);
 }
 
-// ------------------------------------------------------------------ one Stockham pass
-// v[q] holds element (lane + 64*q) of the current sequence.  Butterfly b = lane + 64*m
-// (m < P/R) combines elements b + t*N/R, i.e. v[m + t*(P/R)]; its outputs go to
-// j0 + u*NS with j0 = (b/NS)*NS*R + b%NS.  The exchange buffer is padded by one element per
-// 16 so that both the strided writes and the unit-stride reads are conflict-free; all LDS
-// addresses are "per-lane base + compile-time offset" so they fold into the instructions'
-// immediate fields instead of living in VGPRs.
+// ------------------------------------------------------------------ Stockham passes
+// The sequence lives in the wave's LDS slice between passes, padded by one element per 16
+// (index j -> j + (j >> 4)): the stride-R writes and the unit-stride reads are both conflict-free.
+// Butterfly b combines elements b + t*N/R (t < R) and writes j0 + u*NS, j0 = (b/NS)*NS*R + b%NS.
+//   strided mapping (all passes but the last):  b = lane + 64*m      -> v[m + t*NB] = element b + t*N/R
+//   contiguous mapping (last pass, NB = 4):      b = 4*lane + m       -> every lane ends up with 4
+//     consecutive bins, so the epilogue stores 16 bytes per lane, 1 KiB per wave instruction.
+// All LDS addresses are "per-lane base + compile-time offset" (immediate fields, no VALU).
 constexpr int pad16c(int j) { return j + (j >> 4); }
 
-template <int N, int R, int NS, bool LAST, bool PRUNE>
+template <int N, int R, int NS, bool FIRST, bool LAST, bool PRUNE>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 	constexpr int P = N / 64, NB = P / R;
+	constexpr bool CONTIG = LAST && NB == 4;
 	static_assert(NB >= 1, "radix larger than points per lane");
+	static_assert(!LAST || NB == 1 || NB == 4, "last pass: one or four butterflies per lane");
+	if constexpr (!FIRST) {
+		if constexpr (CONTIG) {
+			const f2* rb = xbuf + (4 * lane + (lane >> 2));
+#pragma unroll
+			for (int t = 0; t < R; t++)
+#pragma unroll
+				for (int m = 0; m < 4; m++) v[m + t * NB] = rb[pad16c(t * (N / R)) + m];
+		} else {
+			const f2* rb = xbuf + (lane + (lane >> 4));
+#pragma unroll
+			for (int q = 0; q < P; q++) v[q] = rb[68 * q];
+		}
+		wave_sync_lds();
+	}
 	if constexpr (NS > 1) {
 #pragma unroll
 		for (int m = 0; m < NB; m++) {
-			const f2* tk = twp + ((lane + 64 * m) & (NS - 1));  // table layout [t-1][k]
+			const int b = CONTIG ? 4 * lane + m : lane + 64 * m;
+			const f2* tk = twp + (b & (NS - 1));  // table layout [t-1][k]
 #pragma unroll
 			for (int t = 1; t < R; t++) v[m + t * NB] = octfft::cmul(v[m + t * NB], tk[(t - 1) * NS]);
 		}
@@ -164,10 +196,6 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 #pragma unroll
 			for (int u = 0; u < R; u++) wb[pad16c(u * NS)] = v[m + u * NB];
 		}
-		wave_sync_lds();
-		const f2* rb = xbuf + (lane + (lane >> 4));
-#pragma unroll
-		for (int q = 0; q < P; q++) v[q] = rb[68 * q];
 		wave_sync_lds();
 	}
 }
@@ -188,9 +216,11 @@ template <int LOG2N> constexpr int twiddle_count() {
 	if (PL::R3 > 1) n += (PL::R3 - 1) * ns;
 	return n;
 }
+template <int LOG2N> struct LastRadix { static constexpr int value = Plan<LOG2N>::R3 == 1 ? Plan<LOG2N>::R2 : Plan<LOG2N>::R3; };
 
-// natural-order inverse FFT of v (element lane+64q); result bin (lane + 64*m + u*N/RL) in
-// v[m + u*NB], RL = radix of the last pass, NB = P/RL.  PRUNE: only u < RL/2 valid.
+// natural-order inverse FFT of v (element lane+64q).  With RL = radix of the last pass and
+// NB = P/RL the result bin is   NB == 4:  4*lane + m + u*N/RL     NB == 1:  lane + u*N/RL
+// held in v[m + u*NB].  PRUNE: only u < RL/2 valid.
 template <int LOG2N, bool PRUNE>
 OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane) {
 	constexpr int N = 1 << LOG2N;
@@ -198,21 +228,23 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
 	static_assert(R0 * R1 * R2 * R3 == N, "plan");
 	constexpr int T1 = 0, T2 = T1 + (R1 - 1) * R0, T3 = T2 + (R2 - 1) * R0 * R1;
-	fft_pass<N, R0, 1, false, PRUNE>(v, xbuf, tw, lane);
-	fft_pass<N, R1, R0, false, PRUNE>(v, xbuf, tw + T1, lane);
+	fft_pass<N, R0, 1, true, false, PRUNE>(v, xbuf, tw, lane);
+	fft_pass<N, R1, R0, false, false, PRUNE>(v, xbuf, tw + T1, lane);
 	if constexpr (R3 == 1) {
-		fft_pass<N, R2, R0 * R1, true, PRUNE>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R2, R0 * R1, false, true, PRUNE>(v, xbuf, tw + T2, lane);
 	} else {
-		fft_pass<N, R2, R0 * R1, false, PRUNE>(v, xbuf, tw + T2, lane);
-		fft_pass<N, R3, R0 * R1 * R2, true, PRUNE>(v, xbuf, tw + T3, lane);
+		fft_pass<N, R2, R0 * R1, false, false, PRUNE>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R3, R0 * R1 * R2, false, true, PRUNE>(v, xbuf, tw + T3, lane);
 	}
 }
-template <int LOG2N> struct LastRadix { static constexpr int value = Plan<LOG2N>::R3 == 1 ? Plan<LOG2N>::R2 : Plan<LOG2N>::R3; };
 
 // ------------------------------------------------------------------ the fused kernel
+// LDS of a workgroup: [twiddles | mean A-line (N/2 complex) | LUT (N float4, LDS_LUT) | WAVES x slice]
 template <int LOG2N> constexpr int tw_lds_bytes() { return (twiddle_count<LOG2N>() * 8 + 15) & ~15; }
+template <int LOG2N> constexpr int mean_lds_bytes() { return (1 << LOG2N) * 4; }
+template <int LOG2N> constexpr int lut_lds_bytes() { return Cfg<LOG2N>::LDS_LUT ? (1 << LOG2N) * 16 : 0; }
 template <int LOG2N> constexpr int block_lds_bytes() {
-	return tw_lds_bytes<LOG2N>() + fused_waves_per_block(LOG2N) * wave_lds_bytes<(1 << LOG2N)>();
+	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N>() + Cfg<LOG2N>::WAVES * wave_lds_bytes<(1 << LOG2N)>();
 }
 
 // MODE bits of the kernel template
@@ -224,37 +256,45 @@ enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4 };
 // (IN_U16 only); MODE_SPECTRUM = write the full complex spectrum instead of the processed half
 // A-scan; MODE_LOG = logarithmic grey-scale mapping (cu:718) instead of the linear one (cu:739).
 template <int LOG2N, int INTYPE, int RS, int MODE>
-__global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, fused_min_waves_per_simd(LOG2N)) void oct_fused_kernel(const FusedArgs a) {
-	constexpr int N = 1 << LOG2N, P = N / 64, NL = N / 256;
-	constexpr int WAVES = fused_waves_per_block(LOG2N), THREADS = WAVES * 64;
+__global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_fused_kernel(const FusedArgs a) {
+	constexpr int N = 1 << LOG2N, P = N / 64;
+	constexpr int WAVES = Cfg<LOG2N>::WAVES, THREADS = WAVES * 64;
+	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
-	constexpr int CB = Chunk<INTYPE>::BYTES;  // bytes of 4 samples
+	typedef Chunk<INTYPE, N> CH;
+	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (64 * SPL);
 	static_assert(!(RS == RS_LANCZOS && INTYPE != IN_F32), "Lanczos needs the prepared float buffer");
 	static_assert(!(ROLL && INTYPE == IN_F32), "prepared input is already DC-corrected");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* tw = reinterpret_cast<f2*>(smem);
+	f2* meanL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>());
+	float4* lutL = reinterpret_cast<float4*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>());
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
-	char* wbase = smem + tw_lds_bytes<LOG2N>() + wave * wave_lds_bytes<N>();
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N>() + wave * wave_lds_bytes<N>();
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
+	// tables -> LDS, once per (persistent) workgroup
 	for (int i = tid; i < twiddle_count<LOG2N>(); i += THREADS) tw[i] = a.twiddle[i];
+	for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
+	if constexpr (LDS_LUT) {
+		for (int i = tid; i < N; i += THREADS) lutL[i] = a.lut[i];
+	}
 	__syncthreads();
 
 	const unsigned wavesTotal = gridDim.x * (unsigned)WAVES;
 	unsigned line = blockIdx.x * (unsigned)WAVES + (unsigned)wave;
 	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16u);
-	const __amdgpu_buffer_rsrc_t meanR = make_rsrc(a.meanLine, N * 8u);
-	const unsigned rowBytes = (unsigned)(N / 4) * CB;
-	typedef typename Chunk<INTYPE>::T ChunkT;
-	ChunkT pre[NL];
+	const unsigned rowBytes = (unsigned)(N / SPL) * CB;
+	const uint32_t shift = a.bitshift ? 4u : 0u;
+	u32x4 pre[NL];
 	if constexpr (RS != RS_LANCZOS) {
 		if (line < a.numLines) {
 			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
 #pragma unroll
-			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(rawR, lane * CB, i * 64 * CB);
+			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
 		}
 	}
 	float* rowl = row + ROW_OFF + lane;
@@ -264,14 +304,15 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, fused_min_waves_
 		if constexpr (RS != RS_LANCZOS) {
 #pragma unroll
 			for (int i = 0; i < NL; i++) {
-				float4 f = chunk_to_float<INTYPE>(pre[i], a.bitshift);
-				*reinterpret_cast<float4*>(&row[ROW_OFF + 4 * lane + 256 * i]) = f;
+#pragma unroll
+				for (int h = 0; h < SPL / 4; h++)
+					*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);
 			}
 			const unsigned next = line + wavesTotal;  // prefetch the next row of this wave
 			if (next < a.numLines) {
 				const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
 #pragma unroll
-				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE>(rawR, lane * CB, i * 64 * CB);
+				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
 			}
 		} else {
 			// Lanczos taps cross line borders (cu:313-321): stage [off-8, off+N+8) of the prepared
@@ -315,7 +356,9 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, fused_min_waves_
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			// {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
-			const f32x4 L = buf_load128(lutR, lane * 16, q * 1024);
+			f32x4 L;
+			if constexpr (LDS_LUT) { const float4 t = lutL[lane + 64 * q]; L = f32x4{t.x, t.y, t.z, t.w}; }
+			else L = buf_load128(lutR, lane * 16, q * 1024);
 			float y;
 			if constexpr (RS == RS_CUBIC) {
 				const int n1 = (int)L.x;
@@ -344,11 +387,17 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, fused_min_waves_
 		fft_wave<LOG2N, !SPECTRUM>(v, xbuf, tw, lane);
 
 		if constexpr (SPECTRUM) {
-			f2* dst = a.spectrum + (size_t)line * N + lane;
+			f2* dst = a.spectrum + (size_t)line * N + NBL * lane;
 #pragma unroll
-			for (int m = 0; m < NBL; m++)
-#pragma unroll
-				for (int u = 0; u < RL; u++) dst[64 * m + u * (N / RL)] = v[m + u * NBL];
+			for (int u = 0; u < RL; u++) {
+				if constexpr (NBL == 4) {
+					float4* d4 = reinterpret_cast<float4*>(dst + u * (N / RL));
+					d4[0] = float4{v[0 + 4 * u].x, v[0 + 4 * u].y, v[1 + 4 * u].x, v[1 + 4 * u].y};
+					d4[1] = float4{v[2 + 4 * u].x, v[2 + 4 * u].y, v[3 + 4 * u].x, v[3 + 4 * u].y};
+				} else {
+					dst[u * (N / RL)] = v[u];
+				}
+			}
 		} else {
 			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
 			unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
@@ -356,17 +405,19 @@ __global__ __launch_bounds__(fused_waves_per_block(LOG2N) * 64, fused_min_waves_
 			// (cu:1547), so with an odd B-scan count the last one is left as it is
 			if (a.flip && (b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) as = a.ascansPerBscan - 1u - as;
 			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2), N * 2u);
+			const f2* ml = meanL + NBL * lane;
 #pragma unroll
-			for (int m = 0; m < NBL; m++) {
+			for (int u = 0; u < RL / 2; u++) {
+				float o[NBL];
 #pragma unroll
-				for (int u = 0; u < RL / 2; u++) {
-					const int r = 64 * m + u * (N / RL);  // bin = lane + r
-					f2 z = v[m + u * NBL];
-					if (a.subtractMean) z = z - __builtin_bit_cast(f2, buf_load64(meanR, lane * 8, r * 8));
+				for (int m = 0; m < NBL; m++) {
+					const f2 z = v[m + u * NBL] - ml[m + u * (N / RL)];
 					const float p = z.x * z.x + z.y * z.y;
 					const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
-					buf_store32(a.sA * s + a.sB, outR, lane * 4, r * 4);
+					o[m] = a.sA * s + a.sB;
 				}
+				if constexpr (NBL == 4) buf_store128(f32x4{o[0], o[1], o[2], o[3]}, outR, lane * 16, u * (N / RL) * 4);
+				else buf_store32(o[0], outR, lane * 4, u * (N / RL) * 4);
 			}
 		}
 		wave_sync_lds();
