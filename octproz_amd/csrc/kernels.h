@@ -48,11 +48,12 @@ struct FusedArgs {
 
 // Per-length launch shape.  WAVES = A-scans in flight per workgroup; all waves of a workgroup share
 // one LDS copy of the twiddle tables, the mean A-line and (LDS_LUT) the resampling/window/phasor LUT.
-// N = 1024: 12 waves + 28 KiB of tables = 132 KiB -> one workgroup per CU, 3 waves per SIMD.
+// N = 1024: 16 waves x 8.5 KiB + 24 KiB of tables = 159.9 KiB -> one 1024-thread workgroup per CU,
+// 4 waves per SIMD.
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
 template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
-template <> struct Cfg<10> { static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; };
+template <> struct Cfg<10> { static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; };
 template <> struct Cfg<11> { static constexpr int WAVES = 4,  MINW = 2; static constexpr bool LDS_LUT = false; };
 template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; };
 constexpr int fused_waves_per_block(int log2n) {
@@ -239,10 +240,10 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 }
 
 // ------------------------------------------------------------------ the fused kernel
-// LDS of a workgroup: [twiddles | mean A-line (N/2 complex) | LUT (N float4, LDS_LUT) | WAVES x slice]
+// LDS of a workgroup: [twiddles | mean A-line (N/2 complex) | LUT: rho (N float) + window*phasor (N complex), LDS_LUT | WAVES x slice]
 template <int LOG2N> constexpr int tw_lds_bytes() { return (twiddle_count<LOG2N>() * 8 + 15) & ~15; }
 template <int LOG2N> constexpr int mean_lds_bytes() { return (1 << LOG2N) * 4; }
-template <int LOG2N> constexpr int lut_lds_bytes() { return Cfg<LOG2N>::LDS_LUT ? (1 << LOG2N) * 16 : 0; }
+template <int LOG2N> constexpr int lut_lds_bytes() { return Cfg<LOG2N>::LDS_LUT ? (1 << LOG2N) * 12 : 0; }
 template <int LOG2N> constexpr int block_lds_bytes() {
 	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N>() + Cfg<LOG2N>::WAVES * wave_lds_bytes<(1 << LOG2N)>();
 }
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* tw = reinterpret_cast<f2*>(smem);
 	f2* meanL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>());
-	float4* lutL = reinterpret_cast<float4*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>());
+	float* rhoL = reinterpret_cast<float*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>());
+	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + N * 4);
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
 	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N>() + wave * wave_lds_bytes<N>();
@@ -280,7 +282,11 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 	for (int i = tid; i < twiddle_count<LOG2N>(); i += THREADS) tw[i] = a.twiddle[i];
 	for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
 	if constexpr (LDS_LUT) {
-		for (int i = tid; i < N; i += THREADS) lutL[i] = a.lut[i];
+		for (int i = tid; i < N; i += THREADS) {
+			const float4 t = a.lut[i];
+			rhoL[i] = t.x;
+			wphL[i] = f2{t.y * t.z, t.y * t.w};  // window folded into the phasor (one rounding of difference)
+		}
 	}
 	__syncthreads();
 
@@ -357,8 +363,13 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 		for (int q = 0; q < P; q++) {
 			// {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
 			f32x4 L;
-			if constexpr (LDS_LUT) { const float4 t = lutL[lane + 64 * q]; L = f32x4{t.x, t.y, t.z, t.w}; }
-			else L = buf_load128(lutR, lane * 16, q * 1024);
+			f2 wph;
+			if constexpr (LDS_LUT) {
+				L.x = rhoL[lane + 64 * q];
+				wph = wphL[lane + 64 * q];
+			} else {
+				L = buf_load128(lutR, lane * 16, q * 1024);
+			}
 			float y;
 			if constexpr (RS == RS_CUBIC) {
 				const int n1 = (int)L.x;
@@ -378,8 +389,12 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 				for (int i = -7; i <= 8; i++) sum += t[i] * lanczos8(L.x - (float)(n0 + i));
 				y = sum;
 			}
-			const float yw = y * L.y;
-			v[q] = f2{yw * L.z, yw * L.w};
+			if constexpr (LDS_LUT) {
+				v[q] = wph * y;
+			} else {
+				const float yw = y * L.y;
+				v[q] = f2{yw * L.z, yw * L.w};
+			}
 		}
 		wave_sync_lds();  // the row is dead from here on; its LDS is reused by the FFT
 
