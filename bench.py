@@ -130,6 +130,15 @@ def main():
         value = ascans_total / dt
         alg_bytes = 4.0 * N * A * B  # 2N B in (uint16) + 4*(N/2) B out (float32) per A-scan
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes of the last profiling run (profiles/hbm_traffic.json,
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE with the guide's gfx950 correction); null for other workloads
+        traffic = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            if rec.get("workload") == "%dx%dx%d" % (N, A, B):
+                traffic = rec["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "A-scans/s", "value": value, "unit": "A-scans/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -140,7 +149,7 @@ def main():
                        "samples_per_ascan": N, "ascans_per_bscan": A, "bscans_per_buffer": B,
                        "distinct_input_buffers": len(vols), "parallelism": "bscan-slab x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "oct_fused_kernel", "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Streaming mode (BASELINE config 5): continuous raw buffers from the virtual OCT system's 2-slot
+ring through octpipe_process (pinned ring slots, hipMemcpyAsync on a copy stream, double-buffered
+device raw slots), exactly the host loop of the reference (processing.cpp:176-218).  Reports the six
+numbers of the reference's info box.  This is the PCIe-inclusive rate; it is never bench.py's `value`.
+
+    python scripts/stream_bench.py --seconds 60
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--samples", type=int, default=1024)
+    ap.add_argument("--ascans", type=int, default=512)
+    ap.add_argument("--bscans", type=int, default=256)
+    ap.add_argument("--buffers-from-file", type=int, default=2, help="2 = both ring slots preloaded (no host memcpy); >2 = memcpy per buffer")
+    ap.add_argument("--stream-to-host", action="store_true", help="also quantise + D2H every buffer (reference v1.8.0 ini: streaming_enabled=true)")
+    args = ap.parse_args()
+
+    import numpy as np
+    from octproz_amd import Pipeline, VirtualOCTSystem, synthetic_raw, v180_benchmark_params
+
+    N, A, B = args.samples, args.ascans, args.bscans
+    n_buf = max(2, args.buffers_from_file)
+    data = np.concatenate([synthetic_raw(N, A, B, seed=100 + i).reshape(-1) for i in range(n_buf)])
+    system = VirtualOCTSystem(12, N, A, B, data=data, buffers_from_file=n_buf, copy_file_to_ram=True, sync_with_processing=True)
+    system.startAcquisition()
+    ring = system.buffer
+    p = v180_benchmark_params(N, A, B)
+    if args.stream_to_host:
+        p.streamToHost = 1
+    pipe = Pipeline.initializeCuda(ring.slot(0, np.uint16), ring.slot(1, np.uint16), p)
+    if args.stream_to_host:
+        out = [np.zeros(N * A * B // 2, dtype=np.uint16) for _ in range(2)]
+        pipe.register_streaming_buffers(out[0], out[1])
+        count = []
+        pipe.set_callbacks(on_streaming=lambda *a: count.append(1))
+    pipe._sync_params()
+    stats = system.run_pipeline(pipe, max_seconds=args.seconds)
+    system.stopAcquisition()
+    res = {"mode": "streaming (host loop, PCIe inclusive)", "seconds": stats.elapsedSeconds,
+           "buffers": stats.buffersProcessed, "volumes_per_s": stats.volumesPerSecond, "buffers_per_s": stats.buffersPerSecond,
+           "bscans_per_s": stats.bscansPerSecond, "ascans_per_s": stats.ascansPerSecond, "buffer_MB": stats.bufferSizeMB,
+           "throughput_MB_per_s": stats.dataThroughputMBs, "buffers_from_file": n_buf, "stream_to_host": bool(args.stream_to_host)}
+    if args.stream_to_host:
+        pipe.unregister_streaming_buffers()
+        res["callbacks"] = len(count)
+    print(json.dumps(res))
+    pipe.close()
+    system.close()
+
+
+if __name__ == "__main__":
+    main()
