@@ -81,6 +81,29 @@ int octhost_processing_run(octhost_system_t* s, octhost_consume_fn consume, void
 /* the same loop with consume = octpipe_process(pipe, buffer) */
 int octhost_processing_run_pipeline(octhost_system_t* s, octpipe_t* pipe, uint64_t maxBuffers, double maxSeconds, OctHostStats* stats);
 
+/* ---- files OCTproZ writes: settings.ini and curve CSVs ----
+ * Curve-defining settings that are not part of OctPipeParams (they only enter through the curves:
+ * OctAlgorithmParameters c0..c3, d0..d3, window, windowCenter, windowFillFactor, custom curve path). */
+typedef struct OctHostCurveSettings {
+	float c[4];                      /* resampling_c0..c3 */
+	float d[4];                      /* dispersion_compensation_d0..d3 */
+	int32_t windowType;              /* window_type (OCTPIPE_WINDOW_*) */
+	float windowCenter, windowFillFactor;
+	int32_t customResampling;        /* custom_resampling */
+	char customResamplingFilePath[1024];
+	char postBackgroundFilePath[1024];
+} OctHostCurveSettings;
+
+/* Reads a QSettings INI written by OCTproZ (key names: src/sidebar.h:47-94; mapping:
+ * src/sidebar.cpp:319-430).  Fields whose key is absent keep their value.  vsys / vsysFilePath may be
+ * NULL; the acquisition group is "Virtual OCT System" (stored as Virtual%20OCT%20System). */
+int octhost_load_settings_ini(const char* path, OctPipeParams* params, OctHostCurveSettings* curves,
+                              OctHostVirtualParams* vsys, char* vsysFilePath, size_t vsysFilePathSize);
+/* "index;value" CSV with one header line (src/octalgorithmparametersmanager.cpp:12-45).  *count
+ * receives the number of data lines even when it exceeds capacity. */
+int octhost_load_curve_csv(const char* path, float* out, unsigned capacity, unsigned* count);
+int octhost_save_curve_csv(const char* path, const float* curve, unsigned count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,13 @@ class VirtualParams(C.Structure):
                 ("syncWithProcessing", C.c_int)]
 
 
+class CurveSettings(C.Structure):
+    """OctHostCurveSettings (include/octhost.h)"""
+    _fields_ = [("c", C.c_float * 4), ("d", C.c_float * 4), ("windowType", C.c_int32), ("windowCenter", C.c_float),
+                ("windowFillFactor", C.c_float), ("customResampling", C.c_int32),
+                ("customResamplingFilePath", C.c_char * 1024), ("postBackgroundFilePath", C.c_char * 1024)]
+
+
 class HostStats(C.Structure):
     """OctHostStats (include/octhost.h)"""
     _fields_ = [("buffersProcessed", C.c_uint64), ("elapsedSeconds", C.c_double), ("volumesPerSecond", C.c_double),
@@ -94,6 +101,7 @@ OCTHOST_SYMBOLS = [
     "octhost_system_start", "octhost_system_stop", "octhost_system_running", "octhost_system_buffer",
     "octhost_system_acquisition_params", "octhost_last_error",
     "octhost_processing_run", "octhost_processing_run_pipeline",
+    "octhost_load_settings_ini", "octhost_load_curve_csv", "octhost_save_curve_csv",
 ]
 
 _lib = None
@@ -135,6 +143,9 @@ def lib():
         L.octhost_buffer_set_curr_index.argtypes = [C.c_void_p, C.c_int]
         L.octhost_buffer_set_curr_index.restype = None
         L.octhost_system_acquisition_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.octhost_load_settings_ini.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.octhost_load_curve_csv.argtypes = [C.c_char_p, C.c_void_p, C.c_uint, C.c_void_p]
+        L.octhost_save_curve_csv.argtypes = [C.c_char_p, C.c_void_p, C.c_uint]
         L.octhost_processing_run.argtypes = [C.c_void_p, CONSUME_FN, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         L.octhost_processing_run_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         # pipeline entry points take the handle as void*

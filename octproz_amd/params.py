@@ -186,3 +186,49 @@ def v180_benchmark_params(samples_per_line=1024, ascans_per_bscan=512, bscans_pe
     p.postProcessBackgroundRemoval = 0
     p.update_all_curves()
     return p
+
+
+def load_curve_csv(path):
+    """OctAlgorithmParametersManager::loadCurveFromFile (octalgorithmparametersmanager.cpp:12-30)"""
+    n = C.c_uint()
+    check(_lib.lib().octhost_load_curve_csv(path.encode(), None, 0, C.byref(n)))
+    out = _f32(n.value)
+    check(_lib.lib().octhost_load_curve_csv(path.encode(), out.ctypes.data, n.value, C.byref(n)))
+    return out
+
+
+def save_curve_csv(path, curve):
+    c = np.ascontiguousarray(curve, dtype=np.float32)
+    check(_lib.lib().octhost_save_curve_csv(path.encode(), c.ctypes.data, len(c)))
+
+
+def load_settings_ini(path, params=None):
+    """Apply an OCTproZ settings.ini (sidebar.h:47-94 key names) to an OctAlgorithmParameters; the
+    acquisition dimensions come from the [Virtual OCT System] group.  Returns (params, virtual-system
+    dict) with all curves rebuilt like OCTproZApp::forceUpdateProcessingParams."""
+    from ._lib import CurveSettings, VirtualParams
+    p = params or OctAlgorithmParameters()
+    pod = p.pod()
+    cs = CurveSettings()
+    cs.c[:] = [p.c0, p.c1, p.c2, p.c3]
+    cs.d[:] = [p.d0, p.d1, p.d2, p.d3]
+    cs.windowType, cs.windowCenter, cs.windowFillFactor = int(p.window), p.windowCenter, p.windowFillFactor
+    vs = VirtualParams(None, int(p.bitDepth), int(p.samplesPerLine), int(p.ascansPerBscan), int(p.bscansPerBuffer),
+                       int(p.buffersPerVolume), 2, 0, 0, 1, 1)
+    fp = C.create_string_buffer(1024)
+    check(_lib.lib().octhost_load_settings_ini(path.encode(), C.byref(pod), C.byref(cs), C.byref(vs), fp, 1024))
+    for name, _ in PipeParams._fields_:
+        setattr(p, name, getattr(pod, name))
+    p.c0, p.c1, p.c2, p.c3 = list(cs.c)
+    p.d0, p.d1, p.d2, p.d3 = list(cs.d)
+    p.window, p.windowCenter, p.windowFillFactor = WindowType(cs.windowType), cs.windowCenter, cs.windowFillFactor
+    p.samplesPerLine, p.ascansPerBscan, p.bscansPerBuffer = vs.width, vs.height, vs.depth
+    p.buffersPerVolume, p.bitDepth = vs.buffersPerVolume, vs.bitDepth
+    p.useCustomResampleCurve = bool(cs.customResampling)
+    if p.useCustomResampleCurve and cs.customResamplingFilePath:
+        p.customResampleCurve = load_curve_csv(cs.customResamplingFilePath.decode())
+    p.update_all_curves()
+    vsys = {"file_path": fp.value.decode(), "bit_depth": vs.bitDepth, "width": vs.width, "height": vs.height, "depth": vs.depth,
+            "buffers_per_volume": vs.buffersPerVolume, "buffers_from_file": vs.buffersFromFile, "bscan_offset": vs.bscanOffset,
+            "wait_time_us": vs.waitTimeUs, "copy_file_to_ram": bool(vs.copyFileToRam), "sync_with_processing": bool(vs.syncWithProcessing)}
+    return p, vsys

@@ -1,0 +1,107 @@
+"""Settings INI and curve CSV readers: the reference's own published settings file
+must reproduce the benchmark parameter set.  CPU only."""
+import os
+
+import numpy as np
+
+from octproz_amd import params as P
+
+# the [processing] / [streaming] / [Virtual OCT System] groups of the reference's
+# performance/v180/20250504_performance_v180_gtx1080/20250504_octproz_settings.ini (values only: a fixture)
+V180_INI = """[General]
+timestamp=20250504_141131540
+
+[record]
+record_processed=true
+save_as_32_bit_float=false
+
+[processing]
+addend=0
+bitshift=false
+coeff=1
+dispersion_compensation=true
+dispersion_compensation_d0=0
+dispersion_compensation_d1=97
+dispersion_compensation_d2=-96.625
+dispersion_compensation_d3=-0.375
+fixed_pattern_removal=true
+fixed_pattern_removal_continuously=false
+fixed_pattern_removal_bscans=1
+flip_bscans=false
+log=true
+max=100
+min=-30
+resampling=true
+resampling_c0=0.535239
+resampling_c1=871.817574
+resampling_c2=-170.633784
+resampling_c3=97.249716
+resampling_interpolation=1
+sinusoidal_scan_correction=false
+window_center_position=0.5
+window_fill_factor=0.95
+window_type=0
+windowing=true
+background_removal=false
+background_removal_window_size=8
+custom_resampling=false
+custom_resampling_filepath=
+post_processing_background_removal=false
+post_processing_background_removal_offset=0
+post_processing_background_removal_weight=1
+
+[streaming]
+streaming_enabled=true
+streaming_skip=0
+
+[Virtual%20OCT%20System]
+bit_depth=12
+buffers_from_file=2
+buffers_per_volume=1
+depth=256
+file_path=C:/test_data_raw.raw
+height=512
+wait_time=0
+width=1024
+copy_file_to_ram=true
+bscan_offset=0
+sync_with_processing=true
+"""
+
+
+def test_reference_settings_file_reproduces_the_benchmark_parameters(tmp_path):
+    path = os.path.join(tmp_path, "settings.ini")
+    open(path, "w").write(V180_INI)
+    p, vsys = P.load_settings_ini(path)
+    want = P.v180_benchmark_params(1024, 512, 256)
+    for name, _ in P.PipeParams._fields_:
+        if name in ("streamToHost",):
+            continue
+        assert getattr(p, name) == getattr(want, name), name
+    assert p.streamToHost == 1  # the published run had streaming enabled
+    assert (p.samplesPerLine, p.ascansPerBscan, p.bscansPerBuffer, p.buffersPerVolume, p.bitDepth) == (1024, 512, 256, 1, 12)
+    for a, b in ((p.resampleCurve, want.resampleCurve), (p.dispersionCurve, want.dispersionCurve), (p.windowCurve, want.windowCurve)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert vsys["file_path"] == "C:/test_data_raw.raw" and vsys["buffers_from_file"] == 2 and vsys["sync_with_processing"]
+
+
+def test_curve_csv_round_trip_and_reference_format(tmp_path):
+    path = os.path.join(tmp_path, "resampling.csv")
+    curve = np.linspace(0.25, 1020.5, 1024, dtype=np.float32)
+    P.save_curve_csv(path, curve)
+    lines = open(path).read().splitlines()
+    assert lines[0] == "Sample Number;Sample Value" and lines[1].startswith("0;") and len(lines) == 1025
+    back = P.load_curve_csv(path)
+    assert np.array_equal(back, curve)
+    # a file as the reference writes it (QTextStream default float formatting, extra column, empty field)
+    open(path, "w").write("Sample Number;Sample Value\n0;1.5\n1;2.25;x\n2;\n3;-7e-1\n")
+    assert np.allclose(P.load_curve_csv(path), [1.5, 2.25, 0.0, -0.7])
+
+
+def test_custom_resampling_curve_from_settings(tmp_path):
+    csv = os.path.join(tmp_path, "resampling.csv")
+    P.save_curve_csv(csv, np.arange(1024, dtype=np.float32) * 0.5)
+    ini = os.path.join(tmp_path, "s.ini")
+    open(ini, "w").write(V180_INI.replace("custom_resampling=false", "custom_resampling=true").replace("custom_resampling_filepath=", "custom_resampling_filepath=" + csv))
+    p, _ = P.load_settings_ini(ini)
+    assert p.useCustomResampleCurve and np.array_equal(p.resampleCurve, np.arange(1024, dtype=np.float32) * 0.5)
