@@ -1,15 +1,17 @@
-// launch.h -- host-visible launchers of the fused kernel, one per transform length
+// launch.h -- host-visible launchers of the fused kernels, one translation unit per transform length
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "bluestein.h"
 #include "kernels.h"
 
 namespace oct {
 
-#define OCT_DECL_LAUNCH(L)                                                                                 \
-	hipError_t launch_fused_##L(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a, int requestedBlocks, \
-	                            hipStream_t stream, int* blocksUsed);                                                \
-	int fused_twiddle_plan_##L(int* radices);
+#define OCT_DECL_LAUNCH(L)                                                                                                  \
+	hipError_t launch_fused_##L(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,              \
+	                            int requestedBlocks, hipStream_t stream, int* blocksUsed);                                   \
+	int fused_twiddle_plan_##L(int* radices);                                                                                \
+	hipError_t launch_bluestein_##L(int rs, bool spectrum, bool logScale, const BluesteinArgs& a, hipStream_t stream);
 OCT_DECL_LAUNCH(8)
 OCT_DECL_LAUNCH(9)
 OCT_DECL_LAUNCH(10)
@@ -17,7 +19,15 @@ OCT_DECL_LAUNCH(11)
 OCT_DECL_LAUNCH(12)
 #undef OCT_DECL_LAUNCH
 
+// power-of-two lengths run the direct FFT
 inline bool fused_supported(unsigned n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
+// every other length up to 2048 runs Bluestein on the padded length 2^log2m >= 2n-1 (log2m in 8..12)
+inline int bluestein_log2m(unsigned n) {
+	if (n < 8 || n > 2048 || fused_supported(n)) return -1;
+	int l = 8;
+	while ((1u << l) < 2 * n - 1) l++;
+	return l <= 12 ? l : -1;
+}
 
 inline hipError_t launch_fused(int log2n, int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,
                                int requestedBlocks, hipStream_t stream, int* blocksUsed) {
@@ -27,6 +37,17 @@ inline hipError_t launch_fused(int log2n, int intype, int rs, bool roll, bool sp
 	case 10: return launch_fused_10(intype, rs, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	case 11: return launch_fused_11(intype, rs, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	case 12: return launch_fused_12(intype, rs, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+inline hipError_t launch_bluestein(int log2m, int rs, bool spectrum, bool logScale, const BluesteinArgs& a, hipStream_t stream) {
+	switch (log2m) {
+	case 8: return launch_bluestein_8(rs, spectrum, logScale, a, stream);
+	case 9: return launch_bluestein_9(rs, spectrum, logScale, a, stream);
+	case 10: return launch_bluestein_10(rs, spectrum, logScale, a, stream);
+	case 11: return launch_bluestein_11(rs, spectrum, logScale, a, stream);
+	case 12: return launch_bluestein_12(rs, spectrum, logScale, a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

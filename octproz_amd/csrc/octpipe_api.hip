@@ -75,6 +75,9 @@ struct octpipe {
 	float4* d_segs = nullptr;
 	float* d_dispBscan = nullptr;
 	float* d_dispEnFace = nullptr;
+	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
+	f2* d_filter = nullptr;    // [M] Bluestein filter spectrum
+	f2* d_outChirp = nullptr;  // [N] c[k] / M
 
 	std::vector<float> resample, dispersion, window, phase;  // host copies (N each, phase 2N); zero like cu:1082-1085
 	std::vector<float> h_postBg;                             // host shadow of the recorded background
@@ -148,6 +151,12 @@ int uploadLut(octpipe* h) {
 		e.y = p.windowing ? h->window[j] : 1.0f;
 		e.z = p.dispersionCompensation ? h->phase[2 * j] : 1.0f;
 		e.w = p.dispersionCompensation ? h->phase[2 * j + 1] : 0.0f;
+		if (h->bluestein) {  // fold the input chirp c[j] = e^{+i pi j^2 / N} into the phasor (float64 product)
+			const double ang = 3.14159265358979323846 * (double)(((long long)j * j) % (2LL * N)) / (double)N;
+			const double cr = cos(ang), ci = sin(ang), pr = e.z, pi = e.w;
+			e.z = (float)(pr * cr - pi * ci);
+			e.w = (float)(pr * ci + pi * cr);
+		}
 		lut[j] = e;
 	}
 	HIP_TRY(hipMemcpyAsync(h->d_lut, lut.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
@@ -188,8 +197,39 @@ int ensure(void** p, size_t bytes) {
 	return OCTPIPE_OK;
 }
 
+// Bluestein tables for a non-power-of-two length N on the padded length M (float64 on the host):
+//   filter  Bt = IFFT_M(b),  b[m] = b[M-m] = conj(c[m]) for m < N, 0 elsewhere,  c[m] = e^{+i pi m^2/N}
+//   outChirp[k] = c[k] / M
+int uploadBluesteinTables(octpipe* h) {
+	const int N = h->N, M = 1 << h->log2n;
+	const double pi = 3.14159265358979323846;
+	std::vector<double> cr(N), ci(N), wr(M), wi(M);
+	for (int m = 0; m < N; ++m) {
+		const double ang = pi * (double)(((long long)m * m) % (2LL * N)) / (double)N;
+		cr[m] = cos(ang); ci[m] = sin(ang);
+	}
+	for (int j = 0; j < M; ++j) { wr[j] = cos(2.0 * pi * j / M); wi[j] = sin(2.0 * pi * j / M); }
+	std::vector<f2> filter(M), chirp(N);
+	for (int k = 0; k < M; ++k) {
+		double sr = cr[0], si = -ci[0];  // m = 0
+		for (int m = 1; m < N; ++m) {
+			// b[m] e^{+2 pi i mk/M} + b[M-m] e^{+2 pi i (M-m)k/M} = conj(c[m]) * 2 cos(2 pi mk/M)
+			const double t = 2.0 * wr[(int)(((long long)m * k) % M)];
+			sr += cr[m] * t;
+			si -= ci[m] * t;
+		}
+		filter[k] = f2{(float)sr, (float)si};
+	}
+	for (int k = 0; k < N; ++k) chirp[k] = f2{(float)(cr[k] / M), (float)(ci[k] / M)};
+	HIP_TRY(hipMalloc((void**)&h->d_filter, sizeof(f2) * M));
+	HIP_TRY(hipMalloc((void**)&h->d_outChirp, sizeof(f2) * N));
+	HIP_TRY(hipMemcpy(h->d_filter, filter.data(), sizeof(f2) * M, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(h->d_outChirp, chirp.data(), sizeof(f2) * N, hipMemcpyHostToDevice));
+	return OCTPIPE_OK;
+}
+
 bool needsPrepared(const octpipe* h) {
-	return h->forcePrepared || h->bytesPerSample != 2 || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
+	return h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
 }
 
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
@@ -242,7 +282,28 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, nullptr));
+	if (h->bluestein) {
+		oct::BluesteinArgs b{};
+		b.samples = h->d_prepared;
+		b.out = out;
+		b.spectrum = spectrumOut;
+		b.lut = h->d_lut;
+		b.filter = h->d_filter;
+		b.outChirp = h->d_outChirp;
+		b.twiddle = h->d_twiddle;
+		b.meanLine = h->d_meanLine;
+		b.N = (unsigned)h->N;
+		b.numLines = lines;
+		b.linesInBuffer = a.linesInBuffer;
+		b.ascansPerBscan = a.ascansPerBscan;
+		b.flip = a.flip;
+		b.subtractMean = a.subtractMean;
+		b.sA = a.sA;
+		b.sB = a.sB;
+		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
+	} else {
+		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, nullptr));
+	}
 	if (timeIt && h->timing) {
 		HIP_TRY(hipEventRecord(t.stop, h->stream));
 		h->timed.push_back(t);
@@ -397,8 +458,8 @@ int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* 
 	*out = nullptr;
 	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
-	if (!oct::fused_supported(acq->samplesPerLine))
-		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must be 256, 512, 1024, 2048 or 4096 in this build");
+	if (!oct::fused_supported(acq->samplesPerLine) && oct::bluestein_log2m(acq->samplesPerLine) < 0)
+		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must be 256, 512, 1024, 2048, 4096 or any other length in 8..2047 in this build");
 	int count = 0;
 	int rc = octpipe_device_count(&count);
 	if (rc) return rc;
@@ -417,6 +478,10 @@ int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* 
 	if (h->bytesPerSample == 3) h->bytesPerSample = 4;    // 17..24 bit live in uint32 (cu:122-124)
 	h->log2n = 0;
 	while ((1 << h->log2n) < h->N) h->log2n++;
+	if (!oct::fused_supported(acq->samplesPerLine)) {
+		h->bluestein = true;
+		h->log2n = oct::bluestein_log2m(acq->samplesPerLine);
+	}
 	h->resample.assign(h->N, 0.0f);
 	h->dispersion.assign(h->N, 0.0f);
 	h->window.assign(h->N, 0.0f);
@@ -441,6 +506,7 @@ int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* 
 	if ((rc = ensure((void**)&h->d_dispBscan, sizeof(float) * ((size_t)h->N * h->A / 2)))) return rc;
 	if ((rc = ensure((void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
 	if ((rc = uploadTwiddles(h))) return rc;
+	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
 	hipLaunchKernelGGL(oct::oct_fill_sinus_curve_kernel, dim3((h->A + 255) / 256), dim3(256), 0, h->stream, h->d_sinusCurve, h->A);  // cu:1093
 	HIP_TRY(hipGetLastError());
 	// ring slots: pinned here, unpinned in octpipe_destroy (cu:1135-1136, 1200-1207)
@@ -471,7 +537,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace};
+	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_filter, h->d_outChirp};
 	for (void* b : bufs) if (b) hipFree(b);
 	if (h->copyStream) hipStreamDestroy(h->copyStream);
 	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);

@@ -152,6 +152,46 @@ def test_every_supported_length(N):
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("N", [1664, 1000, 1536, 300, 96, 2046])
+@pytest.mark.parametrize("interp", [INTERPOLATION.CUBIC, INTERPOLATION.LINEAR, INTERPOLATION.LANCZOS])
+def test_non_power_of_two_lengths_bluestein(N, interp):
+    """the reference gives any samplesPerLine to cuFFT (cu:1140); its own recording has 1664 samples"""
+    if interp != INTERPOLATION.CUBIC and N not in (1664, 300):
+        pytest.skip("interpolation variants on two lengths only")
+    A, B = 20, 2
+    p = v180_benchmark_params(N, A, B)
+    p.resamplingInterpolation = interp
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N)
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "N=%d" % N)
+    spec = pipe.debug_spectrum(d.data_ptr(), A * B)
+    ospec = o.last_spectrum().reshape(-1, N).copy()
+    ospec[:, :N // 2] += o.mean_line()[:N // 2]
+    common.compare_spectra(spec, ospec, N, "N=%d" % N)
+    pipe.close(); o.close()
+
+
+def test_non_power_of_two_fpn_determination_and_flip():
+    N, A, B = 1664, 24, 4
+    p = v180_benchmark_params(N, A, B)
+    p.bscanFlip = 1
+    raw = synthetic_raw(N, A, B, seed=77)
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    m_gpu, m_cpu = pipe.mean_line(), o.mean_line()
+    scale = np.abs(m_cpu[:N // 2]) + 1.0
+    assert (np.abs(m_gpu[:N // 2] - m_cpu[:N // 2]) <= 1e-3 * scale).mean() > 0.9
+    pipe.set_mean_line(m_cpu, pin=True)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    common.compare_images(pipe.processed_host(), want, p, "N=1664 flip")
+    pipe.close(); o.close()
+
+
 @pytest.mark.parametrize("bits,dtype", [(8, np.uint8), (32, np.uint32)])
 def test_other_container_types(bits, dtype):
     N, A, B = 512, 8, 2
