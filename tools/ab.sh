@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: scratch/ab.sh name1 name2 ...   (variants in scratch/variants/lib_<name>.so; "base" = in-tree lib)
+# usage: tools/ab.sh name1 name2 ...   (variants in scratch/variants/lib_<name>.so; "base" = in-tree lib)
+# Interleaved A/B: two rounds over all variants in one box session (box-to-box variance is ~4 %).
 for round in 1 2; do
 for v in "$@"; do
   if [ "$v" = base ]; then unset OCTPIPE_LIB; else export OCTPIPE_LIB=$PWD/scratch/variants/lib_$v.so; fi
