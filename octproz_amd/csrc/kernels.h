@@ -100,12 +100,12 @@ OCT_DEV void buf_store128(f32x4 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 }
 
 // ------------------------------------------------------------------ raw chunk = SPL consecutive samples per lane
-// uint16 rows are fetched 16 bytes per lane (8 samples, one buffer_load_dwordx4 per KiB): the
-// texture-address unit spends ~16 cycles per wave instruction whatever its width, so the number of
-// vector-memory instructions per A-scan is what bounds this kernel, not the bytes.
+// The texture-address unit spends ~16 cycles per vector-memory wave instruction whatever its width,
+// so the NUMBER of such instructions per A-scan matters as much as the bytes: a uint16 row costs
+// N/256 loads of 8 B per lane, the image N/512 stores of 16 B per lane.
 template <int INTYPE, int N> struct Chunk;
 template <int N> struct Chunk<IN_U16, N> {
-	static constexpr int SPL = N >= 512 ? 8 : 4, BYTES = SPL * 2;
+	static constexpr int SPL = 4, BYTES = SPL * 2;  // 8 B per lane: the float4 LDS writes of consecutive lanes stay contiguous (conflict-free)
 	typedef u32x4 T;  // SPL = 4 uses .x/.y only
 };
 template <int N> struct Chunk<IN_F32, N> { static constexpr int SPL = 4, BYTES = 16; typedef u32x4 T; };
@@ -304,6 +304,10 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 		}
 	}
 	float* rowl = row + ROW_OFF + lane;
+	// LDS byte address of tap 0 (= sample -1) of this wave's row, as a scalar: tap address = tapBase + 4*n1
+	typedef __attribute__((address_space(3))) const float lds_cfloat;
+	const uint32_t tapBase = __builtin_amdgcn_readfirstlane(
+	    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
 
 	for (; line < a.numLines; line += wavesTotal) {
 		// ---- stage the raw row in LDS as float32
@@ -373,12 +377,13 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 			float y;
 			if constexpr (RS == RS_CUBIC) {
 				const int n1 = (int)L.x;
-				const float* t = &row[ROW_OFF - 1 + n1];
-				y = cubic_hermite(t[0], t[1], t[2], t[3], L.x - (float)n1);
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + 4u * (uint32_t)n1);
+				// rho >= 0: fract(rho) == rho - (float)n1 exactly (cu:293 `nx - n1`)
+				y = cubic_hermite(t[0], t[1], t[2], t[3], __builtin_amdgcn_fractf(L.x));
 			} else if constexpr (RS == RS_LINEAR) {
 				const int n1 = (int)L.x;
-				const float* t = &row[ROW_OFF + n1];
-				y = t[0] + (t[1] - t[0]) * (L.x - (float)n1);
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + 4u * (uint32_t)n1 + 4u);
+				y = t[0] + (t[1] - t[0]) * __builtin_amdgcn_fractf(L.x);
 			} else if constexpr (RS == RS_NONE) {
 				y = rowl[64 * q];
 			} else {
