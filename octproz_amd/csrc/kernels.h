@@ -54,7 +54,7 @@ template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
 template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
 template <> struct Cfg<10> { static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; };
-template <> struct Cfg<11> { static constexpr int WAVES = 4,  MINW = 2; static constexpr bool LDS_LUT = false; };
+template <> struct Cfg<11> { static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = true; };
 template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; };
 constexpr int fused_waves_per_block(int log2n) {
 	return log2n == 8 ? Cfg<8>::WAVES : log2n == 9 ? Cfg<9>::WAVES : log2n == 10 ? Cfg<10>::WAVES : log2n == 11 ? Cfg<11>::WAVES : Cfg<12>::WAVES;
