@@ -513,3 +513,65 @@ def test_full_size_config2_1024x512x256():
 def test_full_size_config3_2048x1024x512_in_slabs():
     """config 3 is 2 GiB of raw data; one 2048 x 1024 x 128 slab (512 MiB) exercises the 64-bit indexing"""
     _full_size(2048, 1024, 128, sample_lines=1024)
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("A,B", [(1, 1), (1, 2), (3, 1), (64, 1)])
+def test_tiny_and_single_line_buffers(A, B):
+    N = 1024
+    p = v180_benchmark_params(N, A, B)
+    p.fixedPatternNoiseRemoval = 0  # fewer than 9 lines: the FPN estimate is degenerate (segWidth = 0)
+    raw = synthetic_raw(N, A, B, seed=A * 10 + B)
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "A=%d B=%d" % (A, B))
+    pipe.close(); o.close()
+
+
+def test_fpn_with_fewer_than_nine_lines_gives_zero_mean_like_the_reference():
+    """segWidth = H/9 = 0: factor = inf, sums are 0 -> NaN variance never beats FLT_MAX -> mean stays 0 (cu:531-564)"""
+    N, A, B = 512, 4, 2
+    p = v180_benchmark_params(N, A, B)
+    raw = synthetic_raw(N, A, B, seed=1)
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    assert np.all(pipe.mean_line() == 0) and np.all(o.mean_line() == 0)
+    common.compare_images(pipe.processed_host(), want, p, "degenerate fpn")
+    pipe.close(); o.close()
+
+
+def test_bscans_for_noise_larger_than_buffer_is_clamped():
+    N, A, B = 512, 24, 2
+    p = v180_benchmark_params(N, A, B)
+    p.bscansForNoiseDetermination = 7  # > B: the reference would read past its buffer; both sides clamp to B
+    raw = synthetic_raw(N, A, B, seed=2)
+    o = common.make_oracle(p)
+    o.process(raw)
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    m_gpu, m_cpu = pipe.mean_line(), o.mean_line()
+    scale = np.abs(m_cpu[:N // 2]) + 1.0
+    assert (np.abs(m_gpu[:N // 2] - m_cpu[:N // 2]) <= 1e-3 * scale).mean() > 0.9
+    pipe.close(); o.close()
+
+
+def test_parameter_change_between_buffers_takes_effect():
+    """the reference reads the parameter block on every buffer (cu:1409-1604) and re-uploads dirty curves"""
+    N, A, B = 1024, 24, 2
+    p = v180_benchmark_params(N, A, B)
+    raw = synthetic_raw(N, A, B, seed=3)
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "before")
+    p.c1 = 860.0                       # new resampling curve
+    p.window = WindowType.Gauss        # new window
+    p.signalGrayscaleMax = 90.0
+    p.update_all_curves()
+    o2 = common.make_oracle(p); o2.set_mean_line(o.mean_line())
+    want2 = o2.process(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    common.compare_images(pipe.processed_host(), want2, p, "after")
+    assert not np.array_equal(want, want2)
+    pipe.close(); o.close(); o2.close()
