@@ -51,11 +51,11 @@ struct FusedArgs {
 // N = 1024: 16 waves x 8.5 KiB + 24 KiB of tables = 159.9 KiB -> one 1024-thread workgroup per CU,
 // 4 waves per SIMD.
 template <int LOG2N> struct Cfg;
-template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
-template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; };
-template <> struct Cfg<10> { static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; };
-template <> struct Cfg<11> { static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = true; };
-template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; };
+template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
+template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
+template <> struct Cfg<10> { static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
+template <> struct Cfg<11> { static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
+template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = false; };
 constexpr int fused_waves_per_block(int log2n) {
 	return log2n == 8 ? Cfg<8>::WAVES : log2n == 9 ? Cfg<9>::WAVES : log2n == 10 ? Cfg<10>::WAVES : log2n == 11 ? Cfg<11>::WAVES : Cfg<12>::WAVES;
 }
@@ -362,6 +362,11 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 		}
 
 		// ---- k-linearisation x window x dispersion phasor -> complex points in registers
+		// Static per-phase wave priority (s_setprio): waves that are gathering beat waves in the FFT,
+		// which beat waves in the epilogue, which beat waves staging/prefetching.  With 16 waves per CU
+		// all in different phases this keeps the LDS-latency-bound gather from queueing behind the
+		// VALU-dense FFT of its SIMD neighbours: +7 % A-scans/s measured.
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(3);
 		f2 v[P];
 #pragma unroll
 		for (int q = 0; q < P; q++) {
@@ -404,7 +409,9 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 		wave_sync_lds();  // the row is dead from here on; its LDS is reused by the FFT
 
 		// ---- inverse FFT
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(2);
 		fft_wave<LOG2N, !SPECTRUM>(v, xbuf, tw, lane);
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(1);
 
 		if constexpr (SPECTRUM) {
 			f2* dst = a.spectrum + (size_t)line * N + NBL * lane;
@@ -440,6 +447,7 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 				else buf_store32(o[0], outR, lane * 4, u * (N / RL) * 4);
 			}
 		}
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(0);
 		wave_sync_lds();
 	}
 }
