@@ -108,13 +108,13 @@ __global__ __launch_bounds__(bluestein_waves<LOG2M>() * 64) void oct_bluestein_k
 		}
 		wave_sync_lds();
 
-		// ---- t = IFFT_M(a);  p = conj(t * Bt)  (bins in the contiguous layout of fft_wave)
+		// ---- t = IFFT_M(a);  p = conj(t * Bt)  (bin layout of fft_wave: fft_bin)
 		fft_wave<LOG2M, false>(v, xbuf, tw, lane);
 #pragma unroll
 		for (int u = 0; u < RL; u++)
 #pragma unroll
 			for (int m = 0; m < NBL; m++) {
-				const int bin = NBL * lane + m + u * (M / RL);
+				const int bin = fft_bin<LOG2M>(lane, m, u);
 				const f2 t = octfft::cmul(v[m + u * NBL], a.filter[bin]);
 				xbuf[pad16c(0) + bin + (bin >> 4)] = f2{t.x, -t.y};
 			}
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(bluestein_waves<LOG2M>() * 64) void oct_bluestein_k
 		for (int u = 0; u < RL; u++)
 #pragma unroll
 			for (int m = 0; m < NBL; m++) {
-				const int k = NBL * lane + m + u * (M / RL);
+				const int k = fft_bin<LOG2M>(lane, m, u);
 				if (k < (SPECTRUM ? N : half)) {
 					const f2 r = v[m + u * NBL];
 					f2 z = octfft::cmul(f2{r.x, -r.y}, a.outChirp[k]);

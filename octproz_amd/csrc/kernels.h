@@ -50,15 +50,22 @@ struct FusedArgs {
 // one LDS copy of the twiddle tables, the mean A-line and (LDS_LUT) the resampling/window/phasor LUT.
 // N = 1024: 16 waves x 8.5 KiB + 24 KiB of tables = 159.9 KiB -> one 1024-thread workgroup per CU,
 // 4 waves per SIMD.
+// WAVES/MINW: waves per workgroup / minimum waves per SIMD (register budget); LDS_LUT: resampling +
+// window*phasor tables in LDS (else fetched through L1/L2); PRIO: static per-phase wave priority;
+// MEAN_REGS: the lane's share of the mean A-line lives in VGPRs for the whole persistent loop;
+// WAVES_CW > 0: the cubic variant gathers with precomputed Catmull-Rom weights (16 B + 8 B of LDS
+// table per sample instead of 4 B + 8 B) and runs WAVES_CW waves per workgroup so that it fits.
 template <int LOG2N> struct Cfg;
-template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
-template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
-template <> struct Cfg<10> { static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
-template <> struct Cfg<11> { static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; };
-template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = false; };
-constexpr int fused_waves_per_block(int log2n) {
-	return log2n == 8 ? Cfg<8>::WAVES : log2n == 9 ? Cfg<9>::WAVES : log2n == 10 ? Cfg<10>::WAVES : log2n == 11 ? Cfg<11>::WAVES : Cfg<12>::WAVES;
-}
+template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
+template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
+template <> struct Cfg<10> { static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 15; };
+template <> struct Cfg<11> { static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
+template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = false; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
+// per kernel variant: the cubic gather with precomputed weights trades waves for a larger table
+template <int LOG2N, int RS> struct KCfg {
+	static constexpr bool CW = RS == RS_CUBIC && Cfg<LOG2N>::LDS_LUT && Cfg<LOG2N>::WAVES_CW > 0;
+	static constexpr int WAVES = CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
+};
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
 
@@ -157,13 +164,14 @@ OCT_DEV float lanczos8(float x) {
 // All LDS addresses are "per-lane base + compile-time offset" (immediate fields, no VALU).
 constexpr int pad16c(int j) { return j + (j >> 4); }
 
-template <int N, int R, int NS, bool FIRST, bool LAST, bool PRUNE>
+// READ: fetch the pass input from the LDS slice (else it is already in v in the strided mapping);
+// WRITE: store the pass output to the slice (else it stays in v: v[m + u*NB] = element j0 + u*NS).
+template <int N, int R, int NS, bool READ, bool WRITE, bool CONTIG, bool PRUNE>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 	constexpr int P = N / 64, NB = P / R;
-	constexpr bool CONTIG = LAST && NB == 4;
 	static_assert(NB >= 1, "radix larger than points per lane");
-	static_assert(!LAST || NB == 1 || NB == 4, "last pass: one or four butterflies per lane");
-	if constexpr (!FIRST) {
+	static_assert(!CONTIG || (READ && !WRITE && NB == 4), "contiguous mapping: last pass, four butterflies per lane");
+	if constexpr (READ) {
 		if constexpr (CONTIG) {
 			const f2* rb = xbuf + (4 * lane + (lane >> 2));
 #pragma unroll
@@ -187,8 +195,8 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 		}
 	}
 #pragma unroll
-	for (int m = 0; m < NB; m++) octfft::Dft<R, NB, LAST && PRUNE>::run(&v[m]);
-	if constexpr (!LAST) {
+	for (int m = 0; m < NB; m++) octfft::Dft<R, NB, PRUNE>::run(&v[m]);
+	if constexpr (WRITE) {
 #pragma unroll
 		for (int m = 0; m < NB; m++) {
 			const int b = lane + 64 * m;
@@ -202,11 +210,13 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 }
 
 template <int LOG2N> struct Plan;
-template <> struct Plan<8>  { static constexpr int R0 = 4,  R1 = 4,  R2 = 4,  R3 = 4; };
-template <> struct Plan<9>  { static constexpr int R0 = 8,  R1 = 8,  R2 = 8,  R3 = 1; };
-template <> struct Plan<10> { static constexpr int R0 = 16, R1 = 16, R2 = 4,  R3 = 1; };
-template <> struct Plan<11> { static constexpr int R0 = 16, R1 = 16, R2 = 8,  R3 = 1; };
-template <> struct Plan<12> { static constexpr int R0 = 16, R1 = 16, R2 = 16, R3 = 1; };
+// PERM: the exchange in front of the last (radix-4) pass is a 4x4 transpose between lane bits 5:4 and
+// two register-index bits -- done with v_permlane32_swap / v_permlane16_swap instead of through LDS.
+template <> struct Plan<8>  { static constexpr int R0 = 4,  R1 = 4,  R2 = 4,  R3 = 4; static constexpr bool PERM = false; };
+template <> struct Plan<9>  { static constexpr int R0 = 8,  R1 = 8,  R2 = 8,  R3 = 1; static constexpr bool PERM = false; };
+template <> struct Plan<10> { static constexpr int R0 = 16, R1 = 16, R2 = 4,  R3 = 1; static constexpr bool PERM = true; };
+template <> struct Plan<11> { static constexpr int R0 = 16, R1 = 16, R2 = 8,  R3 = 1; static constexpr bool PERM = false; };
+template <> struct Plan<12> { static constexpr int R0 = 16, R1 = 16, R2 = 16, R3 = 1; static constexpr bool PERM = false; };
 
 // entries of the per-pass twiddle tables: sum over passes with NS > 1 of (R-1)*NS
 template <int LOG2N> constexpr int twiddle_count() {
@@ -219,9 +229,53 @@ template <int LOG2N> constexpr int twiddle_count() {
 }
 template <int LOG2N> struct LastRadix { static constexpr int value = Plan<LOG2N>::R3 == 1 ? Plan<LOG2N>::R2 : Plan<LOG2N>::R3; };
 
+// In-register exchange in front of a radix-4 last pass whose predecessor is a radix-16 pass with one
+// butterfly per lane (P = 16).  After that pass lane t holds element 256*(t>>4) + (t&15) + 16*u in v[u];
+// the last pass wants element lane + 64*m + 256*a in v[m + 4*a], i.e. v[4*m + (l>>4)] of lane
+// 16*a + (l&15): for every m a 4x4 transpose of (lane bits 5:4) x (u & 3), two swap steps per dword.
+OCT_DEV void perm_swap32(float& a, float& b) {
+	const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+	const unsigned r0 = r[0], r1 = r[1];  // (bit_cast of a vector-element expression would read element 0)
+	a = __builtin_bit_cast(float, r0);
+	b = __builtin_bit_cast(float, r1);
+}
+OCT_DEV void perm_swap16(float& a, float& b) {
+	const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+	const unsigned r0 = r[0], r1 = r[1];  // (bit_cast of a vector-element expression would read element 0)
+	a = __builtin_bit_cast(float, r0);
+	b = __builtin_bit_cast(float, r1);
+}
+OCT_DEV void perm_exchange16x4(f2 (&v)[16]) {
+#pragma unroll
+	for (int m = 0; m < 4; m++) {
+		float x[4], y[4];
+#pragma unroll
+		for (int c = 0; c < 4; c++) { x[c] = v[4 * m + c].x; y[c] = v[4 * m + c].y; }
+		perm_swap32(x[0], x[2]); perm_swap32(x[1], x[3]); perm_swap32(y[0], y[2]); perm_swap32(y[1], y[3]);  // lane bit 5 <-> c bit 1
+		perm_swap16(x[0], x[1]); perm_swap16(x[2], x[3]); perm_swap16(y[0], y[1]); perm_swap16(y[2], y[3]);  // lane bit 4 <-> c bit 0
+#pragma unroll
+		for (int c = 0; c < 4; c++) v[4 * m + c] = f2{x[c], y[c]};
+	}
+	f2 w[16];
+#pragma unroll
+	for (int m = 0; m < 4; m++)
+#pragma unroll
+		for (int a = 0; a < 4; a++) w[m + 4 * a] = v[4 * m + a];
+#pragma unroll
+	for (int i = 0; i < 16; i++) v[i] = w[i];
+}
+template <int P> OCT_DEV void perm_exchange(f2 (&v)[P]) {
+	if constexpr (P == 16) perm_exchange16x4(v);
+}
+
 // natural-order inverse FFT of v (element lane+64q).  With RL = radix of the last pass and
-// NB = P/RL the result bin is   NB == 4:  4*lane + m + u*N/RL     NB == 1:  lane + u*N/RL
-// held in v[m + u*NB].  PRUNE: only u < RL/2 valid.
+// NB = P/RL the result bin is   contiguous (NB == 4, !PERM):  4*lane + m + u*N/RL
+// strided (NB == 1 or PERM):  lane + 64*m + u*N/RL,   held in v[m + u*NB].  PRUNE: only u < RL/2 valid.
+// bin held in v[m + u*NB] after fft_wave (see above)
+template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
+	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value, NB = (N / 64) / RL;
+	return ((Plan<LOG2N>::PERM || NB == 1) ? lane + 64 * m : NB * lane + m) + u * (N / RL);
+}
 template <int LOG2N, bool PRUNE>
 OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane) {
 	constexpr int N = 1 << LOG2N;
@@ -229,23 +283,31 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
 	static_assert(R0 * R1 * R2 * R3 == N, "plan");
 	constexpr int T1 = 0, T2 = T1 + (R1 - 1) * R0, T3 = T2 + (R2 - 1) * R0 * R1;
-	fft_pass<N, R0, 1, true, false, PRUNE>(v, xbuf, tw, lane);
-	fft_pass<N, R1, R0, false, false, PRUNE>(v, xbuf, tw + T1, lane);
-	if constexpr (R3 == 1) {
-		fft_pass<N, R2, R0 * R1, false, true, PRUNE>(v, xbuf, tw + T2, lane);
+	constexpr int P = N / 64;
+	fft_pass<N, R0, 1, false, true, false, false>(v, xbuf, tw, lane);
+	if constexpr (PL::PERM) {
+		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
+		fft_pass<N, R1, R0, true, false, false, false>(v, xbuf, tw + T1, lane);
+		perm_exchange<P>(v);
+		fft_pass<N, R2, R0 * R1, false, false, false, PRUNE>(v, xbuf, tw + T2, lane);
+	} else if constexpr (R3 == 1) {
+		fft_pass<N, R1, R0, true, true, false, false>(v, xbuf, tw + T1, lane);
+		fft_pass<N, R2, R0 * R1, true, false, P / R2 == 4, PRUNE>(v, xbuf, tw + T2, lane);
 	} else {
-		fft_pass<N, R2, R0 * R1, false, false, PRUNE>(v, xbuf, tw + T2, lane);
-		fft_pass<N, R3, R0 * R1 * R2, false, true, PRUNE>(v, xbuf, tw + T3, lane);
+		fft_pass<N, R1, R0, true, true, false, false>(v, xbuf, tw + T1, lane);
+		fft_pass<N, R2, R0 * R1, true, true, false, false>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R3, R0 * R1 * R2, true, false, P / R3 == 4, PRUNE>(v, xbuf, tw + T3, lane);
 	}
 }
 
 // ------------------------------------------------------------------ the fused kernel
-// LDS of a workgroup: [twiddles | mean A-line (N/2 complex) | LUT: rho (N float) + window*phasor (N complex), LDS_LUT | WAVES x slice]
+// LDS of a workgroup: [twiddles | mean A-line (N/2 complex, unless MEAN_REGS) | LUT, LDS_LUT: rho (N float) or cubic
+// {tap offset, w0, w2, w3} (N x 16 B), then window*phasor (N complex) | WAVES x slice]
 template <int LOG2N> constexpr int tw_lds_bytes() { return (twiddle_count<LOG2N>() * 8 + 15) & ~15; }
-template <int LOG2N> constexpr int mean_lds_bytes() { return (1 << LOG2N) * 4; }
-template <int LOG2N> constexpr int lut_lds_bytes() { return Cfg<LOG2N>::LDS_LUT ? (1 << LOG2N) * 12 : 0; }
-template <int LOG2N> constexpr int block_lds_bytes() {
-	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N>() + Cfg<LOG2N>::WAVES * wave_lds_bytes<(1 << LOG2N)>();
+template <int LOG2N> constexpr int mean_lds_bytes() { return Cfg<LOG2N>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
+template <int LOG2N, int RS> constexpr int lut_lds_bytes() { return !Cfg<LOG2N>::LDS_LUT ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
+template <int LOG2N, int RS> constexpr int block_lds_bytes() {
+	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + KCfg<LOG2N, RS>::WAVES * wave_lds_bytes<(1 << LOG2N)>();
 }
 
 // MODE bits of the kernel template
@@ -257,11 +319,12 @@ enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4 };
 // (IN_U16 only); MODE_SPECTRUM = write the full complex spectrum instead of the processed half
 // A-scan; MODE_LOG = logarithmic grey-scale mapping (cu:718) instead of the linear one (cu:739).
 template <int LOG2N, int INTYPE, int RS, int MODE>
-__global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_fused_kernel(const FusedArgs a) {
+__global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) void oct_fused_kernel(const FusedArgs a) {
 	constexpr int N = 1 << LOG2N, P = N / 64;
-	constexpr int WAVES = Cfg<LOG2N>::WAVES, THREADS = WAVES * 64;
-	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT;
+	constexpr int WAVES = KCfg<LOG2N, RS>::WAVES, THREADS = WAVES * 64;
+	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = Cfg<LOG2N>::MEAN_REGS;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
+	constexpr bool STRIDED_OUT = Plan<LOG2N>::PERM || NBL == 1;  // bin = lane + 64*m + u*N/RL, else NBL*lane + m + u*N/RL
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (64 * SPL);
@@ -271,21 +334,31 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 	f2* tw = reinterpret_cast<f2*>(smem);
 	f2* meanL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>());
 	float* rhoL = reinterpret_cast<float*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>());
-	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + N * 4);
+	f32x4* cwL = reinterpret_cast<f32x4*>(rhoL);  // CW
+	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + N * (CW ? 16 : 4));
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
-	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N>() + wave * wave_lds_bytes<N>();
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + wave * wave_lds_bytes<N>();
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
 	// tables -> LDS, once per (persistent) workgroup
 	for (int i = tid; i < twiddle_count<LOG2N>(); i += THREADS) tw[i] = a.twiddle[i];
-	for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
+	if constexpr (!MEAN_REGS)
+		for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
 	if constexpr (LDS_LUT) {
 		for (int i = tid; i < N; i += THREADS) {
 			const float4 t = a.lut[i];
-			rhoL[i] = t.x;
 			wphL[i] = f2{t.y * t.z, t.y * t.w};  // window folded into the phasor (one rounding of difference)
+			if constexpr (CW) {
+				// cu:258-271 as weights of the four taps, y = y1 + w0 (y0-y1) + w2 (y2-y1) + w3 (y3-y1)
+				// with p = rho - n1 (exact in float): evaluated once per workgroup in double
+				const double p = (double)__builtin_amdgcn_fractf(t.x);
+				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+				cwL[i] = f32x4{__builtin_bit_cast(float, 4 * (int)t.x), (float)w0, (float)w2, (float)w3};
+			} else {
+				rhoL[i] = t.x;
+			}
 		}
 	}
 	__syncthreads();
@@ -302,6 +375,15 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 #pragma unroll
 			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
 		}
+	}
+	// the bins a lane finishes are the same for every A-scan it processes: its mean-line entries stay in registers
+	f2 mreg[MEAN_REGS && !SPECTRUM ? P / 2 : 1];
+	if constexpr (MEAN_REGS && !SPECTRUM) {
+#pragma unroll
+		for (int u = 0; u < RL / 2; u++)
+#pragma unroll
+			for (int m = 0; m < NBL; m++)
+				mreg[m + u * NBL] = a.subtractMean ? a.meanLine[(STRIDED_OUT ? lane + 64 * m : NBL * lane + m) + u * (N / RL)] : f2{0.0f, 0.0f};
 	}
 	float* rowl = row + ROW_OFF + lane;
 	// LDS byte address of tap 0 (= sample -1) of this wave's row, as a scalar: tap address = tapBase + 4*n1
@@ -373,14 +455,22 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 			// {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
 			f32x4 L;
 			f2 wph;
-			if constexpr (LDS_LUT) {
+			f32x4 cw;
+			if constexpr (CW) {
+				cw = cwL[lane + 64 * q];
+				wph = wphL[lane + 64 * q];
+			} else if constexpr (LDS_LUT) {
 				L.x = rhoL[lane + 64 * q];
 				wph = wphL[lane + 64 * q];
 			} else {
 				L = buf_load128(lutR, lane * 16, q * 1024);
 			}
 			float y;
-			if constexpr (RS == RS_CUBIC) {
+			if constexpr (CW) {
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + __builtin_bit_cast(u32x4, cw).x);
+				const float y1 = t[1];
+				y = y1 + cw.y * (t[0] - y1) + cw.z * (t[2] - y1) + cw.w * (t[3] - y1);
+			} else if constexpr (RS == RS_CUBIC) {
 				const int n1 = (int)L.x;
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + 4u * (uint32_t)n1);
 				// rho >= 0: fract(rho) == rho - (float)n1 exactly (cu:293 `nx - n1`)
@@ -414,10 +504,13 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(1);
 
 		if constexpr (SPECTRUM) {
-			f2* dst = a.spectrum + (size_t)line * N + NBL * lane;
+			f2* dst = a.spectrum + (size_t)line * N + (STRIDED_OUT ? 1 : NBL) * lane;
 #pragma unroll
 			for (int u = 0; u < RL; u++) {
-				if constexpr (NBL == 4) {
+				if constexpr (STRIDED_OUT) {
+#pragma unroll
+					for (int m = 0; m < NBL; m++) dst[64 * m + u * (N / RL)] = v[m + u * NBL];
+				} else if constexpr (NBL == 4) {
 					float4* d4 = reinterpret_cast<float4*>(dst + u * (N / RL));
 					d4[0] = float4{v[0 + 4 * u].x, v[0 + 4 * u].y, v[1 + 4 * u].x, v[1 + 4 * u].y};
 					d4[1] = float4{v[2 + 4 * u].x, v[2 + 4 * u].y, v[3 + 4 * u].x, v[3 + 4 * u].y};
@@ -432,19 +525,26 @@ __global__ __launch_bounds__(Cfg<LOG2N>::WAVES * 64, Cfg<LOG2N>::MINW) void oct_
 			// (cu:1547), so with an odd B-scan count the last one is left as it is
 			if (a.flip && (b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) as = a.ascansPerBscan - 1u - as;
 			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2), N * 2u);
-			const f2* ml = meanL + NBL * lane;
+			const f2* ml = meanL + (STRIDED_OUT ? 1 : NBL) * lane;
 #pragma unroll
 			for (int u = 0; u < RL / 2; u++) {
 				float o[NBL];
 #pragma unroll
 				for (int m = 0; m < NBL; m++) {
-					const f2 z = v[m + u * NBL] - ml[m + u * (N / RL)];
+					f2 z;
+					if constexpr (MEAN_REGS) z = v[m + u * NBL] - mreg[m + u * NBL];
+					else z = v[m + u * NBL] - ml[(STRIDED_OUT ? 64 * m : m) + u * (N / RL)];
 					const float p = z.x * z.x + z.y * z.y;
 					const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
 					o[m] = a.sA * s + a.sB;
 				}
-				if constexpr (NBL == 4) buf_store128(f32x4{o[0], o[1], o[2], o[3]}, outR, lane * 16, u * (N / RL) * 4);
-				else buf_store32(o[0], outR, lane * 4, u * (N / RL) * 4);
+				if constexpr (STRIDED_OUT) {
+#pragma unroll
+					for (int m = 0; m < NBL; m++) buf_store32(o[m], outR, lane * 4, (64 * m + u * (N / RL)) * 4);
+				} else {
+					static_assert(STRIDED_OUT || NBL == 4, "contiguous epilogue stores four bins per lane");
+					buf_store128(f32x4{o[0], o[1], o[2], o[3]}, outR, lane * 16, u * (N / RL) * 4);
+				}
 			}
 		}
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(0);
