@@ -25,8 +25,24 @@ __device__ constexpr float kSin16[16] = {
 	0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
 	-1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
 
-OCT_DEV f2 cmul(f2 a, f2 w) { return f2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+OCT_DEV f2 cmul(f2 a, f2 w) {
+	f2 t, r;
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+	return r;
+}
 OCT_DEV f2 mul_i(f2 a) { return f2{-a.y, a.x}; }   // a * (+i)
+// a + i*b and a - i*b in one packed add (operand swizzle + sign on the second source)
+OCT_DEV f2 add_i(f2 a, f2 b) {
+	f2 r;
+	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+OCT_DEV f2 sub_i(f2 a, f2 b) {
+	f2 r;
+	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
 
 // z * exp(+2*pi*i*M/16) with the cheap cases special-cased
 template <int M>
@@ -37,10 +53,10 @@ OCT_DEV f2 mul_w16(f2 z) {
 	else if constexpr (m == 4) return f2{-z.y, z.x};
 	else if constexpr (m == 8) return f2{-z.x, -z.y};
 	else if constexpr (m == 12) return f2{z.y, -z.x};
-	else if constexpr (m == 2) return f2{h * (z.x - z.y), h * (z.x + z.y)};
-	else if constexpr (m == 6) return f2{-h * (z.x + z.y), h * (z.x - z.y)};
-	else if constexpr (m == 10) return f2{-h * (z.x - z.y), -h * (z.x + z.y)};
-	else if constexpr (m == 14) return f2{h * (z.x + z.y), -h * (z.x - z.y)};
+	else if constexpr (m == 2) return add_i(z, z) * h;
+	else if constexpr (m == 6) return sub_i(z, z) * (-h);
+	else if constexpr (m == 10) return add_i(z, z) * (-h);
+	else if constexpr (m == 14) return sub_i(z, z) * h;
 	else return f2{z.x * kCos16[m] - z.y * kSin16[m], z.x * kSin16[m] + z.y * kCos16[m]};
 }
 
@@ -55,12 +71,12 @@ OCT_DEV void dft2(f2& a, f2& b) {
 // outputs natural order in (a,b,c,d) = X[0..3]; PRUNE: only X[0], X[1] valid
 template <bool PRUNE>
 OCT_DEV void dft4(f2& a, f2& b, f2& c, f2& d) {
-	f2 s02 = a + c, d02 = a - c, s13 = b + d, d13 = mul_i(b - d);
+	f2 s02 = a + c, d02 = a - c, s13 = b + d, t13 = b - d;
 	a = s02 + s13;
-	b = d02 + d13;
+	b = add_i(d02, t13);
 	if constexpr (!PRUNE) {
 		c = s02 - s13;
-		d = d02 - d13;
+		d = sub_i(d02, t13);
 	}
 }
 

@@ -128,6 +128,7 @@ template <int INTYPE>
 OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 	if constexpr (INTYPE == IN_U16) {
 		const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
+		if (s == 0) return float4{(float)(a & 0xffffu), (float)(a >> 16), (float)(b & 0xffffu), (float)(b >> 16)};
 		return float4{(float)((a & 0xffffu) >> s), (float)((a >> 16) >> s), (float)((b & 0xffffu) >> s), (float)((b >> 16) >> s)};
 	} else {
 		// (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)
@@ -301,8 +302,8 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 }
 
 // ------------------------------------------------------------------ the fused kernel
-// LDS of a workgroup: [twiddles | mean A-line (N/2 complex, unless MEAN_REGS) | LUT, LDS_LUT: rho (N float) or cubic
-// {tap offset, w0, w2, w3} (N x 16 B), then window*phasor (N complex) | WAVES x slice]
+// LDS of a workgroup: [twiddles | mean A-line (N/2 complex, unless MEAN_REGS) | LUT, LDS_LUT: rho (N float) or the four
+// cubic tap weights (N x 16 B), then window*phasor (N complex) | WAVES x slice]
 template <int LOG2N> constexpr int tw_lds_bytes() { return (twiddle_count<LOG2N>() * 8 + 15) & ~15; }
 template <int LOG2N> constexpr int mean_lds_bytes() { return Cfg<LOG2N>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
 template <int LOG2N, int RS> constexpr int lut_lds_bytes() { return !Cfg<LOG2N>::LDS_LUT ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
@@ -351,11 +352,11 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 			const float4 t = a.lut[i];
 			wphL[i] = f2{t.y * t.z, t.y * t.w};  // window folded into the phasor (one rounding of difference)
 			if constexpr (CW) {
-				// cu:258-271 as weights of the four taps, y = y1 + w0 (y0-y1) + w2 (y2-y1) + w3 (y3-y1)
-				// with p = rho - n1 (exact in float): evaluated once per workgroup in double
+				// cu:258-271 as weights of the four taps, y = w0 y0 + w1 y1 + w2 y2 + w3 y3 with
+				// p = rho - n1 (exact in float); evaluated once per workgroup in double, w1 = 1 - w0 - w2 - w3
 				const double p = (double)__builtin_amdgcn_fractf(t.x);
 				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
-				cwL[i] = f32x4{__builtin_bit_cast(float, 4 * (int)t.x), (float)w0, (float)w2, (float)w3};
+				cwL[i] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
 			} else {
 				rhoL[i] = t.x;
 			}
@@ -386,11 +387,16 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 				mreg[m + u * NBL] = a.subtractMean ? a.meanLine[(STRIDED_OUT ? lane + 64 * m : NBL * lane + m) + u * (N / RL)] : f2{0.0f, 0.0f};
 	}
 	float* rowl = row + ROW_OFF + lane;
+	uint32_t tapA[CW ? P : 1];  // CW: LDS byte address of tap 0 of each of the lane's samples (same for every A-scan)
 	// LDS byte address of tap 0 (= sample -1) of this wave's row, as a scalar: tap address = tapBase + 4*n1
 	typedef __attribute__((address_space(3))) const float lds_cfloat;
 	const uint32_t tapBase = __builtin_amdgcn_readfirstlane(
 	    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
 
+	if constexpr (CW) {
+#pragma unroll
+		for (int q = 0; q < P; q++) tapA[q] = tapBase + 4u * (uint32_t)(int)a.lut[lane + 64 * q].x;
+	}
 	for (; line < a.numLines; line += wavesTotal) {
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
@@ -467,9 +473,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 			}
 			float y;
 			if constexpr (CW) {
-				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + __builtin_bit_cast(u32x4, cw).x);
-				const float y1 = t[1];
-				y = y1 + cw.y * (t[0] - y1) + cw.z * (t[2] - y1) + cw.w * (t[3] - y1);
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
+				y = cw.x * t[0] + cw.y * t[1] + cw.z * t[2] + cw.w * t[3];
 			} else if constexpr (RS == RS_CUBIC) {
 				const int n1 = (int)L.x;
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + 4u * (uint32_t)n1);
