@@ -52,7 +52,7 @@ __global__ __launch_bounds__(bluestein_waves<LOG2M>() * 64) void oct_bluestein_k
 	char* wbase = smem + tw_lds_bytes<LOG2M>() + wave * wave_lds_bytes<M>();
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
-	for (int i = tid; i < twiddle_count<LOG2M>(); i += THREADS) tw[i] = a.twiddle[i];
+	fill_twiddles<LOG2M>(tw, a.twiddle, tid, THREADS);
 	__syncthreads();
 
 	const int N = (int)a.N, half = N / 2;

@@ -167,7 +167,12 @@ constexpr int pad16c(int j) { return j + (j >> 4); }
 
 // READ: fetch the pass input from the LDS slice (else it is already in v in the strided mapping);
 // WRITE: store the pass output to the slice (else it stays in v: v[m + u*NB] = element j0 + u*NS).
-template <int N, int R, int NS, bool READ, bool WRITE, bool CONTIG, bool PRUNE>
+// PACK: twp points to the packed LDS copy of this pass' table (fill_twiddles): two twiddles per 16-byte
+// unit, units of one lane contiguous across lanes -> ds_read_b128, half the LDS cycles of 8-byte reads.
+//   PACK == 2 (R = 16, NS = 16, one butterfly per lane): unit [c][k] = {w(2c, k), w(2c+1, k)}, c < 8, k = lane & 15
+//   PACK == 3 (R = 4, NS = 256, four butterflies per lane): unit [c][lane] = entries 2c, 2c+1 of the lane's
+//             12 twiddles, entry m*3 + t-1 = w(t, lane + 64 m)
+template <int N, int R, int NS, bool READ, bool WRITE, bool CONTIG, bool PRUNE, int PACK = 0>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 	constexpr int P = N / 64, NB = P / R;
 	static_assert(NB >= 1, "radix larger than points per lane");
@@ -186,7 +191,26 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 		}
 		wave_sync_lds();
 	}
-	if constexpr (NS > 1) {
+	if constexpr (PACK == 2) {
+		static_assert(PACK != 2 || (R == 16 && NS == 16 && NB == 1), "packed layout 2");
+		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + (lane & 15);
+#pragma unroll
+		for (int c = 0; c < 8; c++) {
+			const f32x4 w = tp[c * 16];
+			if (c > 0) v[2 * c] = octfft::cmul(v[2 * c], f2{w.x, w.y});
+			v[2 * c + 1] = octfft::cmul(v[2 * c + 1], f2{w.z, w.w});
+		}
+	} else if constexpr (PACK == 3) {
+		static_assert(PACK != 3 || (R == 4 && NS == 256 && NB == 4 && !CONTIG), "packed layout 3");
+		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + lane;
+#pragma unroll
+		for (int c = 0; c < 6; c++) {
+			const f32x4 w = tp[c * 64];
+			const int i0 = 2 * c, i1 = 2 * c + 1;
+			v[i0 / 3 + (i0 % 3 + 1) * NB] = octfft::cmul(v[i0 / 3 + (i0 % 3 + 1) * NB], f2{w.x, w.y});
+			v[i1 / 3 + (i1 % 3 + 1) * NB] = octfft::cmul(v[i1 / 3 + (i1 % 3 + 1) * NB], f2{w.z, w.w});
+		}
+	} else if constexpr (NS > 1) {
 #pragma unroll
 		for (int m = 0; m < NB; m++) {
 			const int b = CONTIG ? 4 * lane + m : lane + 64 * m;
@@ -288,9 +312,9 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	fft_pass<N, R0, 1, false, true, false, false>(v, xbuf, tw, lane);
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
-		fft_pass<N, R1, R0, true, false, false, false>(v, xbuf, tw + T1, lane);
+		fft_pass<N, R1, R0, true, false, false, false, 2>(v, xbuf, tw, lane);
 		perm_exchange<P>(v);
-		fft_pass<N, R2, R0 * R1, false, false, false, PRUNE>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R2, R0 * R1, false, false, false, PRUNE, 3>(v, xbuf, tw + 8 * 16 * 2, lane);
 	} else if constexpr (R3 == 1) {
 		fft_pass<N, R1, R0, true, true, false, false>(v, xbuf, tw + T1, lane);
 		fft_pass<N, R2, R0 * R1, true, false, P / R2 == 4, PRUNE>(v, xbuf, tw + T2, lane);
@@ -304,7 +328,30 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 // ------------------------------------------------------------------ the fused kernel
 // LDS of a workgroup: [twiddles | mean A-line (N/2 complex, unless MEAN_REGS) | LUT, LDS_LUT: rho (N float) or the four
 // cubic tap weights (N x 16 B), then window*phasor (N complex) | WAVES x slice]
-template <int LOG2N> constexpr int tw_lds_bytes() { return (twiddle_count<LOG2N>() * 8 + 15) & ~15; }
+// the PERM plan keeps its tables packed (fft_pass PACK): 8 x 16 + 6 x 64 units of 16 bytes
+template <int LOG2N> constexpr int tw_lds_bytes() { return Plan<LOG2N>::PERM ? (8 * 16 + 6 * 64) * 16 : (twiddle_count<LOG2N>() * 8 + 15) & ~15; }
+// global tables (canonical [t-1][k] per pass) -> LDS, once per persistent workgroup
+template <int LOG2N>
+OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
+	if constexpr (Plan<LOG2N>::PERM) {
+		typedef Plan<LOG2N> PL;
+		constexpr int T2 = (PL::R1 - 1) * PL::R0;  // start of the last pass' table
+		f32x4* p2 = reinterpret_cast<f32x4*>(tw);
+		f32x4* p3 = p2 + 8 * 16;
+		for (int i = tid; i < 8 * 16; i += threads) {
+			const int c = i >> 4, k = i & 15;
+			const f2 w0 = c ? g[(2 * c - 1) * 16 + k] : f2{1.0f, 0.0f}, w1 = g[(2 * c) * 16 + k];
+			p2[i] = f32x4{w0.x, w0.y, w1.x, w1.y};
+		}
+		for (int i = tid; i < 6 * 64; i += threads) {
+			const int c = i >> 6, l = i & 63, i0 = 2 * c, i1 = 2 * c + 1;
+			const f2 w0 = g[T2 + (i0 % 3) * 256 + l + 64 * (i0 / 3)], w1 = g[T2 + (i1 % 3) * 256 + l + 64 * (i1 / 3)];
+			p3[i] = f32x4{w0.x, w0.y, w1.x, w1.y};
+		}
+	} else {
+		for (int i = tid; i < twiddle_count<LOG2N>(); i += threads) tw[i] = g[i];
+	}
+}
 template <int LOG2N> constexpr int mean_lds_bytes() { return Cfg<LOG2N>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
 template <int LOG2N, int RS> constexpr int lut_lds_bytes() { return !Cfg<LOG2N>::LDS_LUT ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
 template <int LOG2N, int RS> constexpr int block_lds_bytes() {
@@ -344,7 +391,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
 	// tables -> LDS, once per (persistent) workgroup
-	for (int i = tid; i < twiddle_count<LOG2N>(); i += THREADS) tw[i] = a.twiddle[i];
+	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
 	if constexpr (!MEAN_REGS)
 		for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
 	if constexpr (LDS_LUT) {
@@ -474,7 +521,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 			float y;
 			if constexpr (CW) {
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
-				y = cw.x * t[0] + cw.y * t[1] + cw.z * t[2] + cw.w * t[3];
+				y = __builtin_fmaf(cw.w, t[3], __builtin_fmaf(cw.z, t[2], __builtin_fmaf(cw.y, t[1], cw.x * t[0])));  // one fma chain (hipcc would split it into packed halves + adds)
 			} else if constexpr (RS == RS_CUBIC) {
 				const int n1 = (int)L.x;
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + 4u * (uint32_t)n1);
