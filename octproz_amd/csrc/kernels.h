@@ -397,7 +397,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 	if constexpr (LDS_LUT) {
 		for (int i = tid; i < N; i += THREADS) {
 			const float4 t = a.lut[i];
-			wphL[i] = f2{t.y * t.z, t.y * t.w};  // window folded into the phasor (one rounding of difference)
+			// window folded into the phasor (one rounding of difference).  CW: the values of samples lane+64q and
+			// lane+64(q+1) (q even) share a 16-byte unit [q/2][lane], so the gather fetches them with one ds_read_b128
+			wphL[CW ? (((i >> 7) << 6) + (i & 63)) * 2 + ((i >> 6) & 1) : i] = f2{t.y * t.z, t.y * t.w};
 			if constexpr (CW) {
 				// cu:258-271 as weights of the four taps, y = w0 y0 + w1 y1 + w2 y2 + w3 y3 with
 				// p = rho - n1 (exact in float); evaluated once per workgroup in double, w1 = 1 - w0 - w2 - w3
@@ -503,6 +505,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 		// VALU-dense FFT of its SIMD neighbours: +7 % A-scans/s measured.
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(3);
 		f2 v[P];
+		f32x4 wph2;
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			// {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
@@ -511,7 +514,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 			f32x4 cw;
 			if constexpr (CW) {
 				cw = cwL[lane + 64 * q];
-				wph = wphL[lane + 64 * q];
+				if ((q & 1) == 0) wph2 = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];
+				wph = (q & 1) ? f2{wph2.z, wph2.w} : f2{wph2.x, wph2.y};
 			} else if constexpr (LDS_LUT) {
 				L.x = rhoL[lane + 64 * q];
 				wph = wphL[lane + 64 * q];
