@@ -130,6 +130,29 @@ int octpipe_window_curve(int windowType, float center, float fillFactor, unsigne
  * (hipHostRegister) here and unpinned in octpipe_destroy, ownership stays with the caller. */
 int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq,
                    const OctPipeParams* params, void* h_buffer1, void* h_buffer2);
+
+/* Sample formats beyond "the bit depth decides" (SURVEY 8 row N4).  The reference declares them
+ * (src/octalgorithmparameters.h:61-77, enum DATA_TYPE, member :88) but never reads the field, so there
+ * is no parity target: the decode is specified here (the test suite restates it independently).
+ *   AUTO           uint8 / uint16 / uint32 by bitDepth -- the reference's behaviour (cu:107-149)
+ *   UINT12_PACKED  two samples in three bytes, little endian (GenICam Mono12p):
+ *                  b0 = s0[7:0], b1 = s0[11:8] | s1[3:0] << 4, b2 = s1[11:4]; buffer = 1.5 B/sample
+ *   INT12_PACKED   same packing, samples are 12-bit two's complement
+ *   INT8 / INT16 / INT32   two's complement in 1 / 2 / 4 bytes (INT10, INT12 travel as INT16)
+ * The sample becomes the float of its integer value (exact; INT32 rounds to nearest even);
+ * `bitshift` is an arithmetic >> 4 on the integer.  Everything downstream is unchanged. */
+#define OCTPIPE_FORMAT_AUTO 0
+#define OCTPIPE_FORMAT_UINT12_PACKED 1
+#define OCTPIPE_FORMAT_INT12_PACKED 2
+#define OCTPIPE_FORMAT_INT8 3
+#define OCTPIPE_FORMAT_INT16 4
+#define OCTPIPE_FORMAT_INT32 5
+/* octpipe_create with an explicit sample format (fixed for the life of the handle: it sets the size
+ * of the ring slots that are pinned here) */
+int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq,
+                               const OctPipeParams* params, void* h_buffer1, void* h_buffer2, int sampleFormat);
+/* bytes of one raw acquisition buffer in the handle's sample format */
+int octpipe_raw_buffer_bytes(const octpipe_t* h, size_t* bytes);
 /* cleanupCuda + releaseBuffers + destroyStreamsAndEvents, kernels.h:65-67 / cu:1164-1212 */
 int octpipe_destroy(octpipe_t* h);
 /* parameter snapshot taken per call in the reference (params-> reads in cu:1409-1604) */

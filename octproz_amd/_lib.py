@@ -78,7 +78,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_abi_version", "octpipe_last_error", "octpipe_device_count", "octpipe_default_params",
     "octpipe_polynomial_curve", "octpipe_resample_curve", "octpipe_custom_resample_curve",
     "octpipe_dispersion_curve", "octpipe_window_curve",
-    "octpipe_create", "octpipe_destroy", "octpipe_set_params", "octpipe_get_acquisition_params",
+    "octpipe_create", "octpipe_create_with_format", "octpipe_raw_buffer_bytes", "octpipe_destroy", "octpipe_set_params", "octpipe_get_acquisition_params",
     "octpipe_update_resample_curve", "octpipe_update_dispersion_curve", "octpipe_update_window_curve",
     "octpipe_update_postprocess_background", "octpipe_copy_postprocess_background_to_host",
     "octpipe_calibration_size", "octpipe_export_calibration", "octpipe_import_calibration",
@@ -150,6 +150,8 @@ def lib():
         L.octhost_processing_run_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         # pipeline entry points take the handle as void*
         L.octpipe_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.octpipe_create_with_format.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.octpipe_raw_buffer_bytes.argtypes = [C.c_void_p, C.c_void_p]
         for name in ("octpipe_destroy", "octpipe_synchronize", "octpipe_unregister_streaming_buffers",
                      "octpipe_unregister_float_streaming_buffers"):
             getattr(L, name).argtypes = [C.c_void_p]

@@ -49,7 +49,7 @@ struct octpipe {
 	int device = 0;
 	OctPipeAcquisitionParams acq{};
 	OctPipeParams params{};
-	int N = 0, A = 0, B = 0, log2n = 0, bytesPerSample = 0;
+	int N = 0, A = 0, B = 0, log2n = 0, bytesPerSample = 0, sampleFormat = OCTPIPE_FORMAT_AUTO;
 	size_t S = 0;  // samplesPerBuffer
 
 	hipStream_t stream = nullptr;      // compute stream (all kernels)
@@ -228,8 +228,20 @@ int uploadBluesteinTables(octpipe* h) {
 	return OCTPIPE_OK;
 }
 
+// bytes of one raw buffer: S * bytesPerSample, 1.5 B/sample for the packed formats
+size_t rawBytes(const octpipe* h) {
+	switch (h->sampleFormat) {
+	case OCTPIPE_FORMAT_UINT12_PACKED:
+	case OCTPIPE_FORMAT_INT12_PACKED: return h->S / 2 * 3;
+	case OCTPIPE_FORMAT_INT8: return h->S;
+	case OCTPIPE_FORMAT_INT16: return h->S * 2;
+	case OCTPIPE_FORMAT_INT32: return h->S * 4;
+	default: return h->S * (size_t)h->bytesPerSample;
+	}
+}
+
 bool needsPrepared(const octpipe* h) {
-	return h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
+	return h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
 }
 
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
@@ -248,7 +260,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
 		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(h->S)), dim3(256), 0, h->stream, d_raw, h->d_prepared,
-		                   (int)h->acq.bitDepth, p.bitshift, roll ? p.rollingAverageWindowSize : 0, h->N, h->S);
+		                   (int)h->acq.bitDepth, p.bitshift, roll ? p.rollingAverageWindowSize : 0, h->N, h->S, h->sampleFormat);
 		HIP_TRY(hipGetLastError());
 		a.raw = h->d_prepared;
 		intype = oct::IN_F32;
@@ -454,8 +466,23 @@ int octpipe_device_count(int* count) {
 
 int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
                    void* h_buffer1, void* h_buffer2) {
+	return octpipe_create_with_format(out, device, acq, params, h_buffer1, h_buffer2, OCTPIPE_FORMAT_AUTO);
+}
+
+int octpipe_raw_buffer_bytes(const octpipe_t* h, size_t* bytes) {
+	if (!h || !bytes) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*bytes = rawBytes(h);
+	return OCTPIPE_OK;
+}
+
+int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
+                               void* h_buffer1, void* h_buffer2, int sampleFormat) {
 	if (!out || !acq || !params) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	*out = nullptr;
+	if (sampleFormat < OCTPIPE_FORMAT_AUTO || sampleFormat > OCTPIPE_FORMAT_INT32) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "unknown sample format");
+	if ((sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED || sampleFormat == OCTPIPE_FORMAT_INT12_PACKED) &&
+	    (((size_t)acq->samplesPerLine * acq->ascansPerBscan * acq->bscansPerBuffer) & 1))
+		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "packed 12-bit buffers need an even number of samples");
 	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
 	if (!oct::fused_supported(acq->samplesPerLine) && oct::bluestein_log2m(acq->samplesPerLine) < 0)
@@ -476,6 +503,7 @@ int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* 
 	h->S = (size_t)h->N * h->A * h->B;
 	h->bytesPerSample = (int)((acq->bitDepth + 7) / 8);  // ceil(bitDepth/8), cu:1077
 	if (h->bytesPerSample == 3) h->bytesPerSample = 4;    // 17..24 bit live in uint32 (cu:122-124)
+	h->sampleFormat = sampleFormat;  // input decode only; the output quantiser keeps following bitDepth
 	h->log2n = 0;
 	while ((1 << h->log2n) < h->N) h->log2n++;
 	if (!oct::fused_supported(acq->samplesPerLine)) {
@@ -514,7 +542,7 @@ int octpipe_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* 
 	for (int i = 0; i < 2; ++i) {
 		h->h_buffer[i] = hb[i];
 		if (hb[i]) {
-			HIP_TRY(hipHostRegister(hb[i], S * (size_t)h->bytesPerSample, hipHostRegisterPortable));
+			HIP_TRY(hipHostRegister(hb[i], rawBytes(h), hipHostRegisterPortable));
 			h->h_bufferRegistered[i] = true;
 		}
 	}
@@ -653,7 +681,7 @@ int octpipe_process(octpipe_t* h, const void* h_inputSignal) {
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	if (!h_inputSignal) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null input buffer");
 	int rc = setDevice(h); if (rc) return rc;
-	const size_t bytes = h->S * (size_t)h->bytesPerSample;
+	const size_t bytes = rawBytes(h);
 	const int s = h->slot;
 	h->slot ^= 1;
 	if ((rc = ensure(&h->d_raw[s], bytes))) return rc;
@@ -782,7 +810,7 @@ int octpipe_debug_unpack(octpipe_t* h, const void* d_raw, size_t count, float* h
 	HIP_TRY(hipMalloc((void**)&d_tmp, sizeof(float) * count));
 	const OctPipeParams& p = h->params;
 	hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(count)), dim3(256), 0, h->stream, d_raw, d_tmp, (int)h->acq.bitDepth,
-	                   p.bitshift, p.backgroundRemoval ? p.rollingAverageWindowSize : 0, h->N, count);
+	                   p.bitshift, p.backgroundRemoval ? p.rollingAverageWindowSize : 0, h->N, count, h->sampleFormat);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(hostOut, d_tmp, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

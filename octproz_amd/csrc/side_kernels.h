@@ -9,9 +9,21 @@ namespace oct {
 
 // ------------------------------------------------------------------ side kernels
 // unpack (+ rolling average) to float32, only used in front of the Lanczos variant
-__global__ void oct_prepare_kernel(const void* raw, float* out, int bitDepth, int bitshift, int rollingW, int N, size_t S) {
+// format: OCTPIPE_FORMAT_* (0 = by bit depth as the reference; 1/2 packed 12 bit, 3/4/5 signed 8/16/32 bit)
+__global__ void oct_prepare_kernel(const void* raw, float* out, int bitDepth, int bitshift, int rollingW, int N, size_t S, int format) {
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < S; i += (size_t)gridDim.x * blockDim.x) {
 		auto get = [&](size_t idx) -> float {
+			if (format == 1 || format == 2) {
+				// samples 2p, 2p+1 live in bytes 3p .. 3p+2
+				const uint8_t* b = reinterpret_cast<const uint8_t*>(raw) + (idx >> 1) * 3;
+				const uint32_t v = (idx & 1) ? ((uint32_t)b[1] >> 4) | ((uint32_t)b[2] << 4) : (uint32_t)b[0] | (((uint32_t)b[1] & 15u) << 8);
+				if (format == 1) return (float)(bitshift ? (v >> 4) : v);
+				const int sv = (int)(v << 20) >> 20;  // sign-extend 12 bits
+				return (float)(bitshift ? (sv >> 4) : sv);
+			}
+			if (format == 3) { const int v = reinterpret_cast<const int8_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
+			if (format == 4) { const int v = reinterpret_cast<const int16_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
+			if (format == 5) { const int v = reinterpret_cast<const int32_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
 			if (bitDepth <= 8) { uint32_t v = reinterpret_cast<const uint8_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
 			if (bitDepth <= 16) { uint32_t v = reinterpret_cast<const uint16_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
 			uint32_t v = reinterpret_cast<const uint32_t*>(raw)[idx];

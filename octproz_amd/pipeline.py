@@ -17,7 +17,7 @@ from .params import OctAlgorithmParameters
 
 
 class Pipeline:
-    def __init__(self, params: OctAlgorithmParameters, device=0, h_buffer1=None, h_buffer2=None):
+    def __init__(self, params: OctAlgorithmParameters, device=0, h_buffer1=None, h_buffer2=None, sample_format=0):
         self.params = params
         self._h = C.c_void_p()
         self._lib = _lib.lib()
@@ -26,7 +26,8 @@ class Pipeline:
         self._keep = (h_buffer1, h_buffer2)
         b1 = h_buffer1.ctypes.data if h_buffer1 is not None else None
         b2 = h_buffer2.ctypes.data if h_buffer2 is not None else None
-        rc = self._lib.octpipe_create(C.byref(self._h), device, C.byref(acq), C.byref(pod), b1, b2)
+        # sample_format: OCTPIPE_FORMAT_* (0 = the reference's rule, 1/2 packed 12 bit, 3/4/5 int8/int16/int32)
+        rc = self._lib.octpipe_create_with_format(C.byref(self._h), device, C.byref(acq), C.byref(pod), b1, b2, int(sample_format))
         if rc != 0:
             msg = self._lib.octpipe_last_error()
             if self._h:
@@ -139,6 +140,11 @@ class Pipeline:
         out = np.empty(lines * self.N, dtype=np.complex64)
         check(self._lib.octpipe_debug_spectrum(self._h, C.c_void_p(d_raw_ptr), lines, out.ctypes.data))
         return out
+
+    def raw_buffer_bytes(self):
+        n = C.c_size_t()
+        check(self._lib.octpipe_raw_buffer_bytes(self._h, C.byref(n)))
+        return n.value
 
     def debug_unpack(self, d_raw_ptr, count):
         self._sync_params()

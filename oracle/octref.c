@@ -184,6 +184,29 @@ void octref_unpack(const void* raw, int bitDepth, int bitshift, size_t samples, 
 	}
 }
 
+/* Row N4 (no reference implementation, see octref.h): packed 12 bit = two samples in three bytes,
+ * b0 = s0[7:0], b1 = s0[11:8] | s1[3:0] << 4, b2 = s1[11:4]; signed variants are two's complement;
+ * bitshift is an arithmetic >> 4 of the integer; the float is the integer value. */
+void octref_unpack_format(const void* raw, int format, int bitshift, size_t samples, octref_c32* out) {
+	for (size_t i = 0; i < samples; i++) {
+		int32_t v = 0;
+		if (format == 1 || format == 2) {
+			const uint8_t* b = (const uint8_t*)raw + (i >> 1) * 3;
+			uint32_t u = (i & 1) ? ((uint32_t)b[1] >> 4) | ((uint32_t)b[2] << 4) : (uint32_t)b[0] | (((uint32_t)b[1] & 15u) << 8);
+			v = (format == 2 && (u & 0x800u)) ? (int32_t)u - 4096 : (int32_t)u;
+		} else if (format == 3) {
+			v = ((const int8_t*)raw)[i];
+		} else if (format == 4) {
+			v = ((const int16_t*)raw)[i];
+		} else if (format == 5) {
+			v = ((const int32_t*)raw)[i];
+		}
+		if (bitshift) v = (v >= 0) ? (v >> 4) : -(((-(int64_t)v) + 15) >> 4); /* floor(v / 16) = arithmetic shift */
+		out[i].x = (float)v;
+		out[i].y = 0.0f;
+	}
+}
+
 /* cu:165-211: per sample, mean over [i-W+1, i+W] clipped to the own A-scan, summed in
  * index order in float, subtracted from the sample. */
 void octref_rolling_average(const octref_c32* in, octref_c32* out, int W, int width, int height, size_t samples) {

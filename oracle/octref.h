@@ -100,6 +100,10 @@ void octref_sinusoidal_curve(unsigned length, float* out);
 
 /* ---- device stages, one function per reference kernel ---- */
 void octref_unpack(const void* raw, int bitDepth, int bitshift, size_t samples, octref_c32* out);
+/* formats the reference declares (src/octalgorithmparameters.h:61-77) but never decodes;
+ * specified in include/octpipe.h (OCTPIPE_FORMAT_*): 1/2 = packed 12 bit unsigned / signed (Mono12p),
+ * 3/4/5 = int8 / int16 / int32.  No reference behaviour exists, so this is a specification, not a port. */
+void octref_unpack_format(const void* raw, int format, int bitshift, size_t samples, octref_c32* out);
 void octref_rolling_average(const octref_c32* in, octref_c32* out, int W, int width, int height, size_t samples);
 void octref_klin(const octref_c32* in, octref_c32* out, int interpolation, const float* resampleCurve,
                  const float* window /*nullable*/, const octref_c32* phase /*nullable*/, int width, size_t samples);

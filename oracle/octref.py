@@ -134,6 +134,14 @@ def sinusoidal_curve(length):
 
 
 # ---------------------------------------------------------------- single stages
+def unpack_format(raw, fmt, bitshift, samples):
+    """row N4 formats (1/2 packed 12 bit, 3/4/5 int8/16/32) -> float32 real parts"""
+    raw = np.ascontiguousarray(raw)
+    out = np.zeros((samples, 2), np.float32)
+    lib().octref_unpack_format(_fp(raw), C.c_int(fmt), C.c_int(int(bitshift)), C.c_size_t(samples), _fp(out))
+    return out[:, 0].copy()
+
+
 def unpack(raw, bit_depth, bitshift):
     raw = np.ascontiguousarray(raw)
     n = raw.size

@@ -1,0 +1,134 @@
+"""packed 12-bit and signed input decode.  The reference only declares these formats
+(src/octalgorithmparameters.h:61-77) and never decodes them, so the parity target is the specification in
+include/octpipe.h, restated in oracle/octref.c (octref_unpack_format) and here in numpy."""
+import numpy as np
+import pytest
+
+from oracle import octref
+
+FORMATS = {"uint12p": 1, "int12p": 2, "int8": 3, "int16": 4, "int32": 5}
+
+
+def pack12(values):
+    """two 12-bit samples -> three bytes, little endian (GenICam Mono12p)"""
+    v = np.asarray(values).astype(np.int64) & 0xFFF
+    assert v.size % 2 == 0
+    s0, s1 = v[0::2], v[1::2]
+    out = np.empty((v.size // 2, 3), np.uint8)
+    out[:, 0] = s0 & 0xFF
+    out[:, 1] = (s0 >> 8) | ((s1 & 0xF) << 4)
+    out[:, 2] = s1 >> 4
+    return out.reshape(-1)
+
+
+def make(fmt, n, seed):
+    """(integer values, raw container) for a format name"""
+    rng = np.random.default_rng(seed)
+    if fmt == "uint12p":
+        v = rng.integers(0, 4095, n, endpoint=True); v[:4] = [0, 4095, 1, 2048]
+        return v, pack12(v)
+    if fmt == "int12p":
+        v = rng.integers(-2048, 2047, n, endpoint=True); v[:4] = [0, -2048, 2047, -1]
+        return v, pack12(v)
+    lo, hi, dt = {"int8": (-128, 127, np.int8), "int16": (-32768, 32767, np.int16), "int32": (-2 ** 31, 2 ** 31 - 1, np.int32)}[fmt]
+    v = rng.integers(lo, hi, n, endpoint=True); v[:4] = [0, lo, hi, -1]
+    return v, v.astype(dt)
+
+
+@pytest.mark.parametrize("fmt", sorted(FORMATS))
+@pytest.mark.parametrize("bitshift", [0, 1])
+def test_oracle_decode_matches_the_specification(fmt, bitshift):
+    v, raw = make(fmt, 4096, 3)
+    want = (v >> 4 if bitshift else v).astype(np.float32)  # numpy >> on signed integers is arithmetic
+    got = octref.unpack_format(raw, FORMATS[fmt], bitshift, v.size)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_packing_helper_layout():
+    assert pack12([0xABC, 0x123]).tolist() == [0xBC, 0x3A, 0x12]
+
+
+# ------------------------------------------------------------------ GPU
+def _dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", sorted(FORMATS))
+@pytest.mark.parametrize("bitshift", [0, 1])
+def test_gpu_decode_bit_exact(fmt, bitshift):
+    from octproz_amd import Pipeline, v180_benchmark_params
+    N, A, B = 256, 8, 2
+    v, raw = make(fmt, N * A * B, 11)
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth = {"int8": 8, "int32": 32}.get(fmt, 12 if "12" in fmt else 16)
+    p.bitshift = bitshift
+    pipe = Pipeline(p, device=0, sample_format=FORMATS[fmt])
+    assert pipe.raw_buffer_bytes() == raw.nbytes
+    d = _dev(raw)
+    got = pipe.debug_unpack(d.data_ptr(), v.size)
+    want = octref.unpack_format(raw, FORMATS[fmt], bitshift, v.size)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_packed_input_gives_the_image_of_the_same_samples_in_uint16():
+    """the packed buffer and its uint16 expansion must produce the same image bit for bit
+    (both go through the float32 'prepared' route), host entry point included"""
+    from octproz_amd import Pipeline, synthetic_raw, v180_benchmark_params
+    N, A, B = 1024, 24, 2
+    raw16 = synthetic_raw(N, A, B, seed=21)
+    packed = pack12(raw16.reshape(-1))
+    p = v180_benchmark_params(N, A, B)
+    ref = Pipeline(p, device=0)
+    ref.debug_force_prepared(True)
+    ref.octCudaPipeline(raw16)
+    ref.synchronize()
+    want = ref.processed_host()
+    ml = ref.mean_line()
+    pk = Pipeline(p, device=0, sample_format=FORMATS["uint12p"])
+    assert pk.raw_buffer_bytes() == N * A * B * 3 // 2
+    pk.octCudaPipeline(packed)
+    pk.synchronize()
+    got = pk.processed_host()
+    assert np.array_equal(np.ascontiguousarray(pk.mean_line()).view(np.uint32), np.ascontiguousarray(ml).view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ref.close(); pk.close()
+
+
+@pytest.mark.gpu
+def test_signed_input_is_the_unsigned_image_of_the_offset_samples_without_dc():
+    """int16 samples x - 2048 differ from uint16 samples x only in the DC term, which the rolling-average
+    background removal takes out exactly (integer-valued floats, exact sums): identical images"""
+    from octproz_amd import Pipeline, synthetic_raw, v180_benchmark_params
+    N, A, B = 512, 24, 2
+    raw16 = synthetic_raw(N, A, B, seed=5)
+    p = v180_benchmark_params(N, A, B)
+    p.backgroundRemoval, p.rollingAverageWindowSize = 1, 16
+    a = Pipeline(p, device=0)
+    a.debug_force_prepared(True)
+    a.octCudaPipeline(raw16); a.synchronize()
+    want = a.processed_host()
+    b = Pipeline(p, device=0, sample_format=FORMATS["int16"])
+    b.octCudaPipeline((raw16.astype(np.int32) - 2048).astype(np.int16)); b.synchronize()
+    got = b.processed_host()
+    # means of integers are not always representable: compare in linear power with the image tolerance
+    import common
+    common.compare_images(got, want, p, "int16 vs uint16 with DC removal")
+    a.close(); b.close()
+
+
+def test_unknown_format_and_odd_sample_count_are_rejected():
+    import ctypes as C
+    from octproz_amd import _lib
+    from octproz_amd.params import OctAlgorithmParameters
+    L = _lib.lib()
+    h = C.c_void_p()
+    p = OctAlgorithmParameters().pod()
+    acq = _lib.AcquisitionParams(1024, 8, 2, 1, 12)
+    assert L.octpipe_create_with_format(C.byref(h), 0, C.byref(acq), C.byref(p), None, None, 9) == 1 and not h.value
+    n = C.c_size_t()
+    assert L.octpipe_raw_buffer_bytes(None, C.byref(n)) == 1
