@@ -476,21 +476,60 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 		}
 		wave_sync_lds();
 
-		// ---- rolling-average DC removal (cu:165-211), values summed in index order
+		// ---- rolling-average DC removal (cu:165-211): mean over [j-W+1, j+W] clipped to the A-scan
 		if constexpr (ROLL) {
 			const int W = a.rollingW;
-			float r[P];
+			if (W <= 128) {
+				// The samples are integers <= 65535, so a float sum of up to 256 of them is exact whatever the
+				// order (< 2^24): the reference's index-order float sum equals an integer window sum, which
+				// comes from one uint32 prefix-sum array per A-scan (2 LDS reads per sample instead of 2W).
+				uint32_t* pfx = reinterpret_cast<uint32_t*>(row + N + 2 * ROW_OFF);
+				uint32_t incl[NL], tot[NL];
 #pragma unroll
-			for (int q = 0; q < P; q++) {
-				const int j = lane + 64 * q;
-				const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
-				float sum = 0.0f;
-				for (int t = lo; t <= hi; t++) sum += row[ROW_OFF + t];
-				r[q] = rowl[64 * q] - __fdiv_rn(sum, (float)(hi - lo + 1));
+				for (int i = 0; i < NL; i++) {
+					const float4 x = *reinterpret_cast<const float4*>(&row[ROW_OFF + 4 * lane + 256 * i]);
+					tot[i] = incl[i] = (uint32_t)x.x + (uint32_t)x.y + (uint32_t)x.z + (uint32_t)x.w;
+				}
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+					for (int i = 0; i < NL; i++) {
+						const uint32_t y = (uint32_t)__shfl_up((int)incl[i], d, 64);
+						if (lane >= d) incl[i] += y;
+					}
+				}
+				uint32_t base = 0;
+#pragma unroll
+				for (int i = 0; i < NL; i++) {
+					const float4 x = *reinterpret_cast<const float4*>(&row[ROW_OFF + 4 * lane + 256 * i]);
+					const uint32_t p0 = base + incl[i] - tot[i] + (uint32_t)x.x, p1 = p0 + (uint32_t)x.y, p2 = p1 + (uint32_t)x.z;
+					*reinterpret_cast<uint4*>(&pfx[4 * lane + 256 * i]) = uint4{p0, p1, p2, p2 + (uint32_t)x.w};
+					base += (uint32_t)__builtin_amdgcn_readlane((int)incl[i], 63);
+				}
+				wave_sync_lds();
+				// every lane replaces only its own samples (the window sums come from pfx): in place
+#pragma unroll
+				for (int q = 0; q < P; q++) {
+					const int j = lane + 64 * q;
+					const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
+					const uint32_t sum = pfx[hi] - (lo > 0 ? pfx[lo - 1] : 0u);
+					rowl[64 * q] = rowl[64 * q] - __fdiv_rn((float)sum, (float)(hi - lo + 1));
+				}
+			} else {
+				// wide windows: the reference's float accumulation in index order
+				float r[P];
+#pragma unroll
+				for (int q = 0; q < P; q++) {
+					const int j = lane + 64 * q;
+					const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
+					float sum = 0.0f;
+					for (int t = lo; t <= hi; t++) sum += row[ROW_OFF + t];
+					r[q] = rowl[64 * q] - __fdiv_rn(sum, (float)(hi - lo + 1));
+				}
+				wave_sync_lds();
+#pragma unroll
+				for (int q = 0; q < P; q++) rowl[64 * q] = r[q];
 			}
-			wave_sync_lds();
-#pragma unroll
-			for (int q = 0; q < P; q++) rowl[64 * q] = r[q];
 			wave_sync_lds();
 		}
 		if constexpr (RS == RS_CUBIC) {

@@ -78,6 +78,36 @@ def test_fused_unpack_equals_standalone_unpack_bitwise():
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("N,W", [(1024, 8), (1024, 100), (1024, 128), (1024, 200), (256, 32), (2048, 64)])
+def test_rolling_average_prefix_sum_route_is_bit_identical_to_the_ordered_float_sum(N, W):
+    """W <= 128: the fused kernel takes window sums from an integer prefix-sum array; the standalone
+    unpack kernel accumulates floats in index order like cu:165-211.  Full-range uint16 input keeps every
+    window sum below 2^24, where both are exact: the two routes must give the same image bit for bit
+    (W = 200 exercises the ordered fallback inside the fused kernel)."""
+    A, B = 24, 2
+    rng = np.random.default_rng(W)
+    raw = rng.integers(0, 65535, size=(B, A, N), endpoint=True).astype(np.uint16)
+    raw[0, 0, :4] = [65535, 0, 65535, 1]
+    raw[1, 3, :] = 65535
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth, p.backgroundRemoval, p.rollingAverageWindowSize = 16, 1, W
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    fused = pipe.processed_host()
+    ml = pipe.mean_line()
+    pipe.debug_force_prepared(True)
+    pipe.set_mean_line(ml, pin=True)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    prepared = pipe.processed_host()
+    assert np.array_equal(fused.view(np.uint32), prepared.view(np.uint32))
+    # and the stage itself against the oracle, bit-exact
+    got = pipe.debug_unpack(d.data_ptr(), raw.size)
+    want = octref.rolling_average(octref.unpack(raw, 16, 0), W, N, A * B).real.reshape(-1)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want, dtype=np.float32).view(np.uint32))
+    pipe.close()
+
+
 @pytest.mark.parametrize("B", [2, 5, 6])
 def test_flip_index_map_bit_exact(B):
     """flip is folded into the store address: flipped output == index-mapped unflipped output, exactly"""
