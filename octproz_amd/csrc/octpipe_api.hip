@@ -319,6 +319,21 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	if (timeIt && h->timing) {
 		HIP_TRY(hipEventRecord(t.stop, h->stream));
 		h->timed.push_back(t);
+		// long timed runs: fold the launches that have already finished so the event list stays bounded
+		if (h->timed.size() >= 1024) {
+			size_t done = 0;
+			while (done < h->timed.size() && hipEventQuery(h->timed[done].stop) == hipSuccess) {
+				float ms = 0.0f;
+				if (hipEventElapsedTime(&ms, h->timed[done].start, h->timed[done].stop) == hipSuccess) {
+					h->timedMs += ms;
+					h->timedLaunches++;
+				}
+				hipEventDestroy(h->timed[done].start);
+				hipEventDestroy(h->timed[done].stop);
+				++done;
+			}
+			h->timed.erase(h->timed.begin(), h->timed.begin() + (long)done);
+		}
 	}
 	return OCTPIPE_OK;
 }

@@ -41,8 +41,8 @@ class Pipeline:
 
     # reference-named entry points ------------------------------------------------------------
     @classmethod
-    def initializeCuda(cls, h_buffer1, h_buffer2, params, device=0):
-        return cls(params, device, h_buffer1, h_buffer2)
+    def initializeCuda(cls, h_buffer1, h_buffer2, params, device=0, sample_format=0):
+        return cls(params, device, h_buffer1, h_buffer2, sample_format)
 
     def octCudaPipeline(self, h_inputSignal):
         self._sync_params()

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--bscans", type=int, default=256)
     ap.add_argument("--buffers-from-file", type=int, default=2, help="2 = both ring slots preloaded (no host memcpy); >2 = memcpy per buffer")
     ap.add_argument("--stream-to-host", action="store_true", help="also quantise + D2H every buffer (reference v1.8.0 ini: streaming_enabled=true)")
+    ap.add_argument("--packed12", action="store_true", help="deliver the samples as packed 12 bit (Mono12p, 1.5 B/sample, OCTPIPE_FORMAT_UINT12_PACKED)")
     args = ap.parse_args()
 
     import numpy as np
@@ -31,13 +32,25 @@ def main():
     N, A, B = args.samples, args.ascans, args.bscans
     n_buf = max(2, args.buffers_from_file)
     data = np.concatenate([synthetic_raw(N, A, B, seed=100 + i).reshape(-1) for i in range(n_buf)])
-    system = VirtualOCTSystem(12, N, A, B, data=data, buffers_from_file=n_buf, copy_file_to_ram=True, sync_with_processing=True)
+    if args.packed12:
+        # the ring carries bytes: 1.5 N "8-bit samples" per line
+        v = data.astype(np.uint32) & 0xFFF
+        pk = np.empty((v.size // 2, 3), np.uint8)
+        pk[:, 0] = v[0::2] & 0xFF
+        pk[:, 1] = (v[0::2] >> 8) | ((v[1::2] & 0xF) << 4)
+        pk[:, 2] = v[1::2] >> 4
+        system = VirtualOCTSystem(8, N * 3 // 2, A, B, data=pk.reshape(-1), buffers_from_file=n_buf, copy_file_to_ram=True, sync_with_processing=True)
+    else:
+        system = VirtualOCTSystem(12, N, A, B, data=data, buffers_from_file=n_buf, copy_file_to_ram=True, sync_with_processing=True)
     system.startAcquisition()
     ring = system.buffer
     p = v180_benchmark_params(N, A, B)
     if args.stream_to_host:
         p.streamToHost = 1
-    pipe = Pipeline.initializeCuda(ring.slot(0, np.uint16), ring.slot(1, np.uint16), p)
+    if args.packed12:
+        pipe = Pipeline.initializeCuda(ring.slot(0, np.uint8), ring.slot(1, np.uint8), p, sample_format=1)
+    else:
+        pipe = Pipeline.initializeCuda(ring.slot(0, np.uint16), ring.slot(1, np.uint16), p)
     if args.stream_to_host:
         out = [np.zeros(N * A * B // 2, dtype=np.uint16) for _ in range(2)]
         pipe.register_streaming_buffers(out[0], out[1])
@@ -49,7 +62,7 @@ def main():
     res = {"mode": "streaming (host loop, PCIe inclusive)", "seconds": stats.elapsedSeconds,
            "buffers": stats.buffersProcessed, "volumes_per_s": stats.volumesPerSecond, "buffers_per_s": stats.buffersPerSecond,
            "bscans_per_s": stats.bscansPerSecond, "ascans_per_s": stats.ascansPerSecond, "buffer_MB": stats.bufferSizeMB,
-           "throughput_MB_per_s": stats.dataThroughputMBs, "buffers_from_file": n_buf, "stream_to_host": bool(args.stream_to_host)}
+           "throughput_MB_per_s": stats.dataThroughputMBs, "buffers_from_file": n_buf, "stream_to_host": bool(args.stream_to_host), "packed12": bool(args.packed12)}
     if args.stream_to_host:
         pipe.unregister_streaming_buffers()
         res["callbacks"] = len(count)
