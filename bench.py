@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--volumes", type=int, default=4, help="distinct raw buffers rotated (defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (exercises the RCCL setup, barrier and all-reduce on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -71,9 +72,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -155,10 +159,19 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, 64, 11)
-        print(json.dumps(out))
     pipe.close()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes its version banner to the C stdout buffer; push it out first so that the JSON
+    # line is the last thing rank 0 prints
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
