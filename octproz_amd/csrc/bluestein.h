@@ -34,7 +34,9 @@ struct BluesteinArgs {
 	float sA, sB;
 };
 
-template <int LOG2M> constexpr int bluestein_waves() { return LOG2M >= 12 ? 2 : (LOG2M == 11 ? 4 : 8); }
+// waves per workgroup (one workgroup per CU): the two M-point transforms plus the tables in flight need
+// ~250 (M = 2048) / ~500 (M = 4096) VGPRs, i.e. 2 / 1 waves per SIMD
+template <int LOG2M> constexpr int bluestein_waves() { return LOG2M >= 12 ? 4 : 8; }
 template <int LOG2M> constexpr int bluestein_lds_bytes() {
 	return tw_lds_bytes<LOG2M>() + bluestein_waves<LOG2M>() * wave_lds_bytes<(1 << LOG2M)>();
 }
@@ -116,15 +118,34 @@ __global__ __launch_bounds__(bluestein_waves<LOG2M>() * 64) void oct_bluestein_k
 			for (int m = 0; m < NBL; m++) {
 				const int bin = fft_bin<LOG2M>(lane, m, u);
 				const f2 t = octfft::cmul(v[m + u * NBL], a.filter[bin]);
-				xbuf[pad16c(0) + bin + (bin >> 4)] = f2{t.x, -t.y};
+				if constexpr (Cfg<LOG2M>::PLANAR) v[m + u * NBL] = f2{t.x, -t.y};
+				else xbuf[pad16c(0) + bin + (bin >> 4)] = f2{t.x, -t.y};
 			}
-		wave_sync_lds();
-		{
+		if constexpr (Cfg<LOG2M>::PLANAR) {
+			// bin order -> natural order through the float plane, one component at a time (both sides
+			// are unit-stride across lanes: no padding needed)
+			float* plane = reinterpret_cast<float*>(wbase);
+			float nx[P], ny[P];
+#pragma unroll
+			for (int c = 0; c < 2; c++) {
+#pragma unroll
+				for (int u = 0; u < RL; u++)
+#pragma unroll
+					for (int m = 0; m < NBL; m++) plane[fft_bin<LOG2M>(lane, m, u)] = c ? v[m + u * NBL].y : v[m + u * NBL].x;
+				wave_sync_lds();
+#pragma unroll
+				for (int q = 0; q < P; q++) (c ? ny : nx)[q] = plane[lane + 64 * q];
+				wave_sync_lds();
+			}
+#pragma unroll
+			for (int q = 0; q < P; q++) v[q] = f2{nx[q], ny[q]};
+		} else {
+			wave_sync_lds();
 			const f2* rb = xbuf + (lane + (lane >> 4));
 #pragma unroll
 			for (int q = 0; q < P; q++) v[q] = rb[68 * q];
+			wave_sync_lds();
 		}
-		wave_sync_lds();
 		// ---- r = IFFT_M(p);  X[k] = (c[k]/M) * conj(r[k])
 		fft_wave<LOG2M, false>(v, xbuf, tw, lane);
 

@@ -16,9 +16,10 @@ constexpr int kN = 1 << kLog2N;
 template <int INTYPE, int RS, int MODE>
 hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t stream, int* blocksUsed) {
 	auto kernel = oct_fused_kernel<kLog2N, INTYPE, RS, MODE>;
-	constexpr int waves = KCfg<kLog2N, RS>::WAVES;
+	constexpr bool kRoll = (MODE & MODE_ROLL) != 0;
+	constexpr int waves = KCfg<kLog2N, RS, kRoll>::WAVES;
 	constexpr int threads = waves * 64;
-	constexpr size_t lds = block_lds_bytes<kLog2N, RS>();
+	constexpr size_t lds = block_lds_bytes<kLog2N, RS, kRoll>();
 	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
 	static int blocksPerCU = 0, numCU = 0;
 	if (blocksPerCU == 0) {

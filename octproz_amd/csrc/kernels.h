@@ -48,30 +48,37 @@ struct FusedArgs {
 
 // Per-length launch shape.  WAVES = A-scans in flight per workgroup; all waves of a workgroup share
 // one LDS copy of the twiddle tables, the mean A-line and (LDS_LUT) the resampling/window/phasor LUT.
-// N = 1024: 16 waves x 8.5 KiB + 24 KiB of tables = 159.9 KiB -> one 1024-thread workgroup per CU,
-// 4 waves per SIMD.
+// N = 1024: 16 (cubic: 15) waves x 8.5 KiB + 24 (32) KiB of tables = 159.9 KiB -> one workgroup per CU.
 // WAVES/MINW: waves per workgroup / minimum waves per SIMD (register budget); LDS_LUT: resampling +
 // window*phasor tables in LDS (else fetched through L1/L2); PRIO: static per-phase wave priority;
 // MEAN_REGS: the lane's share of the mean A-line lives in VGPRs for the whole persistent loop;
 // WAVES_CW > 0: the cubic variant gathers with precomputed Catmull-Rom weights (16 B + 8 B of LDS
 // table per sample instead of 4 B + 8 B) and runs WAVES_CW waves per workgroup so that it fits.
+// PLANAR: the FFT exchanges go through LDS one component at a time (real parts, then imaginary
+// parts) in a float plane of N + N/16 words: half the slice, twice the waves of the long
+// transforms whose occupancy is LDS-bound (N = 2048: 6 -> 12 waves per CU, N = 4096: 2 -> 6);
+// WAVES_ROLL: waves of the rolling-average variants there (their prefix-sum array needs 8 N bytes).
 template <int LOG2N> struct Cfg;
-template <> struct Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
-template <> struct Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
-template <> struct Cfg<10> { static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 15; };
-template <> struct Cfg<11> { static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
-template <> struct Cfg<12> { static constexpr int WAVES = 2,  MINW = 1; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = false; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
+template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
+template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
+template <> struct Cfg<10> { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 15; };
+template <> struct Cfg<11> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 6; static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
+template <> struct Cfg<12> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 3; static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
 // per kernel variant: the cubic gather with precomputed weights trades waves for a larger table
-template <int LOG2N, int RS> struct KCfg {
+template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr bool CW = RS == RS_CUBIC && Cfg<LOG2N>::LDS_LUT && Cfg<LOG2N>::WAVES_CW > 0;
-	static constexpr int WAVES = CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
+	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::PLANAR) ? Cfg<LOG2N>::WAVES_ROLL : CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
+	static constexpr int MINW = (ROLL && Cfg<LOG2N>::PLANAR) ? (Cfg<LOG2N>::WAVES_ROLL + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
 
-template <int N> constexpr int wave_lds_bytes() {
-	constexpr int fft = (N + N / 16) * 8;
-	constexpr int row = (N + 2 * ROW_OFF) * 4;
+constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
+// LDS slice of one wave: the staged row (+ the prefix-sum array of the rolling average) and, later in
+// the iteration, the FFT exchange buffer: N complex padded by 1/16, or one float plane of that shape
+template <int N, bool ROLL = false> constexpr int wave_lds_bytes() {
+	constexpr int fft = (N + N / 16) * (Cfg<ilog2c(N)>::PLANAR ? 4 : 8);
+	constexpr int row = (N + 2 * ROW_OFF) * 4 + (ROLL ? N * 4 : 0);
 	constexpr int m = fft > row ? fft : row;
 	return (m + 15) & ~15;
 }
@@ -234,6 +241,36 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 	}
 }
 
+// PLANAR exchange between a radix-16 pass (NS = 1 or 16, strided mapping) and the next pass (strided
+// mapping): the real parts go through the float plane, then the imaginary parts.  Element j sits at word
+// j + K (j >> 5), K = 1 after the NS = 1 pass, 2 after the NS = 16 pass: with these pads the stride-NS
+// writes and the unit-stride reads of a 32-lane group hit 32 different banks (ds_*_b32), and every
+// address is again "lane base + immediate".
+template <int N, int R, int NS>
+OCT_DEV void exchange_planar(f2 (&v)[N / 64], float* plane, int lane) {
+	constexpr int P = N / 64, NB = P / R, K = NS == 1 ? 1 : 2;
+	static_assert(R == 16 && (NS == 1 || NS == 16), "pads derived for the radix-16 passes with NS = 1, 16");
+	const float* rb = plane + lane + K * (lane >> 5);
+	float nx[P], ny[P];
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+#pragma unroll
+		for (int m = 0; m < NB; m++) {
+			const int b = lane + 64 * m;
+			const int j0 = (b / NS) * (NS * R) + (b & (NS - 1));
+			float* wb = plane + j0 + K * (j0 >> 5);
+#pragma unroll
+			for (int u = 0; u < R; u++) wb[u * NS + K * ((u * NS) >> 5)] = c ? v[m + u * NB].y : v[m + u * NB].x;
+		}
+		wave_sync_lds();
+#pragma unroll
+		for (int q = 0; q < P; q++) (c ? ny : nx)[q] = rb[(64 + 2 * K) * q];
+		wave_sync_lds();
+	}
+#pragma unroll
+	for (int q = 0; q < P; q++) v[q] = f2{nx[q], ny[q]};
+}
+
 template <int LOG2N> struct Plan;
 // PERM: the exchange in front of the last (radix-4) pass is a 4x4 transpose between lane bits 5:4 and
 // two register-index bits -- done with v_permlane32_swap / v_permlane16_swap instead of through LDS.
@@ -295,11 +332,11 @@ template <int P> OCT_DEV void perm_exchange(f2 (&v)[P]) {
 
 // natural-order inverse FFT of v (element lane+64q).  With RL = radix of the last pass and
 // NB = P/RL the result bin is   contiguous (NB == 4, !PERM):  4*lane + m + u*N/RL
-// strided (NB == 1 or PERM):  lane + 64*m + u*N/RL,   held in v[m + u*NB].  PRUNE: only u < RL/2 valid.
+// strided (NB == 1, PERM or PLANAR):  lane + 64*m + u*N/RL,   held in v[m + u*NB].  PRUNE: only u < RL/2 valid.
 // bin held in v[m + u*NB] after fft_wave (see above)
 template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
 	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value, NB = (N / 64) / RL;
-	return ((Plan<LOG2N>::PERM || NB == 1) ? lane + 64 * m : NB * lane + m) + u * (N / RL);
+	return ((Plan<LOG2N>::PERM || Cfg<LOG2N>::PLANAR || NB == 1) ? lane + 64 * m : NB * lane + m) + u * (N / RL);
 }
 template <int LOG2N, bool PRUNE>
 OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane) {
@@ -309,6 +346,16 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	static_assert(R0 * R1 * R2 * R3 == N, "plan");
 	constexpr int T1 = 0, T2 = T1 + (R1 - 1) * R0, T3 = T2 + (R2 - 1) * R0 * R1;
 	constexpr int P = N / 64;
+	if constexpr (Cfg<LOG2N>::PLANAR) {
+		static_assert(!Cfg<LOG2N>::PLANAR || (R3 == 1 && R0 == 16 && R1 == 16), "planar exchange: radix 16, 16, R2");
+		float* plane = reinterpret_cast<float*>(xbuf);
+		fft_pass<N, R0, 1, false, false, false, false>(v, xbuf, tw, lane);
+		exchange_planar<N, R0, 1>(v, plane, lane);
+		fft_pass<N, R1, R0, false, false, false, false>(v, xbuf, tw + T1, lane);
+		exchange_planar<N, R1, R0>(v, plane, lane);
+		fft_pass<N, R2, R0 * R1, false, false, false, PRUNE>(v, xbuf, tw + T2, lane);
+		return;
+	}
 	fft_pass<N, R0, 1, false, true, false, false>(v, xbuf, tw, lane);
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
@@ -354,8 +401,8 @@ OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
 }
 template <int LOG2N> constexpr int mean_lds_bytes() { return Cfg<LOG2N>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
 template <int LOG2N, int RS> constexpr int lut_lds_bytes() { return !Cfg<LOG2N>::LDS_LUT ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
-template <int LOG2N, int RS> constexpr int block_lds_bytes() {
-	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + KCfg<LOG2N, RS>::WAVES * wave_lds_bytes<(1 << LOG2N)>();
+template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
+	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
 }
 
 // MODE bits of the kernel template
@@ -367,12 +414,12 @@ enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4 };
 // (IN_U16 only); MODE_SPECTRUM = write the full complex spectrum instead of the processed half
 // A-scan; MODE_LOG = logarithmic grey-scale mapping (cu:718) instead of the linear one (cu:739).
 template <int LOG2N, int INTYPE, int RS, int MODE>
-__global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) void oct_fused_kernel(const FusedArgs a) {
+__global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KCfg<LOG2N, RS, (MODE & 1) != 0>::MINW)) void oct_fused_kernel(const FusedArgs a) {
 	constexpr int N = 1 << LOG2N, P = N / 64;
-	constexpr int WAVES = KCfg<LOG2N, RS>::WAVES, THREADS = WAVES * 64;
+	constexpr int WAVES = KCfg<LOG2N, RS, (MODE & MODE_ROLL) != 0>::WAVES, THREADS = WAVES * 64;
 	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = Cfg<LOG2N>::MEAN_REGS;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
-	constexpr bool STRIDED_OUT = Plan<LOG2N>::PERM || NBL == 1;  // bin = lane + 64*m + u*N/RL, else NBL*lane + m + u*N/RL
+	constexpr bool STRIDED_OUT = Plan<LOG2N>::PERM || Cfg<LOG2N>::PLANAR || NBL == 1;  // bin = lane + 64*m + u*N/RL, else NBL*lane + m + u*N/RL
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (64 * SPL);
@@ -386,7 +433,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS>::WAVES) * 64, Cfg<LOG2N>::MINW) vo
 	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + N * (CW ? 16 : 4));
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
-	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + wave * wave_lds_bytes<N>();
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + wave * wave_lds_bytes<N, ROLL>();
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
