@@ -433,8 +433,24 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 		HIP_TRY(hipGetLastError());
 	}
 
-	if (p.bscanViewEnabled) { rc = updateBscanDisplay(h, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan); if (rc) return rc; }              // cu:1571-1574
-	if (p.enFaceViewEnabled) { rc = updateEnFaceDisplay(h, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView); if (rc) return rc; }  // cu:1575-1578
+	if (p.bscanViewEnabled && p.enFaceViewEnabled) {  // cu:1571-1578, both frames in one launch
+		oct::DisplayArgs d{};
+		d.dispBscan = h->d_dispBscan; d.dispEnFace = h->d_dispEnFace; d.vol = h->d_processed;
+		d.bscansPerVolume = (unsigned)B * h->acq.buffersPerVolume;
+		d.nBscan = (unsigned)(N * A / 2);
+		d.frameNrBscan = p.frameNr < d.bscansPerVolume ? p.frameNr : 0;
+		d.framesBscan = p.functionFramesBscan; d.fnBscan = p.displayFunctionBscan;
+		d.frameWidth = (unsigned)(N / 2);
+		d.nEnFace = d.bscansPerVolume * (unsigned)A;
+		d.frameNrEnFace = p.frameNrEnFaceView < d.frameWidth ? p.frameNrEnFaceView : 0;
+		d.framesEnFace = p.functionFramesEnFaceView; d.fnEnFace = p.displayFunctionEnFaceView;
+		d.bscanBlocks = (d.nBscan + 255) / 256;
+		hipLaunchKernelGGL(oct::oct_display_frames_kernel, dim3(d.bscanBlocks + (d.nEnFace + 255) / 256), dim3(256), 0, h->stream, d);
+		HIP_TRY(hipGetLastError());
+	} else {
+		if (p.bscanViewEnabled) { rc = updateBscanDisplay(h, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan); if (rc) return rc; }              // cu:1571-1574
+		if (p.enFaceViewEnabled) { rc = updateEnFaceDisplay(h, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView); if (rc) return rc; }  // cu:1575-1578
+	}
 
 	if (p.streamFloatToHost && h->floatStreamingRegistered) {  // streamProcessedFloatData, cu:1374-1386
 		h->floatStreamingBufferNumber = (h->floatStreamingBufferNumber + 1) % 2;

@@ -122,9 +122,7 @@ __global__ void oct_float_to_output_kernel(void* out, const float* in, int bitDe
 	}
 }
 // cu:810-860
-__global__ void oct_display_bscan_kernel(float* disp, const float* vol, unsigned bscansPerVolume, unsigned n, unsigned frameNr, unsigned frames, int fn) {
-	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
+__device__ __forceinline__ void display_bscan_element(unsigned i, float* disp, const float* vol, unsigned bscansPerVolume, unsigned n, unsigned frameNr, unsigned frames, int fn) {
 	if (frames > 1) {
 		if (fn == 0) {
 			int cnt = 0; float sum = 0;
@@ -139,10 +137,12 @@ __global__ void oct_display_bscan_kernel(float* disp, const float* vol, unsigned
 		disp[i] = vol[(size_t)frameNr * n + (n - 1) - i];
 	}
 }
-// cu:862-912
-__global__ void oct_display_enface_kernel(float* disp, const float* vol, unsigned frameWidth, unsigned n, unsigned frameNr, unsigned frames, int fn) {
+__global__ void oct_display_bscan_kernel(float* disp, const float* vol, unsigned bscansPerVolume, unsigned n, unsigned frameNr, unsigned frames, int fn) {
 	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
+	if (i < n) display_bscan_element(i, disp, vol, bscansPerVolume, n, frameNr, frames, fn);
+}
+// cu:862-912
+__device__ __forceinline__ void display_enface_element(unsigned i, float* disp, const float* vol, unsigned frameWidth, unsigned n, unsigned frameNr, unsigned frames, int fn) {
 	if (frames > 1) {
 		if (fn == 0) {
 			int cnt = 0; float sum = 0;
@@ -155,6 +155,27 @@ __global__ void oct_display_enface_kernel(float* disp, const float* vol, unsigne
 		}
 	} else {
 		disp[(n - 1) - i] = vol[frameNr + (size_t)i * frameWidth];
+	}
+}
+__global__ void oct_display_enface_kernel(float* disp, const float* vol, unsigned frameWidth, unsigned n, unsigned frameNr, unsigned frames, int fn) {
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) display_enface_element(i, disp, vol, frameWidth, n, frameNr, frames, fn);
+}
+// both display frames of a buffer in one launch (the two extractions are launch-latency bound):
+// blocks [0, bscanBlocks) take the B-scan frame, the rest the en-face frame
+struct DisplayArgs {
+	float* dispBscan; float* dispEnFace; const float* vol;
+	unsigned bscansPerVolume, nBscan, frameNrBscan, framesBscan; int fnBscan;
+	unsigned frameWidth, nEnFace, frameNrEnFace, framesEnFace; int fnEnFace;
+	unsigned bscanBlocks;
+};
+__global__ void oct_display_frames_kernel(const DisplayArgs a) {
+	if (blockIdx.x < a.bscanBlocks) {
+		const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+		if (i < a.nBscan) display_bscan_element(i, a.dispBscan, a.vol, a.bscansPerVolume, a.nBscan, a.frameNrBscan, a.framesBscan, a.fnBscan);
+	} else {
+		const unsigned i = (blockIdx.x - a.bscanBlocks) * blockDim.x + threadIdx.x;
+		if (i < a.nEnFace) display_enface_element(i, a.dispEnFace, a.vol, a.frameWidth, a.nEnFace, a.frameNrEnFace, a.framesEnFace, a.fnEnFace);
 	}
 }
 
