@@ -109,9 +109,6 @@ OCT_DEV u32x2 buf_load64(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 OCT_DEV void buf_store32(float v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, vbase + (c & 4095), c & ~4095, 0);
 }
-OCT_DEV void buf_store128(f32x4 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
-	__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, vbase + (c & 4095), c & ~4095, 0);
-}
 
 // ------------------------------------------------------------------ raw chunk = SPL consecutive samples per lane
 // The texture-address unit spends ~16 cycles per vector-memory wave instruction whatever its width,
@@ -166,9 +163,10 @@ OCT_DEV float lanczos8(float x) {
 // The sequence lives in the wave's LDS slice between passes, padded by one element per 16
 // (index j -> j + (j >> 4)): the stride-R writes and the unit-stride reads are both conflict-free.
 // Butterfly b combines elements b + t*N/R (t < R) and writes j0 + u*NS, j0 = (b/NS)*NS*R + b%NS.
-//   strided mapping (all passes but the last):  b = lane + 64*m      -> v[m + t*NB] = element b + t*N/R
-//   contiguous mapping (last pass, NB = 4):      b = 4*lane + m       -> every lane ends up with 4
-//     consecutive bins, so the epilogue stores 16 bytes per lane, 1 KiB per wave instruction.
+// Butterfly b = lane + 64*m of a lane:  v[m + t*NB] = element b + t*N/R ("strided mapping"); the lane
+// therefore finishes with the bins lane + 64*m + u*N/R and the epilogue stores 256 contiguous bytes
+// per wave instruction.  (A contiguous last-pass mapping with 16-byte stores was used before the
+// permlane / planar exchanges; the 4-byte stores measured within 2 % of it.)
 // All LDS addresses are "per-lane base + compile-time offset" (immediate fields, no VALU).
 constexpr int pad16c(int j) { return j + (j >> 4); }
 
@@ -179,23 +177,14 @@ constexpr int pad16c(int j) { return j + (j >> 4); }
 //   PACK == 2 (R = 16, NS = 16, one butterfly per lane): unit [c][k] = {w(2c, k), w(2c+1, k)}, c < 8, k = lane & 15
 //   PACK == 3 (R = 4, NS = 256, four butterflies per lane): unit [c][lane] = entries 2c, 2c+1 of the lane's
 //             12 twiddles, entry m*3 + t-1 = w(t, lane + 64 m)
-template <int N, int R, int NS, bool READ, bool WRITE, bool CONTIG, bool PRUNE, int PACK = 0>
+template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 	constexpr int P = N / 64, NB = P / R;
 	static_assert(NB >= 1, "radix larger than points per lane");
-	static_assert(!CONTIG || (READ && !WRITE && NB == 4), "contiguous mapping: last pass, four butterflies per lane");
 	if constexpr (READ) {
-		if constexpr (CONTIG) {
-			const f2* rb = xbuf + (4 * lane + (lane >> 2));
+		const f2* rb = xbuf + (lane + (lane >> 4));
 #pragma unroll
-			for (int t = 0; t < R; t++)
-#pragma unroll
-				for (int m = 0; m < 4; m++) v[m + t * NB] = rb[pad16c(t * (N / R)) + m];
-		} else {
-			const f2* rb = xbuf + (lane + (lane >> 4));
-#pragma unroll
-			for (int q = 0; q < P; q++) v[q] = rb[68 * q];
-		}
+		for (int q = 0; q < P; q++) v[q] = rb[68 * q];
 		wave_sync_lds();
 	}
 	if constexpr (PACK == 2) {
@@ -208,7 +197,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 			v[2 * c + 1] = octfft::cmul(v[2 * c + 1], f2{w.z, w.w});
 		}
 	} else if constexpr (PACK == 3) {
-		static_assert(PACK != 3 || (R == 4 && NS == 256 && NB == 4 && !CONTIG), "packed layout 3");
+		static_assert(PACK != 3 || (R == 4 && NS == 256 && NB == 4), "packed layout 3");
 		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + lane;
 #pragma unroll
 		for (int c = 0; c < 6; c++) {
@@ -220,7 +209,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 	} else if constexpr (NS > 1) {
 #pragma unroll
 		for (int m = 0; m < NB; m++) {
-			const int b = CONTIG ? 4 * lane + m : lane + 64 * m;
+			const int b = lane + 64 * m;
 			const f2* tk = twp + (b & (NS - 1));  // table layout [t-1][k]
 #pragma unroll
 			for (int t = 1; t < R; t++) v[m + t * NB] = octfft::cmul(v[m + t * NB], tk[(t - 1) * NS]);
@@ -330,13 +319,11 @@ template <int P> OCT_DEV void perm_exchange(f2 (&v)[P]) {
 	if constexpr (P == 16) perm_exchange16x4(v);
 }
 
-// natural-order inverse FFT of v (element lane+64q).  With RL = radix of the last pass and
-// NB = P/RL the result bin is   contiguous (NB == 4, !PERM):  4*lane + m + u*N/RL
-// strided (NB == 1, PERM or PLANAR):  lane + 64*m + u*N/RL,   held in v[m + u*NB].  PRUNE: only u < RL/2 valid.
-// bin held in v[m + u*NB] after fft_wave (see above)
+// natural-order inverse FFT of v (element lane+64q).  With RL = radix of the last pass and NB = P/RL
+// the result bin lane + 64*m + u*N/RL is held in v[m + u*NB] (fft_bin).  PRUNE: only u < RL/2 valid.
 template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
-	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value, NB = (N / 64) / RL;
-	return ((Plan<LOG2N>::PERM || Cfg<LOG2N>::PLANAR || NB == 1) ? lane + 64 * m : NB * lane + m) + u * (N / RL);
+	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value;
+	return lane + 64 * m + u * (N / RL);
 }
 template <int LOG2N, bool PRUNE>
 OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane) {
@@ -349,26 +336,26 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	if constexpr (Cfg<LOG2N>::PLANAR) {
 		static_assert(!Cfg<LOG2N>::PLANAR || (R3 == 1 && R0 == 16 && R1 == 16), "planar exchange: radix 16, 16, R2");
 		float* plane = reinterpret_cast<float*>(xbuf);
-		fft_pass<N, R0, 1, false, false, false, false>(v, xbuf, tw, lane);
+		fft_pass<N, R0, 1, false, false, false>(v, xbuf, tw, lane);
 		exchange_planar<N, R0, 1>(v, plane, lane);
-		fft_pass<N, R1, R0, false, false, false, false>(v, xbuf, tw + T1, lane);
+		fft_pass<N, R1, R0, false, false, false>(v, xbuf, tw + T1, lane);
 		exchange_planar<N, R1, R0>(v, plane, lane);
-		fft_pass<N, R2, R0 * R1, false, false, false, PRUNE>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R2, R0 * R1, false, false, PRUNE>(v, xbuf, tw + T2, lane);
 		return;
 	}
-	fft_pass<N, R0, 1, false, true, false, false>(v, xbuf, tw, lane);
+	fft_pass<N, R0, 1, false, true, false>(v, xbuf, tw, lane);
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
-		fft_pass<N, R1, R0, true, false, false, false, 2>(v, xbuf, tw, lane);
+		fft_pass<N, R1, R0, true, false, false, 2>(v, xbuf, tw, lane);
 		perm_exchange<P>(v);
-		fft_pass<N, R2, R0 * R1, false, false, false, PRUNE, 3>(v, xbuf, tw + 8 * 16 * 2, lane);
+		fft_pass<N, R2, R0 * R1, false, false, PRUNE, 3>(v, xbuf, tw + 8 * 16 * 2, lane);
 	} else if constexpr (R3 == 1) {
-		fft_pass<N, R1, R0, true, true, false, false>(v, xbuf, tw + T1, lane);
-		fft_pass<N, R2, R0 * R1, true, false, P / R2 == 4, PRUNE>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R1, R0, true, true, false>(v, xbuf, tw + T1, lane);
+		fft_pass<N, R2, R0 * R1, true, false, PRUNE>(v, xbuf, tw + T2, lane);
 	} else {
-		fft_pass<N, R1, R0, true, true, false, false>(v, xbuf, tw + T1, lane);
-		fft_pass<N, R2, R0 * R1, true, true, false, false>(v, xbuf, tw + T2, lane);
-		fft_pass<N, R3, R0 * R1 * R2, true, false, P / R3 == 4, PRUNE>(v, xbuf, tw + T3, lane);
+		fft_pass<N, R1, R0, true, true, false>(v, xbuf, tw + T1, lane);
+		fft_pass<N, R2, R0 * R1, true, true, false>(v, xbuf, tw + T2, lane);
+		fft_pass<N, R3, R0 * R1 * R2, true, false, PRUNE>(v, xbuf, tw + T3, lane);
 	}
 }
 
@@ -419,7 +406,6 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	constexpr int WAVES = KCfg<LOG2N, RS, (MODE & MODE_ROLL) != 0>::WAVES, THREADS = WAVES * 64;
 	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = Cfg<LOG2N>::MEAN_REGS;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
-	constexpr bool STRIDED_OUT = Plan<LOG2N>::PERM || Cfg<LOG2N>::PLANAR || NBL == 1;  // bin = lane + 64*m + u*N/RL, else NBL*lane + m + u*N/RL
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (64 * SPL);
@@ -480,7 +466,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		for (int u = 0; u < RL / 2; u++)
 #pragma unroll
 			for (int m = 0; m < NBL; m++)
-				mreg[m + u * NBL] = a.subtractMean ? a.meanLine[(STRIDED_OUT ? lane + 64 * m : NBL * lane + m) + u * (N / RL)] : f2{0.0f, 0.0f};
+				mreg[m + u * NBL] = a.subtractMean ? a.meanLine[fft_bin<LOG2N>(lane, m, u)] : f2{0.0f, 0.0f};
 	}
 	float* rowl = row + ROW_OFF + lane;
 	uint32_t tapA[CW ? P : 1];  // CW: LDS byte address of tap 0 of each of the lane's samples (same for every A-scan)
@@ -646,20 +632,11 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(1);
 
 		if constexpr (SPECTRUM) {
-			f2* dst = a.spectrum + (size_t)line * N + (STRIDED_OUT ? 1 : NBL) * lane;
+			f2* dst = a.spectrum + (size_t)line * N + lane;
 #pragma unroll
-			for (int u = 0; u < RL; u++) {
-				if constexpr (STRIDED_OUT) {
+			for (int u = 0; u < RL; u++)
 #pragma unroll
-					for (int m = 0; m < NBL; m++) dst[64 * m + u * (N / RL)] = v[m + u * NBL];
-				} else if constexpr (NBL == 4) {
-					float4* d4 = reinterpret_cast<float4*>(dst + u * (N / RL));
-					d4[0] = float4{v[0 + 4 * u].x, v[0 + 4 * u].y, v[1 + 4 * u].x, v[1 + 4 * u].y};
-					d4[1] = float4{v[2 + 4 * u].x, v[2 + 4 * u].y, v[3 + 4 * u].x, v[3 + 4 * u].y};
-				} else {
-					dst[u * (N / RL)] = v[u];
-				}
-			}
+				for (int m = 0; m < NBL; m++) dst[64 * m + u * (N / RL)] = v[m + u * NBL];
 		} else {
 			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
 			unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
@@ -667,7 +644,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			// (cu:1547), so with an odd B-scan count the last one is left as it is
 			if (a.flip && (b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) as = a.ascansPerBscan - 1u - as;
 			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2), N * 2u);
-			const f2* ml = meanL + (STRIDED_OUT ? 1 : NBL) * lane;
+			const f2* ml = meanL + lane;
 #pragma unroll
 			for (int u = 0; u < RL / 2; u++) {
 				float o[NBL];
@@ -675,18 +652,13 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				for (int m = 0; m < NBL; m++) {
 					f2 z;
 					if constexpr (MEAN_REGS) z = v[m + u * NBL] - mreg[m + u * NBL];
-					else z = v[m + u * NBL] - ml[(STRIDED_OUT ? 64 * m : m) + u * (N / RL)];
+					else z = v[m + u * NBL] - ml[64 * m + u * (N / RL)];
 					const float p = z.x * z.x + z.y * z.y;
 					const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
 					o[m] = a.sA * s + a.sB;
 				}
-				if constexpr (STRIDED_OUT) {
 #pragma unroll
-					for (int m = 0; m < NBL; m++) buf_store32(o[m], outR, lane * 4, (64 * m + u * (N / RL)) * 4);
-				} else {
-					static_assert(STRIDED_OUT || NBL == 4, "contiguous epilogue stores four bins per lane");
-					buf_store128(f32x4{o[0], o[1], o[2], o[3]}, outR, lane * 16, u * (N / RL) * 4);
-				}
+				for (int m = 0; m < NBL; m++) buf_store32(o[m], outR, lane * 4, (64 * m + u * (N / RL)) * 4);
 			}
 		}
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(0);
