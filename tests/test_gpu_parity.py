@@ -172,6 +172,27 @@ def test_chain_matches_oracle(case):
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("N", [256, 512, 2048, 4096])
+@pytest.mark.parametrize("case", ["linear", "lanczos", "rolling8", "rolling64_linear", "lin_scale", "flip", "nothing"])
+def test_chain_variants_on_the_other_lengths(N, case):
+    """the variants of the fused kernel differ per length (radix plan, LDS-resident tables, planar
+    exchange for N >= 2048, rolling-average prefix sums): image and spectrum against the oracle"""
+    A, B = 24, 2
+    p = v180_benchmark_params(N, A, B)
+    CASES[case](p)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + len(case))
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "%s N=%d" % (case, N))
+    if not p.bscanFlip:
+        spec = pipe.debug_spectrum(d.data_ptr(), A * B)
+        ospec = o.last_spectrum().reshape(-1, N).copy()
+        if p.fixedPatternNoiseRemoval:
+            ospec[:, :N // 2] += o.mean_line()[:N // 2]
+        common.compare_spectra(spec, ospec, N, case)
+    pipe.close(); o.close()
+
+
 @pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
 def test_every_supported_length(N):
     A, B = 7, 3  # ragged: 21 A-scans, not a multiple of the waves per workgroup
