@@ -22,6 +22,10 @@ template <int OP> __global__ __launch_bounds__(256) void k(float* out, int iters
 				if (OP == 7) { asm volatile("v_log_f32 %0, %0" : "+v"(a[i].x)); }
 				if (OP == 8) { asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i].x)); }
 				if (OP == 9) { asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "+v"(a[i]) : "v"(c)); }
+				if (OP == 10) { asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i].x), "+v"(a[i].y)); }
+				if (OP == 11) { asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i].x), "+v"(a[i].y)); }
+				if (OP == 12) { asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[i].y)); }
+				if (OP == 13) { asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[i].y)); }
 			}
 		}
 	}
@@ -48,6 +52,7 @@ int main() {
 		run<0>("v_fma_f32", w); run<1>("v_pk_fma_f32", w); run<2>("v_add_f32", w); run<3>("v_pk_add_f32", w);
 		run<4>("v_mov_b32", w); run<5>("v_pk_mul_f32", w); run<6>("v_mul_f32", w); run<7>("v_log_f32", w);
 		run<8>("v_cvt_f32_u32", w); run<9>("v_pk_add_f32 opsel/neg", w);
+		run<10>("v_permlane32_swap", w); run<11>("v_permlane16_swap", w); run<12>("v_mov_dpp quad_perm", w); run<13>("v_mov_dpp row_ror:8", w);
 	}
 	return 0;
 }
