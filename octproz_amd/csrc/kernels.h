@@ -639,11 +639,14 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				for (int m = 0; m < NBL; m++) dst[64 * m + u * (N / RL)] = v[m + u * NBL];
 		} else {
 			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
-			unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
-			// even buffer-local B-scans are mirrored; the reference's launch covers S/4 indices
-			// (cu:1547), so with an odd B-scan count the last one is left as it is
-			if (a.flip && (b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) as = a.ascansPerBscan - 1u - as;
-			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + ((size_t)b * a.ascansPerBscan + as) * (N / 2), N * 2u);
+			unsigned orow = line;  // output row; only the flip needs the (B-scan, A-scan) split of the line index
+			if (a.flip) {
+				const unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
+				// even buffer-local B-scans are mirrored; the reference's launch covers S/4 indices
+				// (cu:1547), so with an odd B-scan count the last one is left as it is
+				if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
+			}
+			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
 			const f2* ml = meanL + lane;
 #pragma unroll
 			for (int u = 0; u < RL / 2; u++) {
