@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -101,6 +102,7 @@ struct octpipe {
 	void* user = nullptr;
 
 	bool timing = false;
+	bool noReal2 = getenv("OCTPIPE_NO_REAL2") != nullptr;  // A/B switch: keep real-input configurations on oct_fused_kernel
 	std::vector<TimedLaunch> timed;
 	double timedMs = 0.0;
 	unsigned timedLaunches = 0;
@@ -313,6 +315,9 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		b.sA = a.sA;
 		b.sB = a.sB;
 		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
+	} else if (h->log2n == 10 && intype == oct::IN_U16 && rs == oct::RS_CUBIC && !roll && !spectrum && !p.dispersionCompensation && !h->noReal2) {
+		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
+		HIP_TRY(oct::launch_real2(p.signalLogScaling != 0, a, h->stream));
 	} else {
 		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, nullptr));
 	}

@@ -1,0 +1,34 @@
+// real2_inst.hip -- instantiates the real-input kernel (two A-scans per complex transform, N = 1024)
+#include "launch.h"
+#include "real2_kernel.h"
+
+namespace oct {
+
+namespace {
+template <int MODE>
+hipError_t launch_real2_one(const FusedArgs& a, hipStream_t stream) {
+	auto kernel = oct_real2_kernel<MODE>;
+	static int numCU = 0;
+	if (numCU == 0) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, REAL2_LDS_BYTES);
+		if (e != hipSuccess) return e;
+		int dev = 0;
+		if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+		if ((e = hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+	}
+	const unsigned pairs = (a.numLines + 1u) / 2u;
+	const unsigned need = (pairs + REAL2_WAVES - 1) / REAL2_WAVES;
+	unsigned blocks = (unsigned)numCU;  // ~156 KiB of LDS: one persistent workgroup per CU
+	if (blocks > need) blocks = need;
+	if (blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(REAL2_WAVES * 64), REAL2_LDS_BYTES, stream, a);
+	return hipGetLastError();
+}
+}  // namespace
+
+// uint16 input, cubic resampling, no rolling average, no dispersion compensation, image output, N = 1024
+hipError_t launch_real2(bool logScale, const FusedArgs& a, hipStream_t stream) {
+	return logScale ? launch_real2_one<MODE_LOG>(a, stream) : launch_real2_one<0>(a, stream);
+}
+
+}  // namespace oct

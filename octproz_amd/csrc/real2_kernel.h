@@ -1,0 +1,160 @@
+// real2_kernel.h -- N = 1024, uint16 input, cubic resampling, image output, dispersion compensation OFF
+// (the reference's default, octalgorithmparameters.cpp:72): the FFT input window[j] * y[j] is real, so
+// TWO A-scans share one complex transform:
+//     z = x1 + i x2,  Z = IDFT(z)   ->   X1[k] = (Z[k] + conj(Z[N-k])) / 2,   X2[k] = (Z[k] - conj(Z[N-k])) / (2i)
+// One wave64 handles a pair of consecutive A-scans per iteration with the same 16 x 16 x 4 transform as
+// oct_fused_kernel (unpruned: Z[N-k] is needed), one extra mirror exchange through LDS and a combine
+// step: about 0.72 of the vector and 0.77 of the LDS instructions per A-scan.  The factor 1/2 is folded
+// into the grey-scale constants (|S/2 - m|^2 = |S - 2m|^2 / 4).  Everything else (tables, tap weights,
+// flip rule, mean line) is the fused kernel's.
+#pragma once
+#include "kernels.h"
+
+namespace oct {
+
+constexpr int REAL2_WAVES = 15;
+constexpr int REAL2_ROW1 = 4224;  // byte offset of the second staged row inside the wave's slice
+constexpr int REAL2_TABLE_BYTES = (8 * 16 + 6 * 64) * 16 + 1024 * 16 + 1024 * 4;  // packed twiddles | tap weights | window
+constexpr int REAL2_LDS_BYTES = REAL2_TABLE_BYTES + REAL2_WAVES * wave_lds_bytes<1024>();
+static_assert(REAL2_LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
+static_assert(REAL2_ROW1 + (1024 + 2 * ROW_OFF) * 4 <= wave_lds_bytes<1024>(), "both staged rows fit the slice");
+static_assert(513 * 8 <= wave_lds_bytes<1024>(), "mirror buffer fits the slice");
+
+template <int MODE>
+__global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const FusedArgs a) {
+	constexpr int N = 1024, P = 16, THREADS = REAL2_WAVES * 64;
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	f2* tw = reinterpret_cast<f2*>(smem);
+	f32x4* cwL = reinterpret_cast<f32x4*>(smem + tw_lds_bytes<10>());
+	f32x4* winL = reinterpret_cast<f32x4*>(smem + tw_lds_bytes<10>() + N * 16);  // unit [q/4][lane] = window of samples lane + 64 (4 (q/4) + 0..3)
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	char* wbase = smem + REAL2_TABLE_BYTES + wave * wave_lds_bytes<N>();
+	float* row = reinterpret_cast<float*>(wbase);
+	f2* xbuf = reinterpret_cast<f2*>(wbase);
+
+	fill_twiddles<10>(tw, a.twiddle, tid, THREADS);
+	for (int i = tid; i < N; i += THREADS) {
+		const float4 t = a.lut[i];
+		const double p = (double)__builtin_amdgcn_fractf(t.x);  // cu:258-271 as tap weights, see kernels.h
+		const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+		cwL[i] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+		const int q = i >> 6, l = i & 63;
+		reinterpret_cast<float*>(winL)[((q >> 2) * 64 + l) * 4 + (q & 3)] = t.y * t.z;  // phasor = (1, 0): the window alone
+	}
+	__syncthreads();
+
+	// ---- loop invariants of the lane
+	typedef __attribute__((address_space(3))) const float lds_cfloat;
+	const uint32_t tapBase = __builtin_amdgcn_readfirstlane(
+	    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
+	uint32_t tapA[P];
+#pragma unroll
+	for (int q = 0; q < P; q++) tapA[q] = tapBase + 4u * (uint32_t)(int)a.lut[lane + 64 * q].x;
+	f2 mean2[8];  // twice the mean A-line at the lane's kept bins lane + 64 m + 256 u, u < 2
+#pragma unroll
+	for (int u = 0; u < 2; u++)
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			mean2[m + 4 * u] = a.subtractMean ? a.meanLine[fft_bin<10>(lane, m, u)] * 2.0f : f2{0.0f, 0.0f};
+	// out = sA f(P) + sB with P = |S - 2m|^2 / 4:  log2(P'/4) = log2(P') - 2,  sqrt(P'/4) = sqrt(P') / 2
+	const float sA = LOGSCALE ? a.sA : 0.5f * a.sA, sB = LOGSCALE ? a.sB - 2.0f * a.sA : a.sB;
+
+	const unsigned numPairs = (a.numLines + 1u) / 2u, pairsStride = gridDim.x * (unsigned)REAL2_WAVES;
+	unsigned pi = blockIdx.x * (unsigned)REAL2_WAVES + (unsigned)wave;
+	u32x2 pre[8];  // chunk i: row i / 4 of the pair, samples 256 (i % 4) + 4 lane .. + 3
+	auto prefetch = [&](unsigned pair) {
+#pragma unroll
+		for (int r = 0; r < 2; r++) {
+			const unsigned ln = 2u * pair + (unsigned)r;
+			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * (N * 2), ln < a.numLines ? N * 2u : 0u);
+#pragma unroll
+			for (int c = 0; c < 4; c++) pre[4 * r + c] = buf_load64(rawR, lane * 8, c * 512);
+		}
+	};
+	if (pi < numPairs) prefetch(pi);
+
+	for (; pi < numPairs; pi += pairsStride) {
+		// ---- stage both raw rows in LDS as float32
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			float* dst = reinterpret_cast<float*>(wbase + (i >> 2) * REAL2_ROW1) + ROW_OFF + 4 * lane + 256 * (i & 3);
+			*reinterpret_cast<float4*>(dst) = chunk_to_float<IN_U16>(u32x4{pre[i].x, pre[i].y, 0u, 0u}, 0, a.bitshift ? 4u : 0u);
+		}
+		if (pi + pairsStride < numPairs) prefetch(pi + pairsStride);
+		wave_sync_lds();
+		if (lane < 2) {  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
+			float* r = reinterpret_cast<float*>(wbase + lane * REAL2_ROW1);
+			r[ROW_OFF - 1] = r[ROW_OFF + 1];
+		}
+		wave_sync_lds();
+
+		// ---- k-linearisation x window of both A-scans -> z = x1 + i x2
+		__builtin_amdgcn_s_setprio(3);
+		f2 v[P];
+		f32x4 win4;
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+			const f32x4 cw = cwL[lane + 64 * q];
+			if ((q & 3) == 0) win4 = winL[lane + 64 * (q >> 2)];
+			const float w = (q & 3) == 0 ? win4.x : (q & 3) == 1 ? win4.y : (q & 3) == 2 ? win4.z : win4.w;
+			lds_cfloat* t0 = (lds_cfloat*)(uintptr_t)(tapA[q]);
+			lds_cfloat* t1 = (lds_cfloat*)(uintptr_t)(tapA[q] + (uint32_t)REAL2_ROW1);
+			const float y0 = __builtin_fmaf(cw.w, t0[3], __builtin_fmaf(cw.z, t0[2], __builtin_fmaf(cw.y, t0[1], cw.x * t0[0])));
+			const float y1 = __builtin_fmaf(cw.w, t1[3], __builtin_fmaf(cw.z, t1[2], __builtin_fmaf(cw.y, t1[1], cw.x * t1[0])));
+			v[q] = f2{w * y0, w * y1};
+		}
+		wave_sync_lds();  // the rows are dead from here on
+
+		__builtin_amdgcn_s_setprio(2);
+		fft_wave<10, false>(v, xbuf, tw, lane);  // Z[lane + 64 m + 256 u] in v[m + 4 u], all u
+
+		// ---- mirror exchange: Z[N - k] of the kept bins k < N/2 comes from the upper half (and Z[0] for k = 0)
+		{
+			f2* mb = xbuf;
+#pragma unroll
+			for (int u = 2; u < 4; u++)
+#pragma unroll
+				for (int m = 0; m < 4; m++) mb[lane + 64 * m + 256 * (u - 2)] = v[m + 4 * u];  // slot k - 512
+			if (lane == 0) mb[512] = v[0];
+			wave_sync_lds();
+#pragma unroll
+			for (int u = 0; u < 2; u++)
+#pragma unroll
+				for (int m = 0; m < 4; m++) v[m + 4 * (u + 2)] = mb[512 - (lane + 64 * m + 256 * u)];  // Z[N - k]
+			wave_sync_lds();
+		}
+		__builtin_amdgcn_s_setprio(1);
+
+		// ---- combine, mean A-line subtraction, |.|^2, log / lin scaling, two output rows
+		const unsigned line0 = 2u * pi;
+		unsigned orow[2] = {line0, line0 + 1u};
+		if (a.flip) {
+#pragma unroll
+			for (int r = 0; r < 2; r++) {
+				const unsigned ln = line0 + (unsigned)r, b = ln / a.ascansPerBscan, as = ln - b * a.ascansPerBscan;
+				if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow[r] = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
+			}
+		}
+		const __amdgpu_buffer_rsrc_t out0 = make_rsrc(a.out + (size_t)orow[0] * (N / 2), N * 2u);
+		const __amdgpu_buffer_rsrc_t out1 = make_rsrc(a.out + (size_t)orow[1] * (N / 2), line0 + 1u < a.numLines ? N * 2u : 0u);
+#pragma unroll
+		for (int u = 0; u < 2; u++)
+#pragma unroll
+			for (int m = 0; m < 4; m++) {
+				const f2 z = v[m + 4 * u], zp = v[m + 4 * (u + 2)], mm = mean2[m + 4 * u];
+				const f2 s1 = f2{z.x + zp.x, z.y - zp.y} - mm;        // 2 X1 - 2 mean
+				const f2 s2 = f2{z.y + zp.y, zp.x - z.x} - mm;        // 2 X2 - 2 mean,  X2 = (Z - conj Zp) / (2i)
+				const float p1 = s1.x * s1.x + s1.y * s1.y, p2 = s2.x * s2.x + s2.y * s2.y;
+				const float f1 = LOGSCALE ? __builtin_amdgcn_logf(p1) : __builtin_amdgcn_sqrtf(p1);
+				const float f2v = LOGSCALE ? __builtin_amdgcn_logf(p2) : __builtin_amdgcn_sqrtf(p2);
+				buf_store32(sA * f1 + sB, out0, lane * 4, (64 * m + 256 * u) * 4);
+				buf_store32(sA * f2v + sB, out1, lane * 4, (64 * m + 256 * u) * 4);
+			}
+		__builtin_amdgcn_s_setprio(0);
+		wave_sync_lds();
+	}
+}
+
+}  // namespace oct

@@ -172,6 +172,35 @@ def test_chain_matches_oracle(case):
     pipe.close(); o.close()
 
 
+REAL_INPUT_CASES = {
+    "log": mutate(dispersionCompensation=0),
+    "lin": mutate(dispersionCompensation=0, signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
+    "flip": mutate(dispersionCompensation=0, bscanFlip=1),
+    "no_fpn": mutate(dispersionCompensation=0, fixedPatternNoiseRemoval=0),
+    "no_window": mutate(dispersionCompensation=0, windowing=0),
+    "bitshift": mutate(dispersionCompensation=0, bitshift=1, bitDepth=16),
+}
+
+
+@pytest.mark.parametrize("case", list(REAL_INPUT_CASES))
+@pytest.mark.parametrize("A,B", [(24, 3), (7, 3), (1, 1)])
+def test_real_input_kernel_matches_oracle(case, A, B):
+    """without dispersion compensation (the reference's default) the N = 1024 cubic variant transforms two
+    A-scans per complex FFT (real2_kernel.h); odd line counts leave the last pair half empty"""
+    N = 1024
+    p = v180_benchmark_params(N, A, B)
+    REAL_INPUT_CASES[case](p)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=A * 10 + B)
+    if case == "bitshift":
+        raw = (raw.astype(np.uint32) * 16).astype(np.uint16)
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0  # fewer than 18 lines cannot give a mean line (see the FPN tests)
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "real input %s %dx%d" % (case, A, B))
+    pipe.close(); o.close()
+
+
 @pytest.mark.parametrize("N", [256, 512, 2048, 4096])
 @pytest.mark.parametrize("case", ["linear", "lanczos", "rolling8", "rolling64_linear", "lin_scale", "flip", "nothing"])
 def test_chain_variants_on_the_other_lengths(N, case):
