@@ -19,9 +19,9 @@ OCT_DECL_LAUNCH(11)
 OCT_DECL_LAUNCH(12)
 #undef OCT_DECL_LAUNCH
 
-// N = 1024 / uint16 / cubic / image output without dispersion compensation: real FFT input, two A-scans per
-// complex transform (real2_kernel.h)
-hipError_t launch_real2(bool logScale, const FusedArgs& a, hipStream_t stream);
+// N = 1024 / uint16 / image output without dispersion compensation (rs = RS_NONE, RS_LINEAR or RS_CUBIC): real FFT
+// input, two A-scans per complex transform (real2_kernel.h)
+hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 
 // power-of-two lengths run the direct FFT
 inline bool fused_supported(unsigned n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }

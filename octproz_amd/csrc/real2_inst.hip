@@ -5,9 +5,9 @@
 namespace oct {
 
 namespace {
-template <int MODE>
+template <int RS, int MODE>
 hipError_t launch_real2_one(const FusedArgs& a, hipStream_t stream) {
-	auto kernel = oct_real2_kernel<MODE>;
+	auto kernel = oct_real2_kernel<RS, MODE>;
 	static int numCU = 0;
 	if (numCU == 0) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, REAL2_LDS_BYTES);
@@ -26,9 +26,14 @@ hipError_t launch_real2_one(const FusedArgs& a, hipStream_t stream) {
 }
 }  // namespace
 
-// uint16 input, cubic resampling, no rolling average, no dispersion compensation, image output, N = 1024
-hipError_t launch_real2(bool logScale, const FusedArgs& a, hipStream_t stream) {
-	return logScale ? launch_real2_one<MODE_LOG>(a, stream) : launch_real2_one<0>(a, stream);
+// uint16 input, no / linear / cubic resampling, no rolling average, no dispersion compensation, image output, N = 1024
+hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	switch (rs) {
+	case RS_NONE: return logScale ? launch_real2_one<RS_NONE, MODE_LOG>(a, stream) : launch_real2_one<RS_NONE, 0>(a, stream);
+	case RS_LINEAR: return logScale ? launch_real2_one<RS_LINEAR, MODE_LOG>(a, stream) : launch_real2_one<RS_LINEAR, 0>(a, stream);
+	case RS_CUBIC: return logScale ? launch_real2_one<RS_CUBIC, MODE_LOG>(a, stream) : launch_real2_one<RS_CUBIC, 0>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 }  // namespace oct

@@ -1,4 +1,4 @@
-// real2_kernel.h -- N = 1024, uint16 input, cubic resampling, image output, dispersion compensation OFF
+// real2_kernel.h -- N = 1024, uint16 input, no / linear / cubic resampling, image output, dispersion compensation OFF
 // (the reference's default, octalgorithmparameters.cpp:72): the FFT input window[j] * y[j] is real, so
 // TWO A-scans share one complex transform:
 //     z = x1 + i x2,  Z = IDFT(z)   ->   X1[k] = (Z[k] + conj(Z[N-k])) / 2,   X2[k] = (Z[k] - conj(Z[N-k])) / (2i)
@@ -20,8 +20,9 @@ static_assert(REAL2_LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
 static_assert(REAL2_ROW1 + (1024 + 2 * ROW_OFF) * 4 <= wave_lds_bytes<1024>(), "both staged rows fit the slice");
 static_assert(513 * 8 <= wave_lds_bytes<1024>(), "mirror buffer fits the slice");
 
-template <int MODE>
+template <int RS, int MODE>
 __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const FusedArgs a) {
+	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
 	constexpr int N = 1024, P = 16, THREADS = REAL2_WAVES * 64;
 	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -37,9 +38,13 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 	fill_twiddles<10>(tw, a.twiddle, tid, THREADS);
 	for (int i = tid; i < N; i += THREADS) {
 		const float4 t = a.lut[i];
-		const double p = (double)__builtin_amdgcn_fractf(t.x);  // cu:258-271 as tap weights, see kernels.h
-		const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
-		cwL[i] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+		const double p = (double)__builtin_amdgcn_fractf(t.x);
+		if constexpr (RS == RS_CUBIC) {  // cu:258-271 as tap weights, see kernels.h
+			const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+			cwL[i] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+		} else if constexpr (RS == RS_LINEAR) {  // cu:225-228: f0 + (f1 - f0) p as weights of taps 1 and 2
+			cwL[i] = f32x4{0.0f, (float)(1.0 - p), (float)p, 0.0f};
+		}
 		const int q = i >> 6, l = i & 63;
 		reinterpret_cast<float*>(winL)[((q >> 2) * 64 + l) * 4 + (q & 3)] = t.y * t.z;  // phasor = (1, 0): the window alone
 	}
@@ -49,9 +54,11 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 	typedef __attribute__((address_space(3))) const float lds_cfloat;
 	const uint32_t tapBase = __builtin_amdgcn_readfirstlane(
 	    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
-	uint32_t tapA[P];
+	uint32_t tapA[RS == RS_NONE ? 1 : P];
+	if constexpr (RS != RS_NONE) {
 #pragma unroll
-	for (int q = 0; q < P; q++) tapA[q] = tapBase + 4u * (uint32_t)(int)a.lut[lane + 64 * q].x;
+		for (int q = 0; q < P; q++) tapA[q] = tapBase + 4u * (uint32_t)(int)a.lut[lane + 64 * q].x;
+	}
 	f2 mean2[8];  // twice the mean A-line at the lane's kept bins lane + 64 m + 256 u, u < 2
 #pragma unroll
 	for (int u = 0; u < 2; u++)
@@ -84,11 +91,13 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 		}
 		if (pi + pairsStride < numPairs) prefetch(pi + pairsStride);
 		wave_sync_lds();
-		if (lane < 2) {  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
-			float* r = reinterpret_cast<float*>(wbase + lane * REAL2_ROW1);
-			r[ROW_OFF - 1] = r[ROW_OFF + 1];
+		if constexpr (RS == RS_CUBIC) {
+			if (lane < 2) {  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
+				float* r = reinterpret_cast<float*>(wbase + lane * REAL2_ROW1);
+				r[ROW_OFF - 1] = r[ROW_OFF + 1];
+			}
+			wave_sync_lds();
 		}
-		wave_sync_lds();
 
 		// ---- k-linearisation x window of both A-scans -> z = x1 + i x2
 		__builtin_amdgcn_s_setprio(3);
@@ -96,13 +105,24 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 		f32x4 win4;
 #pragma unroll
 		for (int q = 0; q < P; q++) {
-			const f32x4 cw = cwL[lane + 64 * q];
 			if ((q & 3) == 0) win4 = winL[lane + 64 * (q >> 2)];
 			const float w = (q & 3) == 0 ? win4.x : (q & 3) == 1 ? win4.y : (q & 3) == 2 ? win4.z : win4.w;
-			lds_cfloat* t0 = (lds_cfloat*)(uintptr_t)(tapA[q]);
-			lds_cfloat* t1 = (lds_cfloat*)(uintptr_t)(tapA[q] + (uint32_t)REAL2_ROW1);
-			const float y0 = __builtin_fmaf(cw.w, t0[3], __builtin_fmaf(cw.z, t0[2], __builtin_fmaf(cw.y, t0[1], cw.x * t0[0])));
-			const float y1 = __builtin_fmaf(cw.w, t1[3], __builtin_fmaf(cw.z, t1[2], __builtin_fmaf(cw.y, t1[1], cw.x * t1[0])));
+			float y0, y1;
+			if constexpr (RS == RS_NONE) {
+				y0 = row[ROW_OFF + lane + 64 * q];
+				y1 = row[REAL2_ROW1 / 4 + ROW_OFF + lane + 64 * q];
+			} else {
+				const f32x4 cw = cwL[lane + 64 * q];
+				lds_cfloat* t0 = (lds_cfloat*)(uintptr_t)(tapA[q]);
+				lds_cfloat* t1 = (lds_cfloat*)(uintptr_t)(tapA[q] + (uint32_t)REAL2_ROW1);
+				if constexpr (RS == RS_CUBIC) {
+					y0 = __builtin_fmaf(cw.w, t0[3], __builtin_fmaf(cw.z, t0[2], __builtin_fmaf(cw.y, t0[1], cw.x * t0[0])));
+					y1 = __builtin_fmaf(cw.w, t1[3], __builtin_fmaf(cw.z, t1[2], __builtin_fmaf(cw.y, t1[1], cw.x * t1[0])));
+				} else {
+					y0 = __builtin_fmaf(cw.z, t0[2], cw.y * t0[1]);
+					y1 = __builtin_fmaf(cw.z, t1[2], cw.y * t1[1]);
+				}
+			}
 			v[q] = f2{w * y0, w * y1};
 		}
 		wave_sync_lds();  // the rows are dead from here on

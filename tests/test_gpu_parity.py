@@ -179,14 +179,19 @@ REAL_INPUT_CASES = {
     "no_fpn": mutate(dispersionCompensation=0, fixedPatternNoiseRemoval=0),
     "no_window": mutate(dispersionCompensation=0, windowing=0),
     "bitshift": mutate(dispersionCompensation=0, bitshift=1, bitDepth=16),
+    "linear": mutate(dispersionCompensation=0, resamplingInterpolation=INTERPOLATION.LINEAR),
+    "linear_lin_flip": mutate(dispersionCompensation=0, resamplingInterpolation=INTERPOLATION.LINEAR, bscanFlip=1, signalLogScaling=0,
+                              signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
+    "no_resampling": mutate(dispersionCompensation=0, resampling=0),
+    "reference_defaults": mutate(dispersionCompensation=0, resampling=0, windowing=0),
 }
 
 
 @pytest.mark.parametrize("case", list(REAL_INPUT_CASES))
 @pytest.mark.parametrize("A,B", [(24, 3), (7, 3), (1, 1)])
 def test_real_input_kernel_matches_oracle(case, A, B):
-    """without dispersion compensation (the reference's default) the N = 1024 cubic variant transforms two
-    A-scans per complex FFT (real2_kernel.h); odd line counts leave the last pair half empty"""
+    """without dispersion compensation (the reference's default) N = 1024 transforms two A-scans per complex
+    FFT (real2_kernel.h; no / linear / cubic resampling); odd line counts leave the last pair half empty"""
     N = 1024
     p = v180_benchmark_params(N, A, B)
     REAL_INPUT_CASES[case](p)
