@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Device-resident throughput of processing-setting variants on the 1024 x 512 x 256 buffer (the headline
+bench.py line is the reference's v1.8.0 settings; this lists what other settings cost).  Without dispersion
+compensation N = 1024 runs the real-input kernel (two A-scans per complex FFT); OCTPIPE_NO_REAL2=1 keeps
+those configurations on the general kernel for an A/B comparison.
+
+    python scripts/variant_bench.py
+"""
+import json
+import os
+import sys
+import time
+
+import torch  # before the library: both bring a HIP runtime, torch's has to initialise first
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from octproz_amd import INTERPOLATION, Pipeline, v180_benchmark_params  # noqa: E402
+from octproz_amd.virtual_oct import synthetic_raw_torch  # noqa: E402
+
+VARIANTS = [
+    ("v1.8.0 settings (dispersion on)", {}),
+    ("no dispersion, cubic", {"dispersionCompensation": 0}),
+    ("no dispersion, linear", {"dispersionCompensation": 0, "resamplingInterpolation": INTERPOLATION.LINEAR}),
+    ("reference defaults (no resampling / window / dispersion)", {"dispersionCompensation": 0, "resampling": 0, "windowing": 0}),
+    ("linear resampling", {"resamplingInterpolation": INTERPOLATION.LINEAR}),
+    ("rolling average W=64", {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}),
+    ("B-scan flip", {"bscanFlip": 1}),
+]
+
+
+def main():
+    N, A, B = 1024, 512, 256
+    vols = [synthetic_raw_torch(N, A, B, "cuda:0", seed=i) for i in range(4)]
+    out = []
+    for name, mut in VARIANTS:
+        p = v180_benchmark_params(N, A, B)
+        for k, v in mut.items():
+            setattr(p, k, v)
+        p.update_all_curves()
+        pipe = Pipeline(p, device=0)
+        for i in range(10):
+            pipe.process_device(vols[i % 4].data_ptr(), sync_params=(i == 0))
+        pipe.synchronize()
+        t = time.perf_counter()
+        for i in range(100):
+            pipe.process_device(vols[i % 4].data_ptr(), sync_params=False)
+        pipe.synchronize()
+        dt = (time.perf_counter() - t) / 100
+        out.append({"settings": name, "ms_per_buffer": dt * 1e3, "ascans_per_s": A * B / dt})
+        pipe.close()
+    print(json.dumps({"workload": "%dx%dx%d" % (N, A, B), "real_input_kernel": not os.environ.get("OCTPIPE_NO_REAL2"), "variants": out}))
+
+
+if __name__ == "__main__":
+    main()
