@@ -58,17 +58,24 @@ struct FusedArgs {
 // parts) in a float plane of N + N/16 words: half the slice, twice the waves of the long
 // transforms whose occupancy is LDS-bound (N = 2048: 6 -> 12 waves per CU, N = 4096: 2 -> 6);
 // WAVES_ROLL: waves of the rolling-average variants there (their prefix-sum array needs 8 N bytes).
+// OCT_REGTAB (N = 1024, cubic-weights variant): the lane-invariant tables (tap weights, window*phasor, twiddles of the
+// second pass) live in VGPRs for the whole persistent loop instead of being re-read from LDS for every A-scan; 8 waves
+// per workgroup (2 per SIMD, 256-register budget) instead of 15.
+#ifndef OCT_REGTAB
+#define OCT_REGTAB 0
+#endif
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
-template <> struct Cfg<10> { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 15; };
+template <> struct Cfg<10> { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = OCT_REGTAB ? 8 : 15; };
 template <> struct Cfg<11> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 6; static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
 template <> struct Cfg<12> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 3; static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
 // per kernel variant: the cubic gather with precomputed weights trades waves for a larger table
 template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr bool CW = RS == RS_CUBIC && Cfg<LOG2N>::LDS_LUT && Cfg<LOG2N>::WAVES_CW > 0;
 	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::PLANAR) ? Cfg<LOG2N>::WAVES_ROLL : CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
-	static constexpr int MINW = (ROLL && Cfg<LOG2N>::PLANAR) ? (Cfg<LOG2N>::WAVES_ROLL + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
+	static constexpr bool REGTAB = CW && LOG2N == 10 && OCT_REGTAB != 0;
+	static constexpr int MINW = (ROLL && Cfg<LOG2N>::PLANAR) ? (Cfg<LOG2N>::WAVES_ROLL + 3) / 4 : REGTAB ? 2 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
@@ -177,8 +184,8 @@ constexpr int pad16c(int j) { return j + (j >> 4); }
 //   PACK == 2 (R = 16, NS = 16, one butterfly per lane): unit [c][k] = {w(2c, k), w(2c+1, k)}, c < 8, k = lane & 15
 //   PACK == 3 (R = 4, NS = 256, four butterflies per lane): unit [c][lane] = entries 2c, 2c+1 of the lane's
 //             12 twiddles, entry m*3 + t-1 = w(t, lane + 64 m)
-template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0>
-OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
+template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0, bool REGTW = false>
+OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const f32x4* twr = nullptr) {
 	constexpr int P = N / 64, NB = P / R;
 	static_assert(NB >= 1, "radix larger than points per lane");
 	if constexpr (READ) {
@@ -192,7 +199,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane) {
 		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + (lane & 15);
 #pragma unroll
 		for (int c = 0; c < 8; c++) {
-			const f32x4 w = tp[c * 16];
+			const f32x4 w = REGTW ? twr[c] : tp[c * 16];
 			if (c > 0) v[2 * c] = octfft::cmul(v[2 * c], f2{w.x, w.y});
 			v[2 * c + 1] = octfft::cmul(v[2 * c + 1], f2{w.z, w.w});
 		}
@@ -325,8 +332,8 @@ template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
 	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value;
 	return lane + 64 * m + u * (N / RL);
 }
-template <int LOG2N, bool PRUNE>
-OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane) {
+template <int LOG2N, bool PRUNE, bool REGTW = false>
+OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane, const f32x4* twr = nullptr) {
 	constexpr int N = 1 << LOG2N;
 	typedef Plan<LOG2N> PL;
 	constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
@@ -346,7 +353,7 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	fft_pass<N, R0, 1, false, true, false>(v, xbuf, tw, lane);
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
-		fft_pass<N, R1, R0, true, false, false, 2>(v, xbuf, tw, lane);
+		fft_pass<N, R1, R0, true, false, false, 2, REGTW>(v, xbuf, tw, lane, twr);
 		perm_exchange<P>(v);
 		fft_pass<N, R2, R0 * R1, false, false, PRUNE, 3>(v, xbuf, tw + 8 * 16 * 2, lane);
 	} else if constexpr (R3 == 1) {
@@ -387,7 +394,7 @@ OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
 	}
 }
 template <int LOG2N> constexpr int mean_lds_bytes() { return Cfg<LOG2N>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
-template <int LOG2N, int RS> constexpr int lut_lds_bytes() { return !Cfg<LOG2N>::LDS_LUT ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
+template <int LOG2N, int RS> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
 template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
 	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
 }
@@ -404,7 +411,7 @@ template <int LOG2N, int INTYPE, int RS, int MODE>
 __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KCfg<LOG2N, RS, (MODE & 1) != 0>::MINW)) void oct_fused_kernel(const FusedArgs a) {
 	constexpr int N = 1 << LOG2N, P = N / 64;
 	constexpr int WAVES = KCfg<LOG2N, RS, (MODE & MODE_ROLL) != 0>::WAVES, THREADS = WAVES * 64;
-	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = Cfg<LOG2N>::MEAN_REGS;
+	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = Cfg<LOG2N>::MEAN_REGS, REGTAB = KCfg<LOG2N, RS>::REGTAB;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	typedef Chunk<INTYPE, N> CH;
@@ -427,7 +434,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
 	if constexpr (!MEAN_REGS)
 		for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
-	if constexpr (LDS_LUT) {
+	if constexpr (LDS_LUT && !REGTAB) {
 		for (int i = tid; i < N; i += THREADS) {
 			const float4 t = a.lut[i];
 			// window folded into the phasor (one rounding of difference).  CW: the values of samples lane+64q and
@@ -478,6 +485,22 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	if constexpr (CW) {
 #pragma unroll
 		for (int q = 0; q < P; q++) tapA[q] = tapBase + 4u * (uint32_t)(int)a.lut[lane + 64 * q].x;
+	}
+	// REGTAB: the same table entries the LDS variant reads per A-scan, computed once per persistent wave
+	f32x4 cwR[REGTAB ? P : 1];
+	f2 wphR[REGTAB ? P : 1];
+	f32x4 tw2R[REGTAB ? 8 : 1];
+	if constexpr (REGTAB) {
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+			const float4 t = a.lut[lane + 64 * q];
+			wphR[q] = f2{t.y * t.z, t.y * t.w};
+			const double p = (double)__builtin_amdgcn_fractf(t.x);
+			const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+			cwR[q] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+		}
+#pragma unroll
+		for (int c = 0; c < 8; c++) tw2R[c] = reinterpret_cast<const f32x4*>(tw)[c * 16 + (lane & 15)];
 	}
 	for (; line < a.numLines; line += wavesTotal) {
 		// ---- stage the raw row in LDS as float32
@@ -584,7 +607,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			f32x4 L;
 			f2 wph;
 			f32x4 cw;
-			if constexpr (CW) {
+			if constexpr (REGTAB) {
+				cw = cwR[q];
+				wph = wphR[q];
+			} else if constexpr (CW) {
 				cw = cwL[lane + 64 * q];
 				if ((q & 1) == 0) wph2 = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];
 				wph = (q & 1) ? f2{wph2.z, wph2.w} : f2{wph2.x, wph2.y};
@@ -628,7 +654,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 
 		// ---- inverse FFT
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(2);
-		fft_wave<LOG2N, !SPECTRUM>(v, xbuf, tw, lane);
+		fft_wave<LOG2N, !SPECTRUM, REGTAB>(v, xbuf, tw, lane, tw2R);
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(1);
 
 		if constexpr (SPECTRUM) {

@@ -28,6 +28,15 @@ int octref_num_threads(void) {
 #endif
 }
 
+/* threads of the following octref_* calls (bench.py times the oracle on 1 core and on all cores) */
+void octref_set_num_threads(int n) {
+#ifdef _OPENMP
+	if (n > 0) omp_set_num_threads(n);
+#else
+	(void)n;
+#endif
+}
+
 /* ======================================================================================
  * Host-side curve generators
  * ====================================================================================*/

@@ -140,6 +140,7 @@ void octref_get_postproc_background_line(const octref_state* s, float* out, int 
 /* complex spectrum (after IDFT / mean subtraction) of the last processed buffer, S values */
 const octref_c32* octref_last_spectrum(const octref_state* s);
 int octref_num_threads(void);
+void octref_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

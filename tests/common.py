@@ -61,16 +61,25 @@ def image_to_power(v, p):
 
 
 def compare_images(got, want, p, what=""):
-    """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima."""
+    """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima.
+
+    Non-finite values: log scaling maps a power of exactly 0 to -inf (cu:718, no guard).  -inf therefore IS the value
+    "P = 0" and is compared as such in the linear-power domain: where one side cancelled exactly against the mean line and
+    the other kept a rounding residue, the two differ by that residue, which must be below POWER_RTOL x line maximum like any
+    other bin.  NaN and +inf have no such meaning: their pattern must be identical on both sides."""
     half = int(p.samplesPerLine) // 2
     g = got.reshape(-1, half)
     w = want.reshape(-1, half)
     assert g.shape == w.shape
-    # identical non-finite pattern (log(0) = -inf must appear in the same places)
-    assert np.array_equal(np.isfinite(g), np.isfinite(w)), what + ": non-finite pattern differs"
-    fin = np.isfinite(w)
-    pg = np.where(fin, image_to_power(np.where(fin, g, 0), p), 0.0)
-    pw = np.where(fin, image_to_power(np.where(fin, w, 0), p), 0.0)
+    bad_g = np.isnan(g) | np.isposinf(g)
+    bad_w = np.isnan(w) | np.isposinf(w)
+    assert np.array_equal(bad_g, bad_w), what + ": NaN / +inf pattern differs"
+    if not p.signalLogScaling:
+        assert np.array_equal(np.isfinite(g), np.isfinite(w)), what + ": non-finite pattern differs"
+    ok = ~bad_w
+    zero_g, zero_w = np.isneginf(g), np.isneginf(w)
+    pg = np.where(ok & ~zero_g, image_to_power(np.where(np.isfinite(g), g, 0), p), 0.0)
+    pw = np.where(ok & ~zero_w, image_to_power(np.where(np.isfinite(w), w, 0), p), 0.0)
     line_max = pw.max(axis=1, keepdims=True)
     line_max[line_max == 0] = 1.0
     rel = np.abs(pg - pw) / line_max
@@ -78,7 +87,7 @@ def compare_images(got, want, p, what=""):
     assert max_rel <= POWER_RTOL, "%s: linear-power error %.3e > %.1e" % (what, max_rel, POWER_RTOL)
     max_db = 0.0
     if p.signalLogScaling:
-        strong = fin & (pw > DB_FLOOR * line_max)
+        strong = np.isfinite(g) & np.isfinite(w) & (pw > DB_FLOOR * line_max)
         if strong.any():
             max_db = float(np.abs(g[strong].astype(np.float64) - w[strong]).max())
             assert max_db <= DB_ATOL, "%s: normalised-dB error %.3e > %.1e" % (what, max_db, DB_ATOL)

@@ -1,0 +1,66 @@
+"""bench.py's launch path: `--gpus N` without WORLD_SIZE in the environment must start N ranks by itself (one process
+per GPU), rendezvous them, share the calibration blob and print ONE JSON line from rank 0.  On CPU this is exercised
+with `--dry-run --backend gloo` (no GPU work); on the GPU box with `--force-dist` (single-rank RCCL init + broadcast)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    js = [l for l in lines if l.lstrip().startswith("{")]
+    assert len(js) == 1 and lines[-1] is js[0], "one JSON line, printed last; got: %r" % lines  # (gloo / RCCL banners may precede it)
+    return json.loads(js[0])
+
+
+def test_gpus_2_launches_two_ranks_that_share_the_blob():
+    d = _run(["--gpus", "2", "--backend", "gloo", "--dry-run"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["max_rank"] == 1
+    assert d["blob_bytes"] == 16 + 22 * 1024
+    assert d["blob_checksum"] == sum(range(1024))  # every rank unpacked rank 0's mean line (max over ranks == the value)
+
+
+def test_torchrun_style_environment_is_one_rank_per_process():
+    """the driver's N > 1 form: WORLD_SIZE / RANK already in the environment -> no second level of launching"""
+    d = _run(["--gpus", "1", "--backend", "gloo", "--dry-run"],
+             {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1
+
+
+def test_a_failing_rank_fails_the_launcher():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "no-such-backend", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+
+
+@pytest.mark.gpu
+def test_force_dist_single_rank_rccl():
+    """one rank over RCCL on the GPU box: init, calibration broadcast, barrier, all-reduce, and the real timed path"""
+    d = _run(["--force-dist", "--steps", "10", "--warmup", "2", "--warmup-seconds", "0.2", "--bscans", "32",
+              "--no-cpu-baseline", "--no-extras"], timeout=900)
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1
+    assert d["value"] > 1e6 and 0.0 < d["roofline"]["frac"] < 1.0
+    assert d["roofline"]["launches"] == 10
+
+
+@pytest.mark.gpu
+def test_gpus_flag_launches_rank_processes_on_the_gpu_box():
+    """`--gpus 2` on a 1-GPU box: two rank processes share the one device (LOCAL_RANK wraps), RCCL cannot span two
+    ranks on one device, so the data path is checked with the gloo backend (device work still runs on the GPU)."""
+    d = _run(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--warmup-seconds", "0.2", "--bscans", "16",
+              "--no-cpu-baseline", "--no-extras"], timeout=900)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2
+    assert d["config"]["parallelism"] == "bscan-slab x2"
+    assert d["value"] > 1e6

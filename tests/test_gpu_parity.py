@@ -591,6 +591,9 @@ def _full_size(N, A, B, sample_lines=192, **settings):
     for b in (0, B // 2 - 1, B - 1):
         nb = max(1, sample_lines // A)
         b0 = min(b, B - nb)
+        if settings.get("bscanFlip"):  # the flip rule is buffer-local (cu:795): keep the sample's parity that of the buffer
+            nb = max(2, nb & ~1)
+            b0 = min(b, B - nb) & ~1
         ps = params(nb)
         o = common.make_oracle(ps)
         o.set_mean_line(mean)
@@ -606,15 +609,24 @@ def test_full_size_config2_1024x512x256():
 
 def test_full_size_real_input_kernel_1024x512x256():
     """the same buffer on the reference's default-style settings (no dispersion compensation): real-input kernel,
-    sharded == unsharded bit for bit (pairs never straddle a slab), idempotent, oracle on sampled B-scans"""
-    # FPN removal off: with a real-valued DC bin, X[0] - mean[0] cancels exactly on a few dozen of the 131 072 lines and
-    # whether log(0) = -inf appears there depends on the last bit (the mean-line path is covered by the small cases)
-    _full_size(1024, 512, 256, dispersionCompensation=0, fixedPatternNoiseRemoval=0)
+    sharded == unsharded bit for bit (pairs never straddle a slab), idempotent, oracle on sampled B-scans.
+    FPN removal stays ON: with a real-valued DC bin, X[0] - mean[0] cancels exactly on a few dozen of the 131 072 lines and
+    log(0) = -inf appears there on one side or the other depending on the last bit; compare_images treats -inf as the
+    power 0 it stands for, so such a bin is held to the same linear-power tolerance as every other one."""
+    _full_size(1024, 512, 256, dispersionCompensation=0)
 
 
-def test_full_size_config3_2048x1024x512_in_slabs():
-    """config 3 is 2 GiB of raw data; one 2048 x 1024 x 128 slab (512 MiB) exercises the 64-bit indexing"""
-    _full_size(2048, 1024, 128, sample_lines=1024)
+def test_full_size_config3_2048x1024x512():
+    """BASELINE config 3 at full size: ONE 2048 x 1024 x 512 buffer = 2 GiB of raw data in, 2 GiB of float32 out; sample and
+    byte offsets pass 2^31 inside a single launch.  Sharded == unsharded (two 1 GiB slabs), idempotent, oracle on the first,
+    a middle and the last B-scan."""
+    _full_size(2048, 1024, 512, sample_lines=1024)
+
+
+def test_config3_slab_with_flip_and_linear_scale():
+    """a 2048 x 1024 x 128 slab of config 3 on the v1.0.0-style settings (flip, linear scaling): the row-descriptor
+    arithmetic of the flipped store beyond 2^31 bytes"""
+    _full_size(2048, 1024, 128, sample_lines=1024, bscanFlip=1, signalLogScaling=0, signalGrayscaleMax=30.0, signalGrayscaleMin=0.0)
 
 
 # ------------------------------------------------------------------ edge cases

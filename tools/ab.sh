@@ -5,5 +5,5 @@
 for round in 1 2; do
 for v in "$@"; do
   if [ "$v" = base ]; then unset OCTPIPE_LIB; else export OCTPIPE_LIB=$PWD/scratch/variants/lib_$v.so; fi
-  python bench.py --steps 100 --warmup 10 --no-cpu-baseline $AB_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']/1e6,1), 'M A-scans/s  kernel_ms', round(d['roofline']['kernel_ms'],4))"
+  python bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-extras $AB_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']/1e6,1), 'M A-scans/s  kernel_ms', round(d['roofline']['kernel_ms'],4))"
 done; done

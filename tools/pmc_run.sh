@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE
            "SQ_IFETCH SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU" \
            "SQC_ICACHE_MISSES SQC_ICACHE_HITS SQC_ICACHE_REQ SQ_LEVEL_WAVES SQ_CYCLES SQ_BUSY_CU_CYCLES"; do
   i=$((i+1))
-  timeout 180 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python3 $OLDPWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" > $out/p$i.log 2>&1
+  timeout 180 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python3 $OLDPWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras "$@" > $out/p$i.log 2>&1
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $OLDPWD/tools/pmc_summary.py "oct_fused_kernel" $f
 done
