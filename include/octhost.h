@@ -81,6 +81,29 @@ int octhost_processing_run(octhost_system_t* s, octhost_consume_fn consume, void
 /* the same loop with consume = octpipe_process(pipe, buffer) */
 int octhost_processing_run_pipeline(octhost_system_t* s, octpipe_t* pipe, uint64_t maxBuffers, double maxSeconds, OctHostStats* stats);
 
+/* ---- Recorder (src/recorder.{h,cpp}): K buffers accumulated in memory, then written back to back into
+ * <savePath>/<timestamp>[_<fileName>]_<name>.raw -- headerless, i.e. a file the virtual OCT system reads back unchanged.
+ * OCTproZ instantiates it twice: name "raw" (fed with the ring slot, processing.cpp:187-189) and "processed" (fed from the
+ * streaming callbacks).  Fields = OctAlgorithmParameters::RecordingParams (octalgorithmparameters.h:84-98) that the class reads. */
+typedef struct OctHostRecordingParams {
+	const char* savePath;        /* existing directory */
+	const char* timestamp;       /* octhost_timestamp() format yyyyMMdd_hhmmsszzz (settingsfilemanager.cpp:36) */
+	const char* fileName;        /* optional user part, may be NULL / "" */
+	size_t   bufferSizeInBytes;
+	unsigned buffersToRecord;
+	int      startWithFirstBuffer; /* skip buffers until currentBufferNr == 0 (recorder.cpp:116-119) */
+} OctHostRecordingParams;
+typedef struct octhost_recorder octhost_recorder_t;
+octhost_recorder_t* octhost_recorder_create(const char* name);
+void octhost_recorder_destroy(octhost_recorder_t* r);
+int  octhost_recorder_init(octhost_recorder_t* r, const OctHostRecordingParams* p);                    /* slot_init, recorder.cpp:64-88 */
+int  octhost_recorder_record(octhost_recorder_t* r, const void* buffer, unsigned currentBufferNr);      /* slot_record, :100-134; writes the file when the K-th buffer arrives */
+int  octhost_recorder_abort(octhost_recorder_t* r);                                                      /* slot_abortRecording, :52-62: saves what was captured */
+int  octhost_recorder_state(const octhost_recorder_t* r, int* recordingEnabled, int* finished, unsigned* recordedBuffers, uint64_t* bytesWritten);
+const char* octhost_recorder_path(const octhost_recorder_t* r);
+const char* octhost_recorder_error(const octhost_recorder_t* r);
+int  octhost_timestamp(char* out, size_t size);   /* >= 19 bytes */
+
 /* ---- files OCTproZ writes: settings.ini and curve CSVs ----
  * Curve-defining settings that are not part of OctPipeParams (they only enter through the curves:
  * OctAlgorithmParameters c0..c3, d0..d3, window, windowCenter, windowFillFactor, custom curve path). */

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCTPIPE_ABI_VERSION 1
+#define OCTPIPE_ABI_VERSION 2
 
 enum {
 	OCTPIPE_OK = 0,
@@ -98,6 +98,7 @@ typedef struct OctPipeParams {
 	uint32_t frameNrEnFaceView;
 	uint32_t functionFramesEnFaceView;
 	int32_t displayFunctionEnFaceView;
+	int32_t volumeViewEnabled;                         /* 8-bit volume down-conversion, cu:1579-1582 (ABI v2) */
 } OctPipeParams;
 
 typedef struct octpipe octpipe_t; /* all state the reference keeps in cu:39-105 */
@@ -109,12 +110,18 @@ typedef void (*octpipe_data_callback)(void* buffer, unsigned bitDepth, unsigned 
                                       unsigned linesPerFrame, unsigned framesPerBuffer,
                                       unsigned buffersPerVolume, unsigned currentBufferNr, void* user);
 typedef void (*octpipe_event_callback)(void* user); /* backgroundRecorded, gpu2hostnotifier.cpp:57 */
+/* Callbacks run inside hipLaunchHostFunc on the pipeline's stream: they MUST NOT call any octpipe_* function that
+ * touches the device (everything except octpipe_last_error, octpipe_get_acquisition_params and
+ * octpipe_get_postprocess_background_host) -- HIP calls are not allowed there and a stream wait would deadlock. */
 
 /* ------------------------------------------------------------------ library */
 int         octpipe_abi_version(void);
 const char* octpipe_last_error(void);             /* thread-local text of the last failure */
 int         octpipe_device_count(int* count);     /* OCTPIPE_ERR_NO_DEVICE when none */
 void        octpipe_default_params(OctPipeParams* p); /* octalgorithmparameters.cpp:36-112 */
+/* sizeof(OctPipeParams) / sizeof(OctPipeAcquisitionParams) as this library was built: lets a foreign-language binding check
+ * its own struct mirror before the first call */
+void        octpipe_struct_sizes(size_t* paramsBytes, size_t* acquisitionParamsBytes);
 
 /* ------------------------------------------------------------------ host curve generators
  * (OctAlgorithmParameters::update*Curve + Polynomial + WindowFunction; bit-exact contract) */
@@ -167,6 +174,10 @@ int octpipe_update_dispersion_curve(octpipe_t* h, const float* curve, int size);
 int octpipe_update_window_curve(octpipe_t* h, const float* curve, int size);
 int octpipe_update_postprocess_background(octpipe_t* h, const float* background, int size);
 int octpipe_copy_postprocess_background_to_host(octpipe_t* h, float* background, int size);
+/* The host shadow of the recorded background.  The pipeline copies the device line into it in-stream BEFORE the
+ * onBackgroundRecorded callback fires (the reference copies into params->postProcessBackground in-stream and the callback
+ * only signals, cu:652-656), so this accessor makes no HIP call and is the one to use from inside that callback. */
+int octpipe_get_postprocess_background_host(const octpipe_t* h, float* background, int size);
 
 /* Calibration blob for multi-GPU: everything a second GPU needs to produce the same output
  * (curves, phasor LUT, mean A-line, post-process background, FPN state).  The host side moves it
@@ -227,6 +238,12 @@ int octpipe_set_callbacks(octpipe_t* h, octpipe_data_callback onStreamingData,
 int octpipe_change_displayed_bscan_frame(octpipe_t* h, unsigned frameNr, unsigned displayFunctionFrames, int displayFunction);
 int octpipe_change_displayed_enface_frame(octpipe_t* h, unsigned frameNr, unsigned displayFunctionFrames, int displayFunction);
 int octpipe_get_display_buffers(octpipe_t* h, void** d_bscanFrame, size_t* bscanCount, void** d_enFaceFrame, size_t* enFaceCount);
+/* updateVolumeDisplayBuffer / updateDisplayedVolume (cu:914-941, cu:1310-1355) into a plain device buffer instead of a GL
+ * 3-D texture: uint8 voxels [N/2][B*buffersPerVolume][A] (x = A-scan fastest, then B-scan in the volume, then depth with
+ * depth reversed, exactly the texel the reference writes: surf3Dwrite(v, y = A-scan, x = B-scan, z = N/2-1-depth)),
+ * voxel = (unsigned char)(value * 255.0) for values in [0, 1]; values outside are clamped to 0 / 255 (undefined cast in the
+ * reference).  Written for every buffer while params.volumeViewEnabled is set; the buffer is allocated on first use. */
+int octpipe_get_volume_view_buffer(octpipe_t* h, void** d_voxels, size_t* bytes);
 int octpipe_register_gl_buffer_bscan(unsigned buf);       /* always OCTPIPE_ERR_UNSUPPORTED */
 int octpipe_register_gl_buffer_enface_view(unsigned buf); /* always OCTPIPE_ERR_UNSUPPORTED */
 int octpipe_register_gl_buffer_volume_view(unsigned buf); /* always OCTPIPE_ERR_UNSUPPORTED */

@@ -13,9 +13,10 @@
 // and drop the CUDA includes of src/kernels.h / src/gpu2hostnotifier.h (cuda_runtime_api.h,
 // helper_cuda.h, cufft.h, cuda_gl_interop.h; CUDART_CB becomes empty).
 //
-// Compile-checked in this repository against the reference headers + Qt 5.9.7
-// (tests/test_integration.py) with OCTPIPE_ADAPTER_NO_NOTIFIER, because gpu2hostnotifier.h pulls in
-// CUDA headers that do not exist here.
+// Compile-checked in this repository against the reference headers + Qt 5.9.7 (tests/test_integration.py), notifier leg
+// included: the test applies the edit named above to a temporary copy of gpu2hostnotifier.h (its two CUDA #include lines
+// dropped, CUDART_CB defined empty) -- exactly what the maintainer does when cuda_code.cu leaves the build.
+// OCTPIPE_ADAPTER_NO_NOTIFIER builds the adapter without the Qt signal leg (plain C hosts).
 #include <cstddef>
 
 #include "octalgorithmparameters.h"  // the reference's parameter singleton (Qt)
@@ -68,6 +69,7 @@ OctPipeParams toPod(const OctAlgorithmParameters* p) {
 	o.frameNrEnFaceView = p->frameNrEnFaceView;
 	o.functionFramesEnFaceView = p->functionFramesEnFaceView;
 	o.displayFunctionEnFaceView = p->displayFunctionEnFaceView;
+	o.volumeViewEnabled = p->volumeViewEnabled;                        // cu:1579 (plain uint8 buffer instead of the GL texture)
 	return o;
 }
 
@@ -80,8 +82,10 @@ void onFloatStreaming(void* buf, unsigned, unsigned, unsigned, unsigned, unsigne
 	Gpu2HostNotifier::dh2FloatStreamingCallback(buf);                 // cu:1385
 }
 void onBackground(void*) {
+	// Runs inside hipLaunchHostFunc: no HIP call is allowed here.  The pipeline has already copied the recorded line into its
+	// host shadow in-stream (the reference copies into params->postProcessBackground in-stream, cu:652-654); take it from there.
 	if (g_pipe && g_params && g_params->postProcessBackground)
-		octpipe_copy_postprocess_background_to_host(g_pipe, g_params->postProcessBackground, static_cast<int>(g_params->samplesPerLine / 2));
+		octpipe_get_postprocess_background_host(g_pipe, g_params->postProcessBackground, static_cast<int>(g_params->samplesPerLine / 2));
 	Gpu2HostNotifier::backgroundSignalCallback(nullptr);              // cu:655
 }
 #endif

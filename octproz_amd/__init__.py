@@ -7,7 +7,7 @@ from . import _lib
 from ._lib import OctPipeError
 from .params import INTERPOLATION, OctAlgorithmParameters, WindowType, v180_benchmark_params
 from .pipeline import Pipeline
-from .virtual_oct import AcquisitionBuffer, VirtualOCTSystem, synthetic_raw
+from .virtual_oct import AcquisitionBuffer, Recorder, VirtualOCTSystem, synthetic_raw
 
 __all__ = ["_lib", "OctPipeError", "INTERPOLATION", "OctAlgorithmParameters", "WindowType", "v180_benchmark_params",
-           "Pipeline", "AcquisitionBuffer", "VirtualOCTSystem", "synthetic_raw"]
+           "Pipeline", "AcquisitionBuffer", "Recorder", "VirtualOCTSystem", "synthetic_raw"]

@@ -43,7 +43,7 @@ class PipeParams(C.Structure):
         ("bscanViewEnabled", C.c_int32), ("enFaceViewEnabled", C.c_int32),
         ("frameNr", C.c_uint32), ("functionFramesBscan", C.c_uint32), ("displayFunctionBscan", C.c_int32),
         ("frameNrEnFaceView", C.c_uint32), ("functionFramesEnFaceView", C.c_uint32),
-        ("displayFunctionEnFaceView", C.c_int32),
+        ("displayFunctionEnFaceView", C.c_int32), ("volumeViewEnabled", C.c_int32),
     ]
 
 
@@ -62,6 +62,12 @@ class CurveSettings(C.Structure):
                 ("customResamplingFilePath", C.c_char * 1024), ("postBackgroundFilePath", C.c_char * 1024)]
 
 
+class RecordingParams(C.Structure):
+    """OctHostRecordingParams (include/octhost.h)"""
+    _fields_ = [("savePath", C.c_char_p), ("timestamp", C.c_char_p), ("fileName", C.c_char_p),
+                ("bufferSizeInBytes", C.c_size_t), ("buffersToRecord", C.c_uint), ("startWithFirstBuffer", C.c_int)]
+
+
 class HostStats(C.Structure):
     """OctHostStats (include/octhost.h)"""
     _fields_ = [("buffersProcessed", C.c_uint64), ("elapsedSeconds", C.c_double), ("volumesPerSecond", C.c_double),
@@ -75,12 +81,13 @@ CONSUME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint, C.c_void_p)
 
 # every symbol include/octpipe.h and include/octhost.h declare (checked by tests/test_abi.py)
 OCTPIPE_SYMBOLS = [
-    "octpipe_abi_version", "octpipe_last_error", "octpipe_device_count", "octpipe_default_params",
+    "octpipe_abi_version", "octpipe_last_error", "octpipe_device_count", "octpipe_default_params", "octpipe_struct_sizes",
     "octpipe_polynomial_curve", "octpipe_resample_curve", "octpipe_custom_resample_curve",
     "octpipe_dispersion_curve", "octpipe_window_curve",
     "octpipe_create", "octpipe_create_with_format", "octpipe_raw_buffer_bytes", "octpipe_destroy", "octpipe_set_params", "octpipe_get_acquisition_params",
     "octpipe_update_resample_curve", "octpipe_update_dispersion_curve", "octpipe_update_window_curve",
     "octpipe_update_postprocess_background", "octpipe_copy_postprocess_background_to_host",
+    "octpipe_get_postprocess_background_host",
     "octpipe_calibration_size", "octpipe_export_calibration", "octpipe_import_calibration",
     "octpipe_process", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
@@ -90,7 +97,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_register_float_streaming_buffers", "octpipe_unregister_float_streaming_buffers",
     "octpipe_set_callbacks",
     "octpipe_change_displayed_bscan_frame", "octpipe_change_displayed_enface_frame", "octpipe_get_display_buffers",
-    "octpipe_register_gl_buffer_bscan", "octpipe_register_gl_buffer_enface_view", "octpipe_register_gl_buffer_volume_view",
+    "octpipe_get_volume_view_buffer", "octpipe_register_gl_buffer_bscan", "octpipe_register_gl_buffer_enface_view", "octpipe_register_gl_buffer_volume_view",
     "octpipe_enable_kernel_timing", "octpipe_kernel_timing",
 ]
 OCTHOST_SYMBOLS = [
@@ -102,6 +109,8 @@ OCTHOST_SYMBOLS = [
     "octhost_system_acquisition_params", "octhost_last_error",
     "octhost_processing_run", "octhost_processing_run_pipeline",
     "octhost_load_settings_ini", "octhost_load_curve_csv", "octhost_save_curve_csv",
+    "octhost_recorder_create", "octhost_recorder_destroy", "octhost_recorder_init", "octhost_recorder_record",
+    "octhost_recorder_abort", "octhost_recorder_state", "octhost_recorder_path", "octhost_recorder_error", "octhost_timestamp",
 ]
 
 _lib = None
@@ -146,6 +155,19 @@ def lib():
         L.octhost_load_settings_ini.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.octhost_load_curve_csv.argtypes = [C.c_char_p, C.c_void_p, C.c_uint, C.c_void_p]
         L.octhost_save_curve_csv.argtypes = [C.c_char_p, C.c_void_p, C.c_uint]
+        L.octhost_recorder_create.restype = C.c_void_p
+        L.octhost_recorder_create.argtypes = [C.c_char_p]
+        L.octhost_recorder_destroy.restype = None
+        L.octhost_recorder_destroy.argtypes = [C.c_void_p]
+        L.octhost_recorder_init.argtypes = [C.c_void_p, C.c_void_p]
+        L.octhost_recorder_record.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.octhost_recorder_abort.argtypes = [C.c_void_p]
+        L.octhost_recorder_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.octhost_recorder_path.restype = C.c_char_p
+        L.octhost_recorder_path.argtypes = [C.c_void_p]
+        L.octhost_recorder_error.restype = C.c_char_p
+        L.octhost_recorder_error.argtypes = [C.c_void_p]
+        L.octhost_timestamp.argtypes = [C.c_char_p, C.c_size_t]
         L.octhost_processing_run.argtypes = [C.c_void_p, CONSUME_FN, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         L.octhost_processing_run_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         # pipeline entry points take the handle as void*
@@ -160,6 +182,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         for name in ("octpipe_update_resample_curve", "octpipe_update_dispersion_curve", "octpipe_update_window_curve",
                      "octpipe_update_postprocess_background", "octpipe_copy_postprocess_background_to_host",
+    "octpipe_get_postprocess_background_host",
                      "octpipe_set_mean_line"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.octpipe_export_calibration.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -176,6 +199,8 @@ def lib():
         L.octpipe_change_displayed_bscan_frame.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int]
         L.octpipe_change_displayed_enface_frame.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_int]
         L.octpipe_get_display_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.octpipe_get_volume_view_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.octpipe_get_postprocess_background_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.octpipe_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.octpipe_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.octpipe_polynomial_curve.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
@@ -185,6 +210,13 @@ def lib():
         L.octpipe_window_curve.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint, C.c_void_p]
         L.octpipe_default_params.argtypes = [C.c_void_p]
         L.octpipe_default_params.restype = None
+        L.octpipe_struct_sizes.argtypes = [C.c_void_p, C.c_void_p]
+        L.octpipe_struct_sizes.restype = None
+        sp, sa = C.c_size_t(), C.c_size_t()
+        L.octpipe_struct_sizes(C.byref(sp), C.byref(sa))
+        if sp.value != C.sizeof(PipeParams) or sa.value != C.sizeof(AcquisitionParams):
+            raise OctPipeError(-1, "struct mirror out of date: library %d/%d bytes, python %d/%d"
+                               % (sp.value, sa.value, C.sizeof(PipeParams), C.sizeof(AcquisitionParams)))
         _lib = L
     return _lib
 

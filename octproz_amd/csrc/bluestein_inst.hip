@@ -16,17 +16,10 @@ hipError_t launch_one(const BluesteinArgs& a, hipStream_t stream) {
 	auto kernel = oct_bluestein_kernel<kLog2M, RS, MODE>;
 	constexpr int waves = bluestein_waves<kLog2M>();
 	constexpr size_t lds = bluestein_lds_bytes<kLog2M>();
-	static int blocksPerCU = 0, numCU = 0;
-	if (blocksPerCU == 0) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) return e;
-		int dev = 0;
-		if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-		if ((e = hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-		int occ = 0;
-		if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, waves * 64, lds)) != hipSuccess) return e;
-		blocksPerCU = occ > 0 ? occ : 1;
-	}
+	KernelLaunchInfo info;
+	hipError_t e = kernel_launch_info(kernel, waves * 64, lds, &info);
+	if (e != hipSuccess) return e;
+	const int blocksPerCU = info.blocksPerCU, numCU = info.numCU;
 	const unsigned need = (a.numLines + waves - 1) / waves;
 	unsigned blocks = (unsigned)(numCU * blocksPerCU);
 	if (blocks > need) blocks = need;

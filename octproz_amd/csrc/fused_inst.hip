@@ -21,17 +21,10 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 	constexpr int threads = waves * 64;
 	constexpr size_t lds = block_lds_bytes<kLog2N, RS, kRoll>();
 	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
-	static int blocksPerCU = 0, numCU = 0;
-	if (blocksPerCU == 0) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) return e;
-		int dev = 0;
-		if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-		if ((e = hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-		int occ = 0;
-		if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds)) != hipSuccess) return e;
-		blocksPerCU = occ > 0 ? occ : 1;
-	}
+	KernelLaunchInfo info;
+	hipError_t e = kernel_launch_info(kernel, threads, lds, &info);
+	if (e != hipSuccess) return e;
+	const int blocksPerCU = info.blocksPerCU, numCU = info.numCU;
 	const unsigned need = (a.numLines + waves - 1) / waves;
 	unsigned blocks = requestedBlocks > 0 ? (unsigned)requestedBlocks : (unsigned)(numCU * blocksPerCU);
 	if (blocks > need) blocks = need;

@@ -152,6 +152,11 @@ int octpipe_window_curve(int windowType, float center, float fillFactor, unsigne
 }
 
 // octalgorithmparameters.cpp:36-112
+void octpipe_struct_sizes(size_t* paramsBytes, size_t* acquisitionParamsBytes) {
+	if (paramsBytes) *paramsBytes = sizeof(OctPipeParams);
+	if (acquisitionParamsBytes) *acquisitionParamsBytes = sizeof(OctPipeAcquisitionParams);
+}
+
 void octpipe_default_params(OctPipeParams* p) {
 	if (!p) return;
 	std::memset(p, 0, sizeof(*p));
@@ -166,6 +171,7 @@ void octpipe_default_params(OctPipeParams* p) {
 	p->postProcessBackgroundOffset = 0.0f;
 	p->bscanViewEnabled = 1;
 	p->enFaceViewEnabled = 1;
+	p->volumeViewEnabled = 0;  // octalgorithmparameters.cpp:100
 }
 
 }  // extern "C"

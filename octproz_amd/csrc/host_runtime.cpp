@@ -42,7 +42,9 @@ struct octhost_system {
 	std::atomic<bool> started{false};
 	std::atomic<bool> failed{false};
 	std::thread thread;
-	size_t bytesPerSample() const { return (p.bitDepth + 7) / 8; }
+	// ceil(bitDepth / 8) like virtualoctsystem.cpp:66, except that 17..24 bit samples travel in 4 bytes: the pipeline reads them
+	// as uint32 (cu:122-124) -- the reference allocates 3 bytes per sample here and then reads 4, past the end of its slot
+	size_t bytesPerSample() const { const size_t b = (p.bitDepth + 7) / 8; return b == 3 ? 4 : b; }
 	size_t bufferBytes() const { return (size_t)p.width * p.height * p.depth * bytesPerSample(); }
 };
 

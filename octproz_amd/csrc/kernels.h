@@ -134,12 +134,30 @@ OCT_DEV u32x4 load_chunk(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
 	else return __builtin_bit_cast(u32x4, buf_load128(r, voff, imm));
 }
 
+#ifndef OCT_SDWA_UNPACK
+#define OCT_SDWA_UNPACK 0
+#endif
+OCT_DEV float cvt_u16_lo(uint32_t x) {
+	float r;
+	asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(x));
+	return r;
+}
+OCT_DEV float cvt_u16_hi(uint32_t x) {
+	float r;
+	asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(x));
+	return r;
+}
 // cu:119-121 / cu:139-141: uint16 -> float (exact), optional >> 4; samples 4h..4h+3 of the chunk
 template <int INTYPE>
 OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 	if constexpr (INTYPE == IN_U16) {
 		const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
+#if OCT_SDWA_UNPACK
+		// one v_cvt_f32_u32 with a 16-bit source select per sample instead of mask / shift + convert
+		if (s == 0) return float4{cvt_u16_lo(a), cvt_u16_hi(a), cvt_u16_lo(b), cvt_u16_hi(b)};
+#else
 		if (s == 0) return float4{(float)(a & 0xffffu), (float)(a >> 16), (float)(b & 0xffffu), (float)(b >> 16)};
+#endif
 		return float4{(float)((a & 0xffffu) >> s), (float)((a >> 16) >> s), (float)((b & 0xffffu) >> s), (float)((b >> 16) >> s)};
 	} else {
 		// (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)

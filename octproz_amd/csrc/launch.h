@@ -2,10 +2,39 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "bluestein.h"
 #include "kernels.h"
 
 namespace oct {
+
+// Per-kernel, per-DEVICE launch facts (CU count, resident workgroups per CU) and the one-time opt-in to > 64 KiB of dynamic
+// LDS.  One process may drive several GPUs through several handles (octpipe_group_*), possibly from several threads: the
+// cache is indexed by the current device and guarded by a mutex (hipFuncSetAttribute is per device).
+struct KernelLaunchInfo { int numCU = 0, blocksPerCU = 0; bool ready = false; };
+template <typename K>
+hipError_t kernel_launch_info(K kernel, int threads, size_t ldsBytes, KernelLaunchInfo* out) {
+	constexpr int kMaxDevices = 64;
+	static std::mutex mtx;
+	static KernelLaunchInfo cache[kMaxDevices];
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+	std::lock_guard<std::mutex> lock(mtx);
+	KernelLaunchInfo& c = cache[dev];
+	if (!c.ready) {
+		if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)) != hipSuccess) return e;
+		if ((e = hipDeviceGetAttribute(&c.numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+		int occ = 0;
+		if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, ldsBytes)) != hipSuccess) return e;
+		c.blocksPerCU = occ > 0 ? occ : 1;
+		c.ready = true;
+	}
+	*out = c;
+	return hipSuccess;
+}
 
 #define OCT_DECL_LAUNCH(L)                                                                                                  \
 	hipError_t launch_fused_##L(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,              \

@@ -76,6 +76,7 @@ struct octpipe {
 	float4* d_segs = nullptr;
 	float* d_dispBscan = nullptr;
 	float* d_dispEnFace = nullptr;
+	uint8_t* d_volumeView = nullptr;  // [N/2][B*buffersPerVolume][A] uint8, lazily (cu:914-941 into a plain buffer)
 	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
 	f2* d_filter = nullptr;    // [M] Bluestein filter spectrum
 	f2* d_outChirp = nullptr;  // [N] c[k] / M
@@ -370,18 +371,63 @@ int minVarianceMean(octpipe* h, const f2* d_in, int width, int height, f2* d_mea
 	return OCTPIPE_OK;
 }
 
-int updateBscanDisplay(octpipe* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1267-1284
-	const unsigned depth = (unsigned)(h->B * (int)h->acq.buffersPerVolume);
-	const unsigned n = (unsigned)(h->N * h->A / 2);
-	frameNr = frameNr < depth ? frameNr : 0;
-	hipLaunchKernelGGL(oct::oct_display_bscan_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_dispBscan, h->d_processed, depth, n, frameNr, frames, fn);
+// display-frame extraction (cu:1223-1308): one launch for the B-scan frame (blocks first) and / or the en-face frame
+template <int MB, int VB, int ME>
+void launchDisplayT(const oct::DisplayArgs& d, unsigned enfaceBlocks, hipStream_t st) {
+	hipLaunchKernelGGL((oct::oct_display_frames_kernel<MB, VB, ME>), dim3(d.bscanBlocks + enfaceBlocks), dim3(256), 0, st, d);
+}
+template <int MB, int VB>
+void launchDisplayE(int me, const oct::DisplayArgs& d, unsigned eb, hipStream_t st) {
+	if (me == oct::DISP_AVG) launchDisplayT<MB, VB, oct::DISP_AVG>(d, eb, st);
+	else if (me == oct::DISP_MIP) launchDisplayT<MB, VB, oct::DISP_MIP>(d, eb, st);
+	else launchDisplayT<MB, VB, oct::DISP_SINGLE>(d, eb, st);
+}
+template <int VB>
+void launchDisplayB(int mb, int me, const oct::DisplayArgs& d, unsigned eb, hipStream_t st) {
+	if (mb == oct::DISP_AVG) launchDisplayE<oct::DISP_AVG, VB>(me, d, eb, st);
+	else if (mb == oct::DISP_MIP) launchDisplayE<oct::DISP_MIP, VB>(me, d, eb, st);
+	else launchDisplayE<oct::DISP_SINGLE, VB>(me, d, eb, st);
+}
+// bscan / enface: which frames to extract; a display function other than averaging / MIP with frames > 1 leaves the frame
+// untouched like the reference's switch (cu:826-846)
+int updateDisplay(octpipe* h, bool bscan, unsigned frameNrB, unsigned framesB, int fnB, bool enface, unsigned frameNrE, unsigned framesE, int fnE) {
+	oct::DisplayArgs d{};
+	d.dispBscan = h->d_dispBscan; d.dispEnFace = h->d_dispEnFace; d.vol = h->d_processed;
+	d.bscansPerVolume = (unsigned)h->B * h->acq.buffersPerVolume;
+	d.nBscan = (unsigned)(h->N * h->A / 2);
+	d.frameNrBscan = frameNrB < d.bscansPerVolume ? frameNrB : 0;   // cu:1269
+	d.framesBscan = framesB;
+	d.frameWidth = (unsigned)(h->N / 2);
+	d.nEnFace = d.bscansPerVolume * (unsigned)h->A;
+	d.frameNrEnFace = frameNrE < d.frameWidth ? frameNrE : 0;       // cu:1288
+	d.framesEnFace = framesE;
+	const int mb = oct::display_mode(framesB, fnB), me = oct::display_mode(framesE, fnE);
+	if (mb < 0) bscan = false;
+	if (me < 0) enface = false;
+	if (!bscan && !enface) return OCTPIPE_OK;
+	const int vec = (d.nBscan % 4 == 0) ? 4 : 1;
+	d.bscanBlocks = bscan ? (unsigned)((d.nBscan / vec + 255) / 256) : 0u;
+	const unsigned eb = enface ? (d.nEnFace + 255) / 256 : 0u;
+	if (vec == 4) launchDisplayB<4>(mb, me, d, eb, h->stream);
+	else launchDisplayB<1>(mb, me, d, eb, h->stream);
 	HIP_TRY(hipGetLastError());
 	return OCTPIPE_OK;
 }
-int updateEnFaceDisplay(octpipe* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1286-1308
-	const unsigned n = (unsigned)(h->B * (int)h->acq.buffersPerVolume * h->A);
-	frameNr = frameNr < (unsigned)(h->N / 2) ? frameNr : 0;
-	hipLaunchKernelGGL(oct::oct_display_enface_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_dispEnFace, h->d_processed, (unsigned)(h->N / 2), n, frameNr, frames, fn);
+
+// sinusoidal correction and / or background removal in one pass (in == out unless sinus)
+template <int VEC>
+void launchPostPassV(bool sinus, bool bg, const oct::PostPassArgs& a, int grid, hipStream_t st) {
+	if (sinus && bg) hipLaunchKernelGGL((oct::oct_postpass_kernel<VEC, true, true>), dim3(grid), dim3(256), 0, st, a);
+	else if (sinus) hipLaunchKernelGGL((oct::oct_postpass_kernel<VEC, true, false>), dim3(grid), dim3(256), 0, st, a);
+	else if (bg) hipLaunchKernelGGL((oct::oct_postpass_kernel<VEC, false, true>), dim3(grid), dim3(256), 0, st, a);
+}
+int launchPostPass(octpipe* h, bool sinus, bool bg, const float* in, float* out) {
+	oct::PostPassArgs a{};
+	a.in = in; a.out = out; a.curve = h->d_sinusCurve; a.bg = h->d_postBg;
+	a.weight = h->params.postProcessBackgroundWeight; a.offset = h->params.postProcessBackgroundOffset;
+	a.W = (unsigned)(h->N / 2); a.A = (unsigned)h->A; a.samples = h->S / 2;
+	if (a.W % 4 == 0) launchPostPassV<4>(sinus, bg, a, gridFor(a.samples / 4), h->stream);
+	else launchPostPassV<1>(sinus, bg, a, gridFor(a.samples), h->stream);
 	HIP_TRY(hipGetLastError());
 	return OCTPIPE_OK;
 }
@@ -414,47 +460,41 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	if (h->acq.buffersPerVolume > 1) h->bufferNumberInVolume = (h->bufferNumberInVolume + 1) % h->acq.buffersPerVolume;  // cu:1530-1532
 	float* d_curr = h->d_processed + (S / 2) * h->bufferNumberInVolume;                                                   // cu:1535
 
-	int rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_curr, true);
-	if (rc) return rc;
+	// with the sinusoidal correction on, the fused kernel writes a scratch slot and the post pass gathers from it into the
+	// volume (cu:1551-1554 copies the buffer device-to-device and runs a second pass instead)
+	float* d_fusedOut = d_curr;
+	int rc;
+	if (p.sinusoidalScanCorrection) {
+		if ((rc = ensure((void**)&h->d_sinusTmp, sizeof(float) * (S / 2)))) return rc;
+		d_fusedOut = h->d_sinusTmp;
+	}
+	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true))) return rc;
 
-	if (p.sinusoidalScanCorrection) {  // cu:1551-1554
-		rc = ensure((void**)&h->d_sinusTmp, sizeof(float) * (S / 2));
-		if (rc) return rc;
-		HIP_TRY(hipMemcpyAsync(h->d_sinusTmp, d_curr, sizeof(float) * (S / 2), hipMemcpyDeviceToDevice, h->stream));
-		hipLaunchKernelGGL(oct::oct_sinusoidal_kernel, dim3(gridFor(S / 2)), dim3(256), 0, h->stream, d_curr, h->d_sinusTmp, h->d_sinusCurve, N / 2, A, S / 2);
+	const bool sinus = p.sinusoidalScanCorrection != 0, bgRemoval = p.postProcessBackgroundRemoval != 0;
+	if (bgRemoval && p.postProcessBackgroundRecordingRequested) {  // cu:1557-1568: record from the corrected first B-scan, then remove
+		if (sinus && (rc = launchPostPass(h, true, false, d_fusedOut, d_curr))) return rc;
+		hipLaunchKernelGGL(oct::oct_get_postproc_background_kernel, dim3((N / 2 + 255) / 256), dim3(256), 0, h->stream, h->d_postBg, d_curr, N / 2, A);
 		HIP_TRY(hipGetLastError());
+		// the host shadow is filled in-stream before the callback fires (cu:652-656): the callback itself makes no HIP call
+		HIP_TRY(hipMemcpyAsync(h->h_postBg.data(), h->d_postBg, sizeof(float) * (N / 2), hipMemcpyDeviceToHost, h->stream));
+		if (h->onBackground) HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, nullptr, 0, 2}));
+		p.postProcessBackgroundRecordingRequested = 0;
+		if ((rc = launchPostPass(h, false, true, d_curr, d_curr))) return rc;
+	} else if (sinus || bgRemoval) {
+		if ((rc = launchPostPass(h, sinus, bgRemoval, d_fusedOut, d_curr))) return rc;
 	}
 
-	if (p.postProcessBackgroundRemoval) {  // cu:1557-1568
-		if (p.postProcessBackgroundRecordingRequested) {
-			hipLaunchKernelGGL(oct::oct_get_postproc_background_kernel, dim3((N / 2 + 255) / 256), dim3(256), 0, h->stream, h->d_postBg, d_curr, N / 2, A);
-			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipMemcpyAsync(h->h_postBg.data(), h->d_postBg, sizeof(float) * (N / 2), hipMemcpyDeviceToHost, h->stream));
-			if (h->onBackground) HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, nullptr, 0, 2}));
-			p.postProcessBackgroundRecordingRequested = 0;
-		}
-		hipLaunchKernelGGL(oct::oct_postproc_background_removal_kernel, dim3(gridFor(S / 2)), dim3(256), 0, h->stream, d_curr, h->d_postBg,
-		                   p.postProcessBackgroundWeight, p.postProcessBackgroundOffset, N / 2, S / 2);
-		HIP_TRY(hipGetLastError());
+	if (p.bscanViewEnabled || p.enFaceViewEnabled) {  // cu:1571-1578, both frames in one launch
+		if ((rc = updateDisplay(h, p.bscanViewEnabled != 0, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan,
+		                        p.enFaceViewEnabled != 0, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView))) return rc;
 	}
-
-	if (p.bscanViewEnabled && p.enFaceViewEnabled) {  // cu:1571-1578, both frames in one launch
-		oct::DisplayArgs d{};
-		d.dispBscan = h->d_dispBscan; d.dispEnFace = h->d_dispEnFace; d.vol = h->d_processed;
-		d.bscansPerVolume = (unsigned)B * h->acq.buffersPerVolume;
-		d.nBscan = (unsigned)(N * A / 2);
-		d.frameNrBscan = p.frameNr < d.bscansPerVolume ? p.frameNr : 0;
-		d.framesBscan = p.functionFramesBscan; d.fnBscan = p.displayFunctionBscan;
-		d.frameWidth = (unsigned)(N / 2);
-		d.nEnFace = d.bscansPerVolume * (unsigned)A;
-		d.frameNrEnFace = p.frameNrEnFaceView < d.frameWidth ? p.frameNrEnFaceView : 0;
-		d.framesEnFace = p.functionFramesEnFaceView; d.fnEnFace = p.displayFunctionEnFaceView;
-		d.bscanBlocks = (d.nBscan + 255) / 256;
-		hipLaunchKernelGGL(oct::oct_display_frames_kernel, dim3(d.bscanBlocks + (d.nEnFace + 255) / 256), dim3(256), 0, h->stream, d);
+	if (p.volumeViewEnabled) {  // cu:1579-1582
+		const unsigned W = (unsigned)(N / 2), BV = (unsigned)B * h->acq.buffersPerVolume;
+		if ((rc = ensure((void**)&h->d_volumeView, (size_t)W * BV * (size_t)A))) return rc;
+		const unsigned tilesY = ((unsigned)A + 63) / 64, tilesR = (W + 63) / 64;
+		hipLaunchKernelGGL(oct::oct_volume_to_u8_kernel, dim3((unsigned)B * tilesY * tilesR), dim3(256), 0, h->stream, h->d_volumeView, d_curr,
+		                   W, (unsigned)A, (unsigned)B, BV, h->bufferNumberInVolume, tilesY, tilesR);
 		HIP_TRY(hipGetLastError());
-	} else {
-		if (p.bscanViewEnabled) { rc = updateBscanDisplay(h, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan); if (rc) return rc; }              // cu:1571-1574
-		if (p.enFaceViewEnabled) { rc = updateEnFaceDisplay(h, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView); if (rc) return rc; }  // cu:1575-1578
 	}
 
 	if (p.streamFloatToHost && h->floatStreamingRegistered) {  // streamProcessedFloatData, cu:1374-1386
@@ -470,7 +510,10 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 			void* dst = h->streamingBufferNumber == 0 ? h->h_stream[0] : h->h_stream[1];
 			rc = ensure(&h->d_output, (S / 2) * (size_t)h->bytesPerSample);
 			if (rc) return rc;
-			hipLaunchKernelGGL(oct::oct_float_to_output_kernel, dim3(gridFor(S / 2)), dim3(256), 0, h->stream, h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
+			const int qgrid = gridFor((S / 2) * (size_t)h->bytesPerSample / 16);
+			if (h->bytesPerSample == 1) hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint8_t>, dim3(qgrid), dim3(256), 0, h->stream, (uint8_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
+			else if (h->bytesPerSample == 2) hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint16_t>, dim3(qgrid), dim3(256), 0, h->stream, (uint16_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
+			else hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint32_t>, dim3(qgrid), dim3(256), 0, h->stream, (uint32_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipMemcpyAsync(dst, h->d_output, (S / 2) * (size_t)h->bytesPerSample, hipMemcpyDeviceToHost, h->stream));
 			HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, dst, h->bufferNumberInVolume, 0}));
@@ -601,7 +644,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_filter, h->d_outChirp};
+	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp};
 	for (void* b : bufs) if (b) hipFree(b);
 	if (h->copyStream) hipStreamDestroy(h->copyStream);
 	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);
@@ -669,6 +712,12 @@ int octpipe_copy_postprocess_background_to_host(octpipe_t* h, float* background,
 	int rc = setDevice(h); if (rc) return rc;
 	HIP_TRY(hipMemcpyAsync(background, h->d_postBg, sizeof(float) * (size_t)size, hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	return OCTPIPE_OK;
+}
+
+int octpipe_get_postprocess_background_host(const octpipe_t* h, float* background, int size) {
+	if (!h || !background || size <= 0 || size > h->N / 2) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
+	std::memcpy(background, h->h_postBg.data(), sizeof(float) * (size_t)size);  // no HIP call: safe inside a callback
 	return OCTPIPE_OK;
 }
 
@@ -905,12 +954,12 @@ int octpipe_set_callbacks(octpipe_t* h, octpipe_data_callback onStreamingData, o
 int octpipe_change_displayed_bscan_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1223-1240
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	int rc = setDevice(h); if (rc) return rc;
-	return updateBscanDisplay(h, frameNr, frames, fn);
+	return updateDisplay(h, true, frameNr, frames, fn, false, 0, 1, 0);
 }
 int octpipe_change_displayed_enface_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1243-1265
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	int rc = setDevice(h); if (rc) return rc;
-	return updateEnFaceDisplay(h, frameNr, frames, fn);
+	return updateDisplay(h, false, 0, 1, 0, true, frameNr, frames, fn);
 }
 int octpipe_get_display_buffers(octpipe_t* h, void** d_bscanFrame, size_t* bscanCount, void** d_enFaceFrame, size_t* enFaceCount) {
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
@@ -918,6 +967,15 @@ int octpipe_get_display_buffers(octpipe_t* h, void** d_bscanFrame, size_t* bscan
 	if (bscanCount) *bscanCount = (size_t)h->N * h->A / 2;
 	if (d_enFaceFrame) *d_enFaceFrame = h->d_dispEnFace;
 	if (enFaceCount) *enFaceCount = (size_t)h->A * h->B * h->acq.buffersPerVolume;
+	return OCTPIPE_OK;
+}
+int octpipe_get_volume_view_buffer(octpipe_t* h, void** d_voxels, size_t* bytes) {
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	int rc = setDevice(h); if (rc) return rc;
+	const size_t n = (size_t)(h->N / 2) * (size_t)h->B * h->acq.buffersPerVolume * (size_t)h->A;
+	if ((rc = ensure((void**)&h->d_volumeView, n))) return rc;
+	if (d_voxels) *d_voxels = h->d_volumeView;
+	if (bytes) *bytes = n;
 	return OCTPIPE_OK;
 }
 int octpipe_register_gl_buffer_bscan(unsigned) { return fail(OCTPIPE_ERR_UNSUPPORTED, "no OpenGL interop on a headless MI355X node"); }

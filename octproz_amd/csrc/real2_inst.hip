@@ -8,14 +8,10 @@ namespace {
 template <int RS, int MODE>
 hipError_t launch_real2_one(const FusedArgs& a, hipStream_t stream) {
 	auto kernel = oct_real2_kernel<RS, MODE>;
-	static int numCU = 0;
-	if (numCU == 0) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, REAL2_LDS_BYTES);
-		if (e != hipSuccess) return e;
-		int dev = 0;
-		if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-		if ((e = hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-	}
+	KernelLaunchInfo info;
+	hipError_t e = kernel_launch_info(kernel, REAL2_WAVES * 64, REAL2_LDS_BYTES, &info);
+	if (e != hipSuccess) return e;
+	const int numCU = info.numCU;
 	const unsigned pairs = (a.numLines + 1u) / 2u;
 	const unsigned need = (pairs + REAL2_WAVES - 1) / REAL2_WAVES;
 	unsigned blocks = (unsigned)numCU;  // ~156 KiB of LDS: one persistent workgroup per CU

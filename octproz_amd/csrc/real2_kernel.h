@@ -42,8 +42,8 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 		if constexpr (RS == RS_CUBIC) {  // cu:258-271 as tap weights, see kernels.h
 			const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
 			cwL[i] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
-		} else if constexpr (RS == RS_LINEAR) {  // cu:225-228: f0 + (f1 - f0) p as weights of taps 1 and 2
-			cwL[i] = f32x4{0.0f, (float)(1.0 - p), (float)p, 0.0f};
+		} else if constexpr (RS == RS_LINEAR) {  // cu:225-228: the fraction p of f0 + (f1 - f0) p, evaluated in the reference's form below
+			cwL[i] = f32x4{(float)p, 0.0f, 0.0f, 0.0f};
 		}
 		const int q = i >> 6, l = i & 63;
 		reinterpret_cast<float*>(winL)[((q >> 2) * 64 + l) * 4 + (q & 3)] = t.y * t.z;  // phasor = (1, 0): the window alone
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 				if constexpr (RS == RS_CUBIC) {
 					y0 = __builtin_fmaf(cw.w, t0[3], __builtin_fmaf(cw.z, t0[2], __builtin_fmaf(cw.y, t0[1], cw.x * t0[0])));
 					y1 = __builtin_fmaf(cw.w, t1[3], __builtin_fmaf(cw.z, t1[2], __builtin_fmaf(cw.y, t1[1], cw.x * t1[0])));
-				} else {
-					y0 = __builtin_fmaf(cw.z, t0[2], cw.y * t0[1]);
-					y1 = __builtin_fmaf(cw.z, t1[2], cw.y * t1[1]);
+				} else {  // same expression as oct_fused_kernel (kernels.h RS_LINEAR): identical bits with dispersion compensation on or off
+					y0 = t0[1] + (t0[2] - t0[1]) * cw.x;
+					y1 = t1[1] + (t1[2] - t1[1]) * cw.x;
 				}
 			}
 			v[q] = f2{w * y0, w * y1};

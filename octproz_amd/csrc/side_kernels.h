@@ -1,4 +1,15 @@
-// side_kernels.h -- the non-fused kernels of the OCT path (included by octpipe_api.hip only).
+// side_kernels.h -- the kernels of the OCT path outside the fused A-scan kernel (included by octpipe_api.hip only).
+//
+// All of them are HBM-bound passes over (parts of) the processed volume; they are shaped for MI355X instead of following
+// the reference's one-thread-per-element kernels:
+//   * sinusoidal scan correction (cu:491-514) + post-process background removal (cu:757-767) are ONE out-of-place pass
+//     (oct_postpass_kernel): when the correction is on, the fused kernel writes into a scratch slot and this pass gathers
+//     from it into the volume -- the reference's device-to-device copy of the buffer (cu:1552) and its second pass vanish;
+//   * 16-byte vector accesses wherever the line length allows (N/2 % 4 == 0), scalar tail otherwise;
+//   * the quantiser (cu:943-967) writes 16 bytes per lane;
+//   * the 8-bit volume down-conversion (cu:914-941) is a 64 x 64 tiled transpose through LDS: the reference writes a 3-D
+//     texture whose fastest axis is the A-scan index while the volume's fastest axis is depth;
+//   * display-frame extraction (cu:810-912) is templated on the display function, B-scan frames move as float4.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,9 +18,11 @@
 
 namespace oct {
 
-// ------------------------------------------------------------------ side kernels
-// unpack (+ rolling average) to float32, only used in front of the Lanczos variant
-// format: OCTPIPE_FORMAT_* (0 = by bit depth as the reference; 1/2 packed 12 bit, 3/4/5 signed 8/16/32 bit)
+OCT_DEV float saturate01(float v) { return !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+// ------------------------------------------------------------------ input decode to float32 ("prepared" route)
+// unpack (+ rolling average) for uint8 / uint32 containers, the signed / packed formats and everything in front of the
+// Lanczos variant.  format: OCTPIPE_FORMAT_* (0 = by bit depth as the reference cu:109-147; 1/2 packed 12 bit, 3/4/5 signed)
 __global__ void oct_prepare_kernel(const void* raw, float* out, int bitDepth, int bitshift, int rollingW, int N, size_t S, int format) {
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < S; i += (size_t)gridDim.x * blockDim.x) {
 		auto get = [&](size_t idx) -> float {
@@ -42,8 +55,9 @@ __global__ void oct_prepare_kernel(const void* raw, float* out, int bitDepth, in
 	}
 }
 
-// cu:523-565, split in two so that 9*width threads share the serial walk; every sum keeps the
-// reference's order (one segment = one sequential float accumulation, strict '<' over segments).
+// ------------------------------------------------------------------ fixed-pattern-noise estimate (cu:523-565)
+// split in two so that 9*width threads share the serial walk; every sum keeps the reference's order (one segment = one
+// sequential float accumulation, strict '<' over segments).
 __global__ void oct_minvar_segments_kernel(const f2* in, int width, int segWidth, int segs, float4* segOut) {
 #pragma clang fp contract(off)
 	const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,18 +88,8 @@ __global__ void oct_minvar_select_kernel(const float4* seg, int width, int segs,
 	meanLine[k] = best;
 }
 
-// cu:491-514
-__global__ void oct_sinusoidal_kernel(float* out, const float* in, const float* curve, int width, int height, size_t samples) {
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + width < samples; i += (size_t)gridDim.x * blockDim.x) {
-		const size_t j = i % width, k = (i / width) % height, l = i / ((size_t)width * height);
-		const float x = curve[k];
-		const size_t x0 = (size_t)(int)x * width + j + l * (size_t)width * height;
-		const size_t x1 = x0 + width;
-		const float f0 = x0 < samples ? in[x0] : 0.0f, f1 = x1 < samples ? in[x1] : 0.0f;
-		out[i] = f0 + (f1 - f0) * (x - (float)(int)x);
-	}
-}
-// cu:516-521
+// ------------------------------------------------------------------ post pass: sinusoidal correction + background removal
+// s[k] = (A/pi) acos(1 - 2k/A), cu:516-521
 __global__ void oct_fill_sinus_curve_kernel(float* curve, int length) {
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k < length) {
@@ -93,7 +97,67 @@ __global__ void oct_fill_sinus_curve_kernel(float* curve, int length) {
 		curve[k] = (float)(((float)length / 3.14159265358979323846) * acosf(arg));
 	}
 }
-// cu:743-755
+
+struct PostPassArgs {
+	const float* in;     // SINUS: the scratch slot the fused kernel wrote; else == out (in place, elementwise)
+	float* out;          // the buffer's slot in the processed volume
+	const float* curve;  // [A] sinusoidal resampling positions
+	const float* bg;     // [W] recorded background line
+	float weight, offset;
+	unsigned W, A;       // samples per processed A-scan (N/2), A-scans per B-scan
+	size_t samples;      // S/2
+};
+
+// One lane produces VEC consecutive depth samples of one output A-scan.  SINUS (cu:491-514): out[b][a][r] = f0 + (f1 - f0) frac
+// with f0, f1 from rows floor(s[a]), floor(s[a]) + 1 of the SAME B-scan start (row A aliases the first row of the next
+// B-scan, reads past the buffer are 0) and the last A-scan of the buffer passes through unchanged (the reference's launch
+// bound `i + width < samples`).  BG (cu:757-767): saturate(v - (weight bg[r] + offset)), contraction off like the oracle.
+template <int VEC, bool SINUS, bool BG>
+__global__ __launch_bounds__(256) void oct_postpass_kernel(const PostPassArgs a) {
+#pragma clang fp contract(off)
+	typedef float vec_t __attribute__((ext_vector_type(VEC)));
+	const size_t units = a.samples / VEC;
+	const unsigned upl = a.W / VEC;  // units per line
+	for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+		const size_t line = u / upl;
+		const unsigned r = (unsigned)(u - line * upl) * VEC;
+		const size_t i = line * a.W + r;
+		vec_t v;
+		if constexpr (SINUS) {
+			if (i + a.W < a.samples) {
+				const size_t b = line / a.A;
+				const unsigned k = (unsigned)(line - b * a.A);
+				const float x = a.curve[k];
+				const int row = (int)x;
+				const float frac = x - (float)row;
+				const size_t x0 = (b * a.A + (size_t)row) * a.W + r, x1 = x0 + a.W;
+				vec_t f0, f1;
+				if (x0 + VEC <= a.samples) f0 = *reinterpret_cast<const vec_t*>(a.in + x0); else f0 = vec_t(0.0f);
+				if (x1 + VEC <= a.samples) f1 = *reinterpret_cast<const vec_t*>(a.in + x1); else f1 = vec_t(0.0f);
+				v = f0 + (f1 - f0) * frac;
+			} else {
+				v = *reinterpret_cast<const vec_t*>(a.in + i);
+			}
+		} else {
+			v = *reinterpret_cast<const vec_t*>(a.in + i);
+		}
+		if constexpr (BG) {
+			const vec_t g = *reinterpret_cast<const vec_t*>(a.bg + r);
+			vec_t o;
+			if constexpr (VEC == 1) {
+				o = vec_t(saturate01(v[0] - (a.weight * g[0] + a.offset)));
+			} else {
+#pragma unroll
+				for (int c = 0; c < VEC; c++) o[c] = saturate01(v[c] - (a.weight * g[c] + a.offset));
+			}
+			v = o;
+		}
+		*reinterpret_cast<vec_t*>(a.out + i) = v;
+	}
+}
+
+// mean over the A-scans of the first B-scan, cu:743-755: one thread per depth sample walks the A rows (coalesced across
+// the wave), sequential float sum in the reference's order
 __global__ void oct_get_postproc_background_kernel(float* bg, const float* in, int spa, int ascans) {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r < spa) {
@@ -102,80 +166,165 @@ __global__ void oct_get_postproc_background_kernel(float* bg, const float* in, i
 		bg[r] = __fdiv_rn(sum, (float)ascans);
 	}
 }
-OCT_DEV float saturate01(float v) { return !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v); }
-// cu:757-767
-__global__ void oct_postproc_background_removal_kernel(float* data, const float* bg, float w, float o, int spa, size_t samples) {
-#pragma clang fp contract(off)
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < samples; i += (size_t)gridDim.x * blockDim.x)
-		data[i] = saturate01(data[i] - (w * bg[i % spa] + o));
-}
-// cu:943-967
-__global__ void oct_float_to_output_kernel(void* out, const float* in, int bitDepth, size_t samples) {
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < samples; i += (size_t)gridDim.x * blockDim.x) {
-		const float s = saturate01(in[i]);
-		if (bitDepth <= 8) reinterpret_cast<uint8_t*>(out)[i] = (uint8_t)((double)s * 255.0);
-		else if (bitDepth <= 10) reinterpret_cast<uint16_t*>(out)[i] = (uint16_t)((double)s * 1023.0);
-		else if (bitDepth <= 12) reinterpret_cast<uint16_t*>(out)[i] = (uint16_t)((double)s * 4095.0);
-		else if (bitDepth <= 16) reinterpret_cast<uint16_t*>(out)[i] = (uint16_t)((double)s * 65535.0);
-		else if (bitDepth <= 24) reinterpret_cast<uint32_t*>(out)[i] = (uint32_t)(s * 16777215.0f);
-		else { const float v = s * 4294967295.0f; reinterpret_cast<uint32_t*>(out)[i] = v >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)v; }
+
+// ------------------------------------------------------------------ quantiser (cu:943-967)
+// (T)(saturate(v) * M), M = 2^bits - 1, truncation; the product in double up to 16 bit like the reference's `* (255.0)`.
+// One lane converts 16 / sizeof(T) values and stores 16 bytes.
+template <typename T> struct QuantTraits;
+template <> struct QuantTraits<uint8_t> { static constexpr int PER = 16; };
+template <> struct QuantTraits<uint16_t> { static constexpr int PER = 8; };
+template <> struct QuantTraits<uint32_t> { static constexpr int PER = 4; };
+
+template <typename T>
+OCT_DEV T quantise_one(float x, int bitDepth) {
+	const float s = saturate01(x);
+	if constexpr (sizeof(T) == 1) return (T)((double)s * 255.0);
+	else if constexpr (sizeof(T) == 2) return (T)((double)s * (bitDepth <= 10 ? 1023.0 : bitDepth <= 12 ? 4095.0 : 65535.0));
+	else {
+		if (bitDepth <= 24) return (T)(s * 16777215.0f);
+		const float v = s * 4294967295.0f;
+		return v >= 4294967296.0f ? 0xFFFFFFFFu : (T)v;
 	}
 }
-// cu:810-860
-__device__ __forceinline__ void display_bscan_element(unsigned i, float* disp, const float* vol, unsigned bscansPerVolume, unsigned n, unsigned frameNr, unsigned frames, int fn) {
-	if (frames > 1) {
-		if (fn == 0) {
-			int cnt = 0; float sum = 0;
-			for (unsigned j = 0; j < frames; j++) { const unsigned f = frameNr + j; if (f < bscansPerVolume) { sum += vol[(size_t)f * n + (n - 1) - i]; cnt++; } }
-			disp[i] = __fdiv_rn(sum, (float)cnt);
-		} else if (fn == 1) {
-			float mx = 0;
-			for (unsigned j = 0; j < frames; j++) { const unsigned f = frameNr + j; if (f < bscansPerVolume) { const float c = vol[(size_t)f * n + (n - 1) - i]; if (mx < c) mx = c; } }
-			disp[i] = mx;
+
+template <typename T>
+__global__ __launch_bounds__(256) void oct_float_to_output_kernel(T* out, const float* in, int bitDepth, size_t samples) {
+	constexpr int PER = QuantTraits<T>::PER;
+	typedef T out_vec __attribute__((ext_vector_type(PER)));
+	const size_t units = samples / PER;
+	for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+		const float4* src = reinterpret_cast<const float4*>(in + u * PER);
+		out_vec o;
+#pragma unroll
+		for (int q = 0; q < PER / 4; q++) {
+			const float4 f = src[q];
+			o[4 * q + 0] = quantise_one<T>(f.x, bitDepth);
+			o[4 * q + 1] = quantise_one<T>(f.y, bitDepth);
+			o[4 * q + 2] = quantise_one<T>(f.z, bitDepth);
+			o[4 * q + 3] = quantise_one<T>(f.w, bitDepth);
 		}
-	} else {
-		disp[i] = vol[(size_t)frameNr * n + (n - 1) - i];
+		*reinterpret_cast<out_vec*>(out + u * PER) = o;
+	}
+	// tail (samples % PER values): first lanes of block 0
+	if (blockIdx.x == 0) {
+		const size_t i = units * PER + threadIdx.x;
+		if (i < samples) out[i] = quantise_one<T>(in[i], bitDepth);
 	}
 }
-__global__ void oct_display_bscan_kernel(float* disp, const float* vol, unsigned bscansPerVolume, unsigned n, unsigned frameNr, unsigned frames, int fn) {
-	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) display_bscan_element(i, disp, vol, bscansPerVolume, n, frameNr, frames, fn);
-}
-// cu:862-912
-__device__ __forceinline__ void display_enface_element(unsigned i, float* disp, const float* vol, unsigned frameWidth, unsigned n, unsigned frameNr, unsigned frames, int fn) {
-	if (frames > 1) {
-		if (fn == 0) {
-			int cnt = 0; float sum = 0;
-			for (unsigned j = 0; j < frames; j++) { const unsigned f = frameNr + j; if (f < frameWidth) { sum += vol[f + (size_t)i * frameWidth]; cnt++; } }
-			disp[(n - 1) - i] = __fdiv_rn(sum, (float)cnt);
-		} else if (fn == 1) {
-			float mx = 0;
-			for (unsigned j = 0; j < frames; j++) { const unsigned f = frameNr + j; if (f < frameWidth) { const float c = vol[f + (size_t)i * frameWidth]; if (mx < c) mx = c; } }
-			disp[(n - 1) - i] = mx;
+
+// ------------------------------------------------------------------ 8-bit volume view (cu:914-941)
+// in:  one processed buffer [B][A][W] float32 (W fastest).   out: voxels [W][BV][A] uint8, voxel (z, x, y) =
+// in[b][y][W-1-z] with x = b + bufferNr * B (the texel surf3Dwrite(v, y, x, z) addresses).  A workgroup transposes one
+// 64 (A-scans) x 64 (depth) tile of one B-scan through LDS: 256 B coalesced reads along depth, 16-byte stores along y.
+__global__ __launch_bounds__(256) void oct_volume_to_u8_kernel(uint8_t* out, const float* in, unsigned W, unsigned A, unsigned B, unsigned BV,
+                                                               unsigned bufferNr, unsigned tilesY, unsigned tilesR) {
+	__shared__ uint32_t tile[64 * 17];  // [r][y / 4], pitch 17 words: conflict-free for lanes that vary r
+	const unsigned t = threadIdx.x;
+	unsigned id = blockIdx.x;
+	const unsigned tr = id % tilesR; id /= tilesR;
+	const unsigned ty = id % tilesY; id /= tilesY;
+	const unsigned b = id;
+	const unsigned r = tr * 64 + (t & 63), yq = t >> 6;  // this thread: depth r, A-scans 16 yq .. 16 yq + 15 in groups of 4
+	const float* src = in + (size_t)b * A * W;
+#pragma unroll
+	for (int g = 0; g < 4; g++) {
+		uint32_t word = 0;
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			const unsigned y = ty * 64 + 16 * yq + 4 * g + c;
+			float v = 0.0f;
+			if (y < A && r < W) v = src[(size_t)y * W + r];
+			const float s = saturate01(v);
+			word |= (uint32_t)(uint8_t)((double)s * 255.0) << (8 * c);
 		}
-	} else {
-		disp[(n - 1) - i] = vol[frameNr + (size_t)i * frameWidth];
+		tile[(t & 63) * 17 + 4 * yq + g] = word;
+	}
+	__syncthreads();
+	// thread -> depth row rr = t / 4 of the tile, 16 A-scans starting at 16 (t % 4)
+	const unsigned rr = t >> 2, yo = (t & 3) * 16;
+	const unsigned rg = tr * 64 + rr;
+	if (rg < W) {
+		const unsigned z = W - 1 - rg;
+		const unsigned x = b + bufferNr * B;
+		uint8_t* dst = out + ((size_t)z * BV + x) * A + ty * 64 + yo;
+		const uint32_t* trow = tile + rr * 17 + (t & 3) * 4;
+		const unsigned y0 = ty * 64 + yo;
+		if (y0 + 16 <= A && (((uintptr_t)dst) & 15) == 0) {
+			*reinterpret_cast<uint4*>(dst) = uint4{trow[0], trow[1], trow[2], trow[3]};
+		} else {
+			for (unsigned c = 0; c < 16 && y0 + c < A; c++) dst[c] = (uint8_t)(trow[c >> 2] >> (8 * (c & 3)));
+		}
 	}
 }
-__global__ void oct_display_enface_kernel(float* disp, const float* vol, unsigned frameWidth, unsigned n, unsigned frameNr, unsigned frames, int fn) {
-	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) display_enface_element(i, disp, vol, frameWidth, n, frameNr, frames, fn);
+
+// ------------------------------------------------------------------ display frames (cu:810-912)
+// fn: 0 = average over `frames` consecutive frames that exist, 1 = maximum intensity projection (starting from 0 like the
+// reference), frames <= 1 = the frame itself.
+enum { DISP_SINGLE = 0, DISP_AVG = 1, DISP_MIP = 2 };
+inline int display_mode(unsigned frames, int fn) { return frames > 1 ? (fn == 0 ? DISP_AVG : fn == 1 ? DISP_MIP : -1) : DISP_SINGLE; }
+
+// B-scan frame: disp[i] = f_j vol[(frameNr + j) n + (n - 1) - i]: the frame reversed end to end.  VEC = 4: a lane loads
+// one float4 per frame and writes it component-reversed.
+template <int MODE, int VEC>
+OCT_DEV void display_bscan_unit(size_t u, float* disp, const float* vol, unsigned bscansPerVolume, unsigned n, unsigned frameNr, unsigned frames) {
+	typedef float vec_t __attribute__((ext_vector_type(VEC)));
+	const size_t i = u * VEC;                 // first output element
+	const size_t s = (size_t)n - VEC - i;     // first source element of the reversed group
+	vec_t acc = vec_t(0.0f);
+	int cnt = 0;
+	const unsigned nf = MODE == DISP_SINGLE ? 1u : frames;
+	for (unsigned j = 0; j < nf; j++) {
+		const unsigned f = frameNr + j;
+		if (MODE != DISP_SINGLE && f >= bscansPerVolume) break;
+		const vec_t c = *reinterpret_cast<const vec_t*>(vol + (size_t)f * n + s);
+		if constexpr (MODE == DISP_AVG) { acc += c; cnt++; }
+		else if constexpr (MODE == DISP_MIP) {
+#pragma unroll
+			for (int k = 0; k < VEC; k++) if (acc[k] < c[k]) acc[k] = c[k];
+		} else acc = c;
+	}
+	vec_t o;
+#pragma unroll
+	for (int k = 0; k < VEC; k++) {
+		const float x = acc[VEC - 1 - k];
+		o[k] = MODE == DISP_AVG ? __fdiv_rn(x, (float)cnt) : x;
+	}
+	*reinterpret_cast<vec_t*>(disp + i) = o;
 }
-// both display frames of a buffer in one launch (the two extractions are launch-latency bound):
-// blocks [0, bscanBlocks) take the B-scan frame, the rest the en-face frame
+// en-face frame: disp[(n - 1) - i] = f_j vol[frameNr + j + i W]: one depth plane, a strided gather by nature
+template <int MODE>
+OCT_DEV void display_enface_unit(unsigned i, float* disp, const float* vol, unsigned frameWidth, unsigned n, unsigned frameNr, unsigned frames) {
+	const float* p = vol + (size_t)i * frameWidth;
+	float acc = 0.0f;
+	int cnt = 0;
+	const unsigned nf = MODE == DISP_SINGLE ? 1u : frames;
+	for (unsigned j = 0; j < nf; j++) {
+		const unsigned f = frameNr + j;
+		if (MODE != DISP_SINGLE && f >= frameWidth) break;
+		const float c = p[f];
+		if constexpr (MODE == DISP_AVG) { acc += c; cnt++; }
+		else if constexpr (MODE == DISP_MIP) { if (acc < c) acc = c; }
+		else acc = c;
+	}
+	disp[(n - 1) - i] = MODE == DISP_AVG ? __fdiv_rn(acc, (float)cnt) : acc;
+}
+
+// both display frames of a buffer in one launch (each is launch-latency bound on its own): blocks [0, bscanBlocks) take
+// the B-scan frame, the rest the en-face frame; either part may be empty
 struct DisplayArgs {
 	float* dispBscan; float* dispEnFace; const float* vol;
-	unsigned bscansPerVolume, nBscan, frameNrBscan, framesBscan; int fnBscan;
-	unsigned frameWidth, nEnFace, frameNrEnFace, framesEnFace; int fnEnFace;
+	unsigned bscansPerVolume, nBscan, frameNrBscan, framesBscan;
+	unsigned frameWidth, nEnFace, frameNrEnFace, framesEnFace;
 	unsigned bscanBlocks;
 };
-__global__ void oct_display_frames_kernel(const DisplayArgs a) {
+template <int MODE_B, int VEC_B, int MODE_E>
+__global__ __launch_bounds__(256) void oct_display_frames_kernel(const DisplayArgs a) {
 	if (blockIdx.x < a.bscanBlocks) {
-		const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-		if (i < a.nBscan) display_bscan_element(i, a.dispBscan, a.vol, a.bscansPerVolume, a.nBscan, a.frameNrBscan, a.framesBscan, a.fnBscan);
+		const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (u * VEC_B < a.nBscan) display_bscan_unit<MODE_B, VEC_B>(u, a.dispBscan, a.vol, a.bscansPerVolume, a.nBscan, a.frameNrBscan, a.framesBscan);
 	} else {
 		const unsigned i = (blockIdx.x - a.bscanBlocks) * blockDim.x + threadIdx.x;
-		if (i < a.nEnFace) display_enface_element(i, a.dispEnFace, a.vol, a.frameWidth, a.nEnFace, a.frameNrEnFace, a.framesEnFace, a.fnEnFace);
+		if (i < a.nEnFace) display_enface_unit<MODE_E>(i, a.dispEnFace, a.vol, a.frameWidth, a.nEnFace, a.frameNrEnFace, a.framesEnFace);
 	}
 }
 

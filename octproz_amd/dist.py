@@ -8,6 +8,13 @@ mean line, post-processing background: ~26 KB at N = 1024) whenever rank 0 (re)d
 The reference has no counterpart (single GPU, README.md:27); the invariant tested is
 "sharded output == unsharded output, bit for bit, with the calibration shared".
 
+The invariant holds for the per-A-scan chain (everything the benchmark settings use).  Three optional stages read across
+A-scan or B-scan borders and therefore differ at slab edges (documented restriction; give slabs a one-B-scan halo or keep
+these stages off in sharded mode): sinusoidal scan correction blends row A of a B-scan with row 0 of the NEXT B-scan and
+leaves the last A-scan of a buffer untouched (cu:506-510); Lanczos taps reach 8 samples across line and buffer borders
+(cu:313-321); and `bscansForNoiseDetermination` larger than a slab is clamped to the slab.  `check_sharding_exact(params)`
+reports these cases.
+
 Slab rule: slab sizes are even (except possibly the last) so that the buffer-local "every even
 B-scan is flipped" rule of the reference (cuda_code.cu:795) keeps its parity in every slab.
 """
@@ -32,7 +39,21 @@ def slab_bounds(total_bscans, world_size):
 
 
 def slab_for_rank(total_bscans, world_size, rank):
+    """(first, count) of this rank; count may be 0 when there are fewer B-scan pairs than ranks (e.g. 2 B-scans on 4 ranks):
+    such a rank must skip pipeline creation (octpipe_create rejects bscansPerBuffer == 0) and only join the collectives."""
     return slab_bounds(total_bscans, world_size)[rank]
+
+
+def check_sharding_exact(params, slab_bscans=None):
+    """Reasons why sharded != unsharded at slab edges for these settings (empty list: bit-exact)."""
+    why = []
+    if getattr(params, "sinusoidalScanCorrection", 0):
+        why.append("sinusoidal scan correction reads the first A-scan of the next B-scan and skips the last A-scan of a buffer (cu:506-510)")
+    if getattr(params, "resampling", 0) and int(getattr(params, "resamplingInterpolation", 0)) == 2:
+        why.append("Lanczos taps cross line and buffer borders (cu:313-321)")
+    if slab_bscans is not None and getattr(params, "fixedPatternNoiseRemoval", 0) and int(getattr(params, "bscansForNoiseDetermination", 1)) > slab_bscans:
+        why.append("bscansForNoiseDetermination exceeds the slab: the estimate is clamped to the slab")
+    return why
 
 
 def pack_calibration(n, resample, dispersion, window, mean_line, post_bg, fpn_determined=True):

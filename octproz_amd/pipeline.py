@@ -203,6 +203,18 @@ class Pipeline:
         check(self._lib.octpipe_get_display_buffers(self._h, C.byref(pb), C.byref(nb), C.byref(pe), C.byref(ne)))
         return (pb.value, nb.value), (pe.value, ne.value)
 
+    def volume_view_buffer(self):
+        """(device pointer, bytes) of the uint8 volume view [N/2][B*buffersPerVolume][A] (cu:914-941 into a plain buffer)"""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        check(self._lib.octpipe_get_volume_view_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def postprocess_background_host(self):
+        """the host shadow filled in-stream before the backgroundRecorded callback (no HIP call: callable from it)"""
+        out = np.empty(self.N // 2, dtype=np.float32)
+        check(self._lib.octpipe_get_postprocess_background_host(self._h, out.ctypes.data, self.N // 2))
+        return out
+
     def enable_kernel_timing(self, on=True):
         check(self._lib.octpipe_enable_kernel_timing(self._h, 1 if on else 0))
 

@@ -166,3 +166,59 @@ class VirtualOCTSystem:
         stats = HostStats()
         check(self._lib.octhost_processing_run_pipeline(self._s, pipeline.handle, int(max_buffers), float(max_seconds), C.byref(stats)))
         return stats
+
+
+class Recorder:
+    """Recorder (src/recorder.cpp) over octhost_recorder_*: K buffers -> <savePath>/<timestamp>[_<fileName>]_<name>.raw"""
+
+    def __init__(self, name):
+        self._lib = _lib.lib()
+        self._r = C.c_void_p(self._lib.octhost_recorder_create(name.encode()))
+
+    @staticmethod
+    def timestamp():
+        buf = C.create_string_buffer(32)
+        check(_lib.lib().octhost_timestamp(buf, 32))
+        return buf.value.decode()
+
+    def slot_init(self, save_path, buffer_size_in_bytes, buffers_to_record, timestamp=None, file_name="", start_with_first_buffer=False):
+        ts = timestamp if timestamp is not None else self.timestamp()
+        self._keep = (save_path.encode(), ts.encode(), file_name.encode())
+        p = _lib.RecordingParams(self._keep[0], self._keep[1], self._keep[2], int(buffer_size_in_bytes), int(buffers_to_record),
+                                 1 if start_with_first_buffer else 0)
+        rc = self._lib.octhost_recorder_init(self._r, C.byref(p))
+        if rc:
+            raise _lib.OctPipeError(rc, self._lib.octhost_recorder_error(self._r).decode())
+
+    def slot_record(self, buffer, current_buffer_nr=0):
+        a = np.ascontiguousarray(buffer)
+        rc = self._lib.octhost_recorder_record(self._r, a.ctypes.data, int(current_buffer_nr))
+        if rc:
+            raise _lib.OctPipeError(rc, self._lib.octhost_recorder_error(self._r).decode())
+
+    def slot_record_ptr(self, ptr, current_buffer_nr=0):
+        return self._lib.octhost_recorder_record(self._r, C.c_void_p(ptr), int(current_buffer_nr))
+
+    def slot_abortRecording(self):
+        check(self._lib.octhost_recorder_abort(self._r))
+
+    @property
+    def state(self):
+        en, fin, n, w = C.c_int(), C.c_int(), C.c_uint(), C.c_uint64()
+        self._lib.octhost_recorder_state(self._r, C.byref(en), C.byref(fin), C.byref(n), C.byref(w))
+        return {"recordingEnabled": bool(en.value), "finished": bool(fin.value), "recordedBuffers": n.value, "bytesWritten": w.value}
+
+    @property
+    def path(self):
+        return self._lib.octhost_recorder_path(self._r).decode()
+
+    def close(self):
+        if self._r:
+            self._lib.octhost_recorder_destroy(self._r)
+            self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

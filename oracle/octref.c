@@ -515,6 +515,23 @@ void octref_float_to_output(const float* in, void* out, int bitDepth, size_t sam
 	}
 }
 
+/* cu:914-941 (updateDisplayedVolume) with the 3-D texture replaced by a plain buffer: the kernel is launched with
+ * textureDim = (x: A-scans per B-scan, y: B-scans per volume, z: samples per processed A-scan) (cu:1334, 1346) and writes
+ * texel (y_tex = A-scan, x_tex = B-scan in the volume, z_tex = depth reversed) = surf3Dwrite(voxel, surface, y, x, z); with
+ * the texture's x axis fastest that is out[(z * bscansPerVolume + x) * ascans + y].  voxel = (unsigned char)(v * 255.0):
+ * defined for v in [0, 1]; outside, the C cast is undefined and the oracle clamps (so does the product). */
+void octref_volume_to_u8(const float* in, unsigned char* out, unsigned samplesInBuffer, unsigned currBufferNr,
+                         unsigned bscansPerBuffer, unsigned ascans, unsigned bscansPerVolume, unsigned depth) {
+	for (unsigned i = 0; i < samplesInBuffer; i++) {
+		unsigned samplesPerFrame = ascans * depth;
+		unsigned y = (i / depth) % ascans;
+		unsigned z = (depth - 1) - (i % depth);
+		unsigned x = i / samplesPerFrame + currBufferNr * bscansPerBuffer;
+		float s = saturatef(in[i]);
+		out[((size_t)z * bscansPerVolume + x) * ascans + y] = (unsigned char)(s * (255.0));
+	}
+}
+
 /* cu:810-860: B-scan frame (reversed sample order), optional averaging / MIP over frames */
 void octref_display_bscan(const float* vol, float* disp, unsigned bscansPerVolume, unsigned n,
                           unsigned frameNr, unsigned frames, int fn) {

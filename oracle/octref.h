@@ -119,6 +119,8 @@ void octref_sinusoidal(const float* in, float* out, const float* curve, int widt
 void octref_get_postproc_background(const float* in, float* bg, int samplesPerAscan, int ascansPerBuffer);
 void octref_postproc_background_removal(float* io, const float* bg, float weight, float offset, int samplesPerAscan, size_t samples);
 void octref_float_to_output(const float* in, void* out, int bitDepth, size_t samples);
+void octref_volume_to_u8(const float* in, unsigned char* out, unsigned samplesInBuffer, unsigned currBufferNr,
+                         unsigned bscansPerBuffer, unsigned ascans, unsigned bscansPerVolume, unsigned depth);
 void octref_display_bscan(const float* vol, float* disp, unsigned bscansPerVolume, unsigned samplesInFrame,
                           unsigned frameNr, unsigned frames, int fn);
 void octref_display_enface(const float* vol, float* disp, unsigned frameWidth, unsigned samplesInFrame,

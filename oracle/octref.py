@@ -197,11 +197,37 @@ def sinusoidal(v, width, height, depth):
     return out
 
 
+def get_postproc_background(v, samples_per_ascan, ascans):
+    """cu:743-755: mean over the A-scans of the first B-scan, per depth sample"""
+    v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
+    out = _f32(samples_per_ascan)
+    lib().octref_get_postproc_background(_fp(v), _fp(out), C.c_int(samples_per_ascan), C.c_int(ascans))
+    return out
+
+
+def postproc_background_removal(v, bg, weight, offset, samples_per_ascan):
+    """cu:757-767: saturate(v - (weight * bg[r] + offset))"""
+    out = np.array(v, dtype=np.float32, copy=True).reshape(-1)
+    bg = np.ascontiguousarray(bg, dtype=np.float32)
+    lib().octref_postproc_background_removal(_fp(out), _fp(bg), C.c_float(weight), C.c_float(offset), C.c_int(samples_per_ascan),
+                                             C.c_size_t(out.size))
+    return out
+
+
 def float_to_output(v, bit_depth):
     v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
     dt = np.uint8 if bit_depth <= 8 else (np.uint16 if bit_depth <= 16 else np.uint32)
     out = np.empty(v.size, dtype=dt)
     lib().octref_float_to_output(_fp(v), _fp(out), C.c_int(bit_depth), C.c_size_t(v.size))
+    return out
+
+
+def volume_to_u8(buf, out, curr_buffer_nr, bscans_per_buffer, ascans, bscans_per_volume, depth):
+    """cu:914-941 into the plain voxel buffer `out` (uint8 [depth][bscans_per_volume][ascans], updated in place)"""
+    buf = np.ascontiguousarray(buf, dtype=np.float32).reshape(-1)
+    assert out.dtype == np.uint8 and out.size == depth * bscans_per_volume * ascans and out.flags.c_contiguous
+    lib().octref_volume_to_u8(_fp(buf), _fp(out), C.c_uint(buf.size), C.c_uint(curr_buffer_nr), C.c_uint(bscans_per_buffer),
+                              C.c_uint(ascans), C.c_uint(bscans_per_volume), C.c_uint(depth))
     return out
 
 

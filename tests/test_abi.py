@@ -21,7 +21,7 @@ def declared(header, prefix):
 
 def test_library_loads_and_reports_abi_version():
     L = _lib.lib()
-    assert L.octpipe_abi_version() == 1
+    assert L.octpipe_abi_version() == 2
 
 
 @pytest.mark.parametrize("header,prefix,listed", [("octpipe.h", "octpipe", _lib.OCTPIPE_SYMBOLS),
@@ -37,9 +37,12 @@ def test_every_declared_symbol_is_exported(header, prefix, listed):
 
 
 def test_struct_layouts_match_header_sizes():
-    # 33 x 4-byte fields, no padding; 5 x uint32
-    assert C.sizeof(_lib.PipeParams) == 33 * 4
+    # 34 x 4-byte fields, no padding; 5 x uint32 -- and what the library itself was compiled with
+    assert C.sizeof(_lib.PipeParams) == 34 * 4
     assert C.sizeof(_lib.AcquisitionParams) == 5 * 4
+    sp, sa = C.c_size_t(), C.c_size_t()
+    _lib.lib().octpipe_struct_sizes(C.byref(sp), C.byref(sa))
+    assert (sp.value, sa.value) == (34 * 4, 5 * 4)
 
 
 def test_gl_interop_entry_points_always_fail():

@@ -98,3 +98,13 @@ def test_two_ranks_sharded_equals_unsharded(tmp_path):
     got = np.concatenate([np.load(os.path.join(tmp_path, "slab%d.npy" % r)) for r in range(2)])
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     o.close()
+
+
+def test_sharding_restrictions_are_reported_and_empty_slabs_possible():
+    p = v180_benchmark_params(512, 8, 4)
+    assert odist.check_sharding_exact(p, slab_bscans=2) == []
+    p.sinusoidalScanCorrection = 1
+    p.resamplingInterpolation = 2
+    p.bscansForNoiseDetermination = 3
+    assert len(odist.check_sharding_exact(p, slab_bscans=2)) == 3
+    assert odist.slab_bounds(2, 4) == [(0, 2), (2, 0), (2, 0), (2, 0)]  # ranks 1..3 own nothing and must skip octpipe_create

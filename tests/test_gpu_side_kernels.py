@@ -1,0 +1,165 @@
+"""The passes outside the fused kernel (csrc/side_kernels.h) against the oracle's restatements of cu:491-521, 743-767,
+810-967, given the SAME float volume: these stages are elementwise / index maps on float32 data, so the bar is bit-exact.
+Sizes are chosen to hit the vector paths (N/2 % 4 == 0), the scalar paths (Bluestein lengths with odd N/2) and the tails."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import common
+from oracle import octref
+from octproz_amd import Pipeline, synthetic_raw, v180_benchmark_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(raw):
+    import torch
+    a = np.ascontiguousarray(raw)
+    return torch.from_numpy(a.view(np.int16)).to("cuda:0")
+
+
+def _fetch(ptr, n, dtype):
+    out = np.empty(n, dtype=dtype)
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(out.nbytes), 2) == 0
+    return out
+
+
+def _grey(p):
+    """grey-scale window that puts the synthetic image inside [0, 1] so that clamps / quantisers see real values"""
+    p.signalGrayscaleMax, p.signalGrayscaleMin = 110.0, 20.0
+
+
+@pytest.mark.parametrize("N,A,B", [(1024, 24, 3), (256, 5, 2), (300, 7, 2), (2046, 3, 2), (512, 130, 1)])
+@pytest.mark.parametrize("sinus,bg", [(1, 0), (0, 1), (1, 1)])
+def test_post_pass_sinusoidal_and_background_bit_exact(N, A, B, sinus, bg):
+    p = v180_benchmark_params(N, A, B)
+    _grey(p)
+    p.fixedPatternNoiseRemoval = 0
+    raw = synthetic_raw(N, A, B, seed=N + A)
+    d = _dev(raw)
+    plain = Pipeline(p, device=0)
+    plain.process_device(d.data_ptr()); plain.synchronize()
+    img = plain.processed_host()  # the fused kernel's output: the post pass' input
+    plain.close()
+    W = N // 2
+    rng = np.random.default_rng(1)
+    bgline = (rng.random(W) * 0.2).astype(np.float32)
+    p.sinusoidalScanCorrection, p.postProcessBackgroundRemoval = sinus, bg
+    p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 0.75, 0.01
+    p.loadPostProcessingBackground(bgline)
+    pipe = Pipeline(p, device=0)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    got = pipe.processed_host()
+    want = img.copy()
+    if sinus:
+        want = octref.sinusoidal(want, W, A, B)
+    if bg:
+        want = octref.postproc_background_removal(want, bgline, 0.75, 0.01, W)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # idempotent per call: the scratch slot, not the volume, is the fused kernel's target when the correction is on
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    assert np.array_equal(pipe.processed_host().view(np.uint32), want.view(np.uint32))
+    pipe.close()
+
+
+@pytest.mark.parametrize("sinus", [0, 1])
+def test_background_recording_uses_the_corrected_first_bscan_and_fills_the_host_shadow_before_the_callback(sinus):
+    N, A, B = 512, 16, 3
+    p = v180_benchmark_params(N, A, B)
+    _grey(p)
+    p.fixedPatternNoiseRemoval = 0
+    p.sinusoidalScanCorrection = sinus
+    raw = synthetic_raw(N, A, B, seed=9)
+    d = _dev(raw)
+    ref = Pipeline(p, device=0)
+    ref.process_device(d.data_ptr()); ref.synchronize()
+    corrected = ref.processed_host()  # after the (optional) sinusoidal pass, before any background removal
+    ref.close()
+    p.postProcessBackgroundRemoval, p.postProcessBackgroundRecordingRequested = 1, 1
+    p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 1.0, 0.0
+    pipe = Pipeline(p, device=0)
+    seen = []
+    # the callback runs inside hipLaunchHostFunc: it may only use the no-HIP accessor (the device copy deadlocks)
+    pipe.set_callbacks(on_background=lambda user: seen.append(pipe.postprocess_background_host()))
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    W = N // 2
+    want_bg = octref.get_postproc_background(corrected, W, A)
+    assert len(seen) == 1 and np.array_equal(seen[0].view(np.uint32), want_bg.view(np.uint32))
+    assert np.array_equal(pipe.postprocess_background().view(np.uint32), want_bg.view(np.uint32))
+    want = octref.postproc_background_removal(corrected, want_bg, 1.0, 0.0, W)
+    assert np.array_equal(pipe.processed_host().view(np.uint32), want.view(np.uint32))
+    pipe.close()
+
+
+@pytest.mark.parametrize("bits,N,A,B", [(8, 256, 5, 3), (10, 256, 7, 1), (12, 300, 3, 1), (16, 1024, 9, 2), (24, 256, 3, 3), (32, 2046, 1, 1)])
+def test_quantiser_bit_exact_including_tails(bits, N, A, B):
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth = bits
+    _grey(p)
+    p.streamToHost = 1
+    dt = np.uint8 if bits <= 8 else (np.uint16 if bits <= 16 else np.uint32)
+    raw12 = synthetic_raw(N, A, B, seed=bits)
+    raw = (raw12 >> 4).astype(dt) if bits == 8 else raw12.astype(dt)
+    import torch
+    view = {1: np.uint8, 2: np.int16, 4: np.int32}[np.dtype(dt).itemsize]
+    d = torch.from_numpy(np.ascontiguousarray(raw).view(view)).to("cuda:0")
+    pipe = Pipeline(p, device=0)
+    S2 = N // 2 * A * B
+    qb = [np.zeros(S2, dt), np.zeros(S2, dt)]
+    pipe.register_streaming_buffers(qb[0], qb[1])
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    img = pipe.processed_host()
+    assert 0.05 < np.mean((img > 0) & (img < 1)) and (img <= 0).any()  # the clamp and the open interval are both exercised
+    assert np.array_equal(qb[1], octref.float_to_output(img, bits))
+    pipe.unregister_streaming_buffers()
+    pipe.close()
+
+
+@pytest.mark.parametrize("N,A,B,bpv", [(256, 70, 3, 2), (1024, 64, 2, 1), (300, 5, 2, 3), (512, 129, 1, 2)])
+def test_volume_view_u8_bit_exact(N, A, B, bpv):
+    """updateDisplayedVolume (cu:914-941) into a plain uint8 buffer [N/2][B*bpv][A]: every buffer lands at its B-scan offset"""
+    p = v180_benchmark_params(N, A, B, buffers_per_volume=bpv)
+    _grey(p)
+    p.volumeViewEnabled = 1
+    W, BV = N // 2, B * bpv
+    pipe = Pipeline(p, device=0)
+    want = np.zeros(W * BV * A, np.uint8)
+    for k in range(bpv + 1):  # one more than a volume: slot 0 is overwritten by the last buffer
+        raw = synthetic_raw(N, A, B, seed=50 + k)
+        d = _dev(raw)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        _, _, nr = pipe.processed_device()
+        assert nr == k % bpv
+        octref.volume_to_u8(pipe.processed_host(), want, nr, B, A, BV, W)
+    ptr, nbytes = pipe.volume_view_buffer()
+    assert nbytes == W * BV * A
+    got = _fetch(ptr, nbytes, np.uint8)
+    assert np.array_equal(got, want)
+    assert 8 < len(np.unique(got))  # a real grey-scale image, not a constant
+    pipe.close()
+
+
+@pytest.mark.parametrize("N,A,B", [(256, 6, 4), (300, 5, 3), (1024, 33, 2)])
+def test_display_frames_every_function_bit_exact(N, A, B):
+    p = v180_benchmark_params(N, A, B)
+    _grey(p)
+    raw = synthetic_raw(N, A, B, seed=3)
+    pipe = Pipeline(p, device=0)
+    d = _dev(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    vol = pipe.processed_host()
+    (pb, nb), (pe, ne) = pipe.display_buffers()
+    assert nb == N // 2 * A and ne == A * B
+    for frame_b, frame_e, frames, fn in ((0, 0, 1, 0), (B - 1, N // 2 - 1, 1, 1), (1, 17, 3, 0), (1, 17, 3, 1), (B - 2, N // 2 - 2, 9, 0), (0, 5, 2, 1)):
+        pipe.change_displayed_bscan_frame(frame_b, frames, fn)
+        pipe.change_displayed_enface_frame(frame_e, frames, fn)
+        pipe.synchronize()
+        assert np.array_equal(_fetch(pb, nb, np.float32).view(np.uint32), octref.display_bscan(vol, B, nb, frame_b, frames, fn).view(np.uint32))
+        assert np.array_equal(_fetch(pe, ne, np.float32).view(np.uint32), octref.display_enface(vol, N // 2, ne, frame_e, frames, fn).view(np.uint32))
+    # an unknown display function with frames > 1 leaves the frame as it is (the reference's switch has no default)
+    before = _fetch(pb, nb, np.float32)
+    pipe.change_displayed_bscan_frame(0, 4, 7); pipe.synchronize()
+    assert np.array_equal(_fetch(pb, nb, np.float32), before)
+    pipe.close()

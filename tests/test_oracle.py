@@ -184,3 +184,20 @@ def test_log_of_zero_power_is_minus_infinity():
     img = o.process(raw)
     assert np.all(np.isneginf(img))
     o.close()
+
+
+def test_volume_view_index_map_from_first_principles():
+    """cu:914-941: texel (A-scan, B-scan in the volume, depth reversed) <- uchar(v * 255) of buffer element [b][a][r]"""
+    W, A, B, bpv, nr = 6, 5, 2, 3, 1
+    rng = np.random.default_rng(0)
+    buf = rng.uniform(-0.2, 1.2, size=(B, A, W)).astype(np.float32)
+    buf[0, 0, :3] = [0.0, 1.0, 0.5]
+    out = np.full(W * B * bpv * A, 7, np.uint8)
+    octref.volume_to_u8(buf, out, nr, B, A, B * bpv, W)
+    vox = out.reshape(W, B * bpv, A)
+    want = np.full((W, B * bpv, A), 7, np.uint8)
+    q = np.floor(np.clip(buf.astype(np.float64), 0.0, 1.0) * 255.0).astype(np.uint8)
+    for b in range(B):
+        want[::-1, b + nr * B, :] = q[b].T  # z = W-1-r, y = a
+    assert np.array_equal(vox, want)
+    assert vox[W - 1, nr * B, 0] == 0 and vox[W - 2, nr * B, 0] == 255 and vox[W - 3, nr * B, 0] == 127
