@@ -81,6 +81,9 @@ int octhost_processing_run(octhost_system_t* s, octhost_consume_fn consume, void
 /* the same loop with consume = octpipe_process(pipe, buffer) */
 int octhost_processing_run_pipeline(octhost_system_t* s, octpipe_t* pipe, uint64_t maxBuffers, double maxSeconds, OctHostStats* stats);
 
+/* the same loop over a multi-GPU group: consume = octpipe_group_process(group, buffer) */
+int octhost_processing_run_group(octhost_system_t* s, octpipe_group_t* group, uint64_t maxBuffers, double maxSeconds, OctHostStats* stats);
+
 /* ---- Recorder (src/recorder.{h,cpp}): K buffers accumulated in memory, then written back to back into
  * <savePath>/<timestamp>[_<fileName>]_<name>.raw -- headerless, i.e. a file the virtual OCT system reads back unchanged.
  * OCTproZ instantiates it twice: name "raw" (fed with the ring slot, processing.cpp:187-189) and "processed" (fed from the

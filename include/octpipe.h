@@ -191,6 +191,11 @@ int    octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size);
  * raw buffer has completed (the reference's event wait cu:1418-1419), so the caller may hand the
  * ring slot back (processing.cpp:191); the rest of the chain is merely enqueued. */
 int octpipe_process(octpipe_t* h, const void* h_inputSignal);
+/* The two halves of octpipe_process: enqueue everything (H2D on the copy stream + the chain) without blocking, and wait
+ * until the H2D copy of the last enqueued buffer has completed.  A caller that drives several handles (one per GPU,
+ * octpipe_group_process) enqueues on all of them before it waits on any. */
+int octpipe_process_async(octpipe_t* h, const void* h_inputSignal);
+int octpipe_wait_input(octpipe_t* h);
 /* Same chain with the raw buffer already resident in HBM (d_raw: device pointer, S*bytesPerSample
  * bytes).  No reference counterpart: it is what the roofline measurement times. */
 int octpipe_process_device(octpipe_t* h, const void* d_raw);
@@ -247,6 +252,37 @@ int octpipe_get_volume_view_buffer(octpipe_t* h, void** d_voxels, size_t* bytes)
 int octpipe_register_gl_buffer_bscan(unsigned buf);       /* always OCTPIPE_ERR_UNSUPPORTED */
 int octpipe_register_gl_buffer_enface_view(unsigned buf); /* always OCTPIPE_ERR_UNSUPPORTED */
 int octpipe_register_gl_buffer_volume_view(unsigned buf); /* always OCTPIPE_ERR_UNSUPPORTED */
+
+/* ------------------------------------------------------------------ multi-GPU group (no reference counterpart: the
+ * reference is single-GPU, README.md:27).  One host process, one acquisition buffer per call, n GPUs: the buffer's B-scans are
+ * cut into contiguous even-sized slabs (the buffer-local flip rule cu:795 keeps its parity), member i processes slab i on
+ * devices[i], no sample data crosses GPUs.  Member 0 determines calibration data (fixed-pattern-noise mean line cu:1518-1525,
+ * recorded background cu:1557-1561) on the buffer's first B-scans; the blob reaches the other members through ONE
+ * ncclBroadcast (RCCL over xGMI, bound with dlopen at group creation) when all devices are distinct, through plain copies
+ * when members share a device.  Result: identical, bit for bit, to one handle processing the whole buffer, for every setting
+ * that works per A-scan (not: sinusoidal correction, Lanczos taps, bscansForNoiseDetermination beyond slab 0).
+ * The call shape mirrors the single-handle API so that Processing::slot_start (processing.cpp:176-218) only swaps the handle. */
+typedef struct octpipe_group octpipe_group_t;
+int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acqWholeBuffer,
+                         const OctPipeParams* params, void* h_buffer1, void* h_buffer2);          /* initializeCuda */
+int octpipe_group_destroy(octpipe_group_t* g);                                                     /* cleanupCuda */
+int octpipe_group_size(const octpipe_group_t* g);
+octpipe_t* octpipe_group_member(octpipe_group_t* g, int i);   /* NULL for a member without B-scans */
+int octpipe_group_slab(const octpipe_group_t* g, int i, unsigned* firstBscan, unsigned* bscanCount);
+const char* octpipe_group_backend(const octpipe_group_t* g);   /* "rccl" or "copy" */
+uint64_t octpipe_group_broadcast_count(const octpipe_group_t* g);
+const char* octpipe_group_last_error(void);
+int octpipe_group_set_params(octpipe_group_t* g, const OctPipeParams* params);
+int octpipe_group_update_resample_curve(octpipe_group_t* g, const float* curve, int size);
+int octpipe_group_update_dispersion_curve(octpipe_group_t* g, const float* curve, int size);
+int octpipe_group_update_window_curve(octpipe_group_t* g, const float* curve, int size);
+int octpipe_group_update_postprocess_background(octpipe_group_t* g, const float* background, int size);
+int octpipe_group_set_mean_line(octpipe_group_t* g, const float* meanLineComplex, int pin);
+int octpipe_group_process(octpipe_group_t* g, const void* h_inputSignal);          /* octCudaPipeline: whole buffer in host memory */
+int octpipe_group_process_device(octpipe_group_t* g, const void* const* d_slabs);  /* slab i resident on devices[i] */
+int octpipe_group_broadcast_calibration(octpipe_group_t* g);
+int octpipe_group_synchronize(octpipe_group_t* g);
+int octpipe_group_copy_processed_to_host(octpipe_group_t* g, float* dst /* S/2 floats, slabs back to back */);
 
 /* ------------------------------------------------------------------ measurement helper
  * Average duration in ms of the dominant (fused) kernel since the last reset, measured with HIP

@@ -6,8 +6,8 @@ this package is the Python plumbing around it used by the tests and the benchmar
 from . import _lib
 from ._lib import OctPipeError
 from .params import INTERPOLATION, OctAlgorithmParameters, WindowType, v180_benchmark_params
-from .pipeline import Pipeline
+from .pipeline import Pipeline, PipelineGroup
 from .virtual_oct import AcquisitionBuffer, Recorder, VirtualOCTSystem, synthetic_raw
 
 __all__ = ["_lib", "OctPipeError", "INTERPOLATION", "OctAlgorithmParameters", "WindowType", "v180_benchmark_params",
-           "Pipeline", "AcquisitionBuffer", "Recorder", "VirtualOCTSystem", "synthetic_raw"]
+           "Pipeline", "PipelineGroup", "AcquisitionBuffer", "Recorder", "VirtualOCTSystem", "synthetic_raw"]

@@ -89,7 +89,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_update_postprocess_background", "octpipe_copy_postprocess_background_to_host",
     "octpipe_get_postprocess_background_host",
     "octpipe_calibration_size", "octpipe_export_calibration", "octpipe_import_calibration",
-    "octpipe_process", "octpipe_process_device", "octpipe_synchronize",
+    "octpipe_process", "octpipe_process_async", "octpipe_wait_input", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
     "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_debug_spectrum",
     "octpipe_debug_unpack", "octpipe_debug_force_prepared",
@@ -99,6 +99,12 @@ OCTPIPE_SYMBOLS = [
     "octpipe_change_displayed_bscan_frame", "octpipe_change_displayed_enface_frame", "octpipe_get_display_buffers",
     "octpipe_get_volume_view_buffer", "octpipe_register_gl_buffer_bscan", "octpipe_register_gl_buffer_enface_view", "octpipe_register_gl_buffer_volume_view",
     "octpipe_enable_kernel_timing", "octpipe_kernel_timing",
+    "octpipe_group_create", "octpipe_group_destroy", "octpipe_group_size", "octpipe_group_member", "octpipe_group_slab",
+    "octpipe_group_backend", "octpipe_group_broadcast_count", "octpipe_group_last_error", "octpipe_group_set_params",
+    "octpipe_group_update_resample_curve", "octpipe_group_update_dispersion_curve", "octpipe_group_update_window_curve",
+    "octpipe_group_update_postprocess_background", "octpipe_group_set_mean_line", "octpipe_group_process",
+    "octpipe_group_process_device", "octpipe_group_broadcast_calibration", "octpipe_group_synchronize",
+    "octpipe_group_copy_processed_to_host",
 ]
 OCTHOST_SYMBOLS = [
     "octhost_buffer_create", "octhost_buffer_destroy", "octhost_buffer_allocate", "octhost_buffer_release",
@@ -107,7 +113,7 @@ OCTHOST_SYMBOLS = [
     "octhost_virtual_system_create", "octhost_memory_system_create", "octhost_system_destroy",
     "octhost_system_start", "octhost_system_stop", "octhost_system_running", "octhost_system_buffer",
     "octhost_system_acquisition_params", "octhost_last_error",
-    "octhost_processing_run", "octhost_processing_run_pipeline",
+    "octhost_processing_run", "octhost_processing_run_pipeline", "octhost_processing_run_group",
     "octhost_load_settings_ini", "octhost_load_curve_csv", "octhost_save_curve_csv",
     "octhost_recorder_create", "octhost_recorder_destroy", "octhost_recorder_init", "octhost_recorder_record",
     "octhost_recorder_abort", "octhost_recorder_state", "octhost_recorder_path", "octhost_recorder_error", "octhost_timestamp",
@@ -201,6 +207,25 @@ def lib():
         L.octpipe_get_display_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.octpipe_get_volume_view_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.octpipe_get_postprocess_background_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.octpipe_process_async.argtypes = [C.c_void_p, C.c_void_p]
+        L.octpipe_wait_input.argtypes = [C.c_void_p]
+        L.octpipe_group_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.octpipe_group_member.restype = C.c_void_p
+        L.octpipe_group_member.argtypes = [C.c_void_p, C.c_int]
+        L.octpipe_group_backend.restype = C.c_char_p
+        L.octpipe_group_backend.argtypes = [C.c_void_p]
+        L.octpipe_group_broadcast_count.restype = C.c_uint64
+        L.octpipe_group_broadcast_count.argtypes = [C.c_void_p]
+        L.octpipe_group_last_error.restype = C.c_char_p
+        L.octpipe_group_slab.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        for name in ("octpipe_group_destroy", "octpipe_group_size", "octpipe_group_broadcast_calibration", "octpipe_group_synchronize"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("octpipe_group_set_params", "octpipe_group_process", "octpipe_group_process_device", "octpipe_group_copy_processed_to_host"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        for name in ("octpipe_group_update_resample_curve", "octpipe_group_update_dispersion_curve", "octpipe_group_update_window_curve",
+                     "octpipe_group_update_postprocess_background", "octpipe_group_set_mean_line"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.octhost_processing_run_group.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         L.octpipe_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.octpipe_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.octpipe_polynomial_curve.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]

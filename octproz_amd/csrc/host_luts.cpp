@@ -65,6 +65,16 @@ void dispersive_phase(const float* curve, unsigned size, float* outComplex) {
 	}
 }
 
+// fillSinusoidalScanCorrectionCurve (cuda_code.cu:516-521): s[k] = (A/pi) acos(1 - 2k/A).  Evaluated once on the host like the
+// dispersive phasor (the reference fills it with a device kernel at init, cu:1093): A values, and the host's acosf is the one
+// the CPU oracle uses, so the resampling positions agree bit for bit.
+void sinusoidal_curve(unsigned length, float* out) {
+	for (unsigned k = 0; k < length; ++k) {
+		const float arg = static_cast<float>(1.0 - ((2.0 * static_cast<float>(k)) / static_cast<float>(length)));
+		out[k] = static_cast<float>((static_cast<float>(length) / 3.14159265358979323846) * acosf(arg));
+	}
+}
+
 namespace {
 struct Support {  // windowfunction.cpp:122-130 and the identical preambles of the other shapes
 	unsigned width;

@@ -9,4 +9,5 @@ void custom_resample_curve(const float* curve, unsigned curveLength, unsigned si
 void dispersion_curve(float d0, float d1, float d2, float d3, unsigned size, float* out);
 void dispersive_phase(const float* curve, unsigned size, float* outComplex);
 void window_curve(int type, float center, float fill, unsigned size, float* out);
+void sinusoidal_curve(unsigned length, float* out);
 }  // namespace octhost

@@ -336,4 +336,13 @@ int octhost_processing_run_pipeline(octhost_system_t* s, octpipe_t* pipe, uint64
 	return rc;
 }
 
+static int consumeGroup(void* raw, unsigned, void* user) { return octpipe_group_process(static_cast<octpipe_group_t*>(user), raw); }
+
+int octhost_processing_run_group(octhost_system_t* s, octpipe_group_t* group, uint64_t maxBuffers, double maxSeconds, OctHostStats* stats) {
+	if (!group) return hostFail("null group");
+	int rc = octhost_processing_run(s, consumeGroup, group, maxBuffers, maxSeconds, stats);
+	if (!rc) rc = octpipe_group_synchronize(group);
+	return rc;
+}
+
 }  // extern "C"

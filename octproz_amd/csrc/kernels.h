@@ -64,6 +64,14 @@ struct FusedArgs {
 #ifndef OCT_REGTAB
 #define OCT_REGTAB 0
 #endif
+// OCT_PERM_EXCHANGE = 0: the exchange in front of the last radix-4 pass of the N = 1024 plan goes through LDS (packed twiddle
+// tables kept) instead of v_permlane32/16_swap.  OCT_REGTW3 = 1 (with OCT_REGTAB): the last pass' twiddles in VGPRs too.
+#ifndef OCT_PERM_EXCHANGE
+#define OCT_PERM_EXCHANGE 1
+#endif
+#ifndef OCT_REGTW3
+#define OCT_REGTW3 0
+#endif
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
@@ -134,30 +142,12 @@ OCT_DEV u32x4 load_chunk(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
 	else return __builtin_bit_cast(u32x4, buf_load128(r, voff, imm));
 }
 
-#ifndef OCT_SDWA_UNPACK
-#define OCT_SDWA_UNPACK 0
-#endif
-OCT_DEV float cvt_u16_lo(uint32_t x) {
-	float r;
-	asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(x));
-	return r;
-}
-OCT_DEV float cvt_u16_hi(uint32_t x) {
-	float r;
-	asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(x));
-	return r;
-}
 // cu:119-121 / cu:139-141: uint16 -> float (exact), optional >> 4; samples 4h..4h+3 of the chunk
 template <int INTYPE>
 OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 	if constexpr (INTYPE == IN_U16) {
 		const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
-#if OCT_SDWA_UNPACK
-		// one v_cvt_f32_u32 with a 16-bit source select per sample instead of mask / shift + convert
-		if (s == 0) return float4{cvt_u16_lo(a), cvt_u16_hi(a), cvt_u16_lo(b), cvt_u16_hi(b)};
-#else
 		if (s == 0) return float4{(float)(a & 0xffffu), (float)(a >> 16), (float)(b & 0xffffu), (float)(b >> 16)};
-#endif
 		return float4{(float)((a & 0xffffu) >> s), (float)((a >> 16) >> s), (float)((b & 0xffffu) >> s), (float)((b >> 16) >> s)};
 	} else {
 		// (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)
@@ -226,7 +216,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + lane;
 #pragma unroll
 		for (int c = 0; c < 6; c++) {
-			const f32x4 w = tp[c * 64];
+			const f32x4 w = (REGTW && OCT_REGTW3) ? twr[8 + c] : tp[c * 64];
 			const int i0 = 2 * c, i1 = 2 * c + 1;
 			v[i0 / 3 + (i0 % 3 + 1) * NB] = octfft::cmul(v[i0 / 3 + (i0 % 3 + 1) * NB], f2{w.x, w.y});
 			v[i1 / 3 + (i1 % 3 + 1) * NB] = octfft::cmul(v[i1 / 3 + (i1 % 3 + 1) * NB], f2{w.z, w.w});
@@ -371,9 +361,10 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	fft_pass<N, R0, 1, false, true, false>(v, xbuf, tw, lane);
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
-		fft_pass<N, R1, R0, true, false, false, 2, REGTW>(v, xbuf, tw, lane, twr);
-		perm_exchange<P>(v);
-		fft_pass<N, R2, R0 * R1, false, false, PRUNE, 3>(v, xbuf, tw + 8 * 16 * 2, lane);
+		constexpr bool PX = OCT_PERM_EXCHANGE != 0;
+		fft_pass<N, R1, R0, true, !PX, false, 2, REGTW>(v, xbuf, tw, lane, twr);
+		if constexpr (PX) perm_exchange<P>(v);
+		fft_pass<N, R2, R0 * R1, !PX, false, PRUNE, 3, REGTW>(v, xbuf, tw + 8 * 16 * 2, lane, twr);
 	} else if constexpr (R3 == 1) {
 		fft_pass<N, R1, R0, true, true, false>(v, xbuf, tw + T1, lane);
 		fft_pass<N, R2, R0 * R1, true, false, PRUNE>(v, xbuf, tw + T2, lane);
@@ -507,7 +498,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// REGTAB: the same table entries the LDS variant reads per A-scan, computed once per persistent wave
 	f32x4 cwR[REGTAB ? P : 1];
 	f2 wphR[REGTAB ? P : 1];
-	f32x4 tw2R[REGTAB ? 8 : 1];
+	f32x4 tw2R[REGTAB ? (OCT_REGTW3 ? 14 : 8) : 1];
 	if constexpr (REGTAB) {
 #pragma unroll
 		for (int q = 0; q < P; q++) {
@@ -519,6 +510,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 #pragma unroll
 		for (int c = 0; c < 8; c++) tw2R[c] = reinterpret_cast<const f32x4*>(tw)[c * 16 + (lane & 15)];
+		if constexpr (OCT_REGTW3 != 0) {
+#pragma unroll
+			for (int c = 0; c < 6; c++) tw2R[8 + c] = reinterpret_cast<const f32x4*>(tw)[8 * 16 + c * 64 + lane];
+		}
 	}
 	for (; line < a.numLines; line += wavesTotal) {
 		// ---- stage the raw row in LDS as float32

@@ -60,6 +60,7 @@ struct octpipe {
 	hipEvent_t slotFree[2] = {nullptr, nullptr};  // fused kernel finished reading the raw slot
 	bool slotUsed[2] = {false, false};
 	int slot = 0;
+	int lastInputSlot = -1;  // raw slot of the last octpipe_process[_async] call
 
 	void* d_raw[2] = {nullptr, nullptr};
 	float* d_prepared = nullptr;   // S floats (uint8/uint32 input, Lanczos): lazily allocated
@@ -614,8 +615,11 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	if ((rc = ensure((void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
 	if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
-	hipLaunchKernelGGL(oct::oct_fill_sinus_curve_kernel, dim3((h->A + 255) / 256), dim3(256), 0, h->stream, h->d_sinusCurve, h->A);  // cu:1093
-	HIP_TRY(hipGetLastError());
+	{  // cu:1093
+		std::vector<float> sc((size_t)h->A);
+		octhost::sinusoidal_curve((unsigned)h->A, sc.data());
+		HIP_TRY(hipMemcpy(h->d_sinusCurve, sc.data(), sizeof(float) * sc.size(), hipMemcpyHostToDevice));
+	}
 	// ring slots: pinned here, unpinned in octpipe_destroy (cu:1135-1136, 1200-1207)
 	void* hb[2] = {h_buffer1, h_buffer2};
 	for (int i = 0; i < 2; ++i) {
@@ -762,7 +766,7 @@ int octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size) {
 	return OCTPIPE_OK;
 }
 
-int octpipe_process(octpipe_t* h, const void* h_inputSignal) {
+int octpipe_process_async(octpipe_t* h, const void* h_inputSignal) {
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	if (!h_inputSignal) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null input buffer");
 	int rc = setDevice(h); if (rc) return rc;
@@ -779,9 +783,23 @@ int octpipe_process(octpipe_t* h, const void* h_inputSignal) {
 	if (rc) return rc;
 	HIP_TRY(hipEventRecord(h->slotFree[s], h->stream));
 	h->slotUsed[s] = true;
-	// completion contract of the reference (cu:1416-1419): the host buffer is no longer read on return
-	HIP_TRY(hipEventSynchronize(h->h2dDone[s]));
+	h->lastInputSlot = s;
 	return OCTPIPE_OK;
+}
+
+int octpipe_wait_input(octpipe_t* h) {
+	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
+	if (h->lastInputSlot < 0) return OCTPIPE_OK;
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipEventSynchronize(h->h2dDone[h->lastInputSlot]));
+	return OCTPIPE_OK;
+}
+
+int octpipe_process(octpipe_t* h, const void* h_inputSignal) {
+	int rc = octpipe_process_async(h, h_inputSignal);
+	if (rc) return rc;
+	// completion contract of the reference (cu:1416-1419): the host buffer is no longer read on return
+	return octpipe_wait_input(h);
 }
 
 int octpipe_process_device(octpipe_t* h, const void* d_raw) {

@@ -1,0 +1,333 @@
+// octpipe_group.hip -- one acquisition buffer processed by SEVERAL GPUs of a node from ONE host process (include/octpipe.h,
+// "multi-GPU group").  The reference is single-GPU (README.md:27); its host loop (processing.cpp:176-218) calls one
+// octCudaPipeline per buffer.  A group keeps that call shape: octpipe_group_process(group, ring slot) -- inside, the
+// buffer's B-scans are cut into contiguous even-sized slabs (flip parity preserved, cu:795), member i owns slab i on its own
+// device with its own streams, and NO sample data crosses GPUs.  The only exchange is the calibration blob (curves,
+// fixed-pattern-noise mean line, post-process background: 22 N + 16 bytes) that member 0 determines on the first B-scans of
+// the buffer (cu:1518-1525) and every other member imports: one ncclBroadcast over RCCL (xGMI) when the members sit on
+// distinct devices, plain copies when they share a device (tests on a one-GPU box).
+//
+// RCCL is bound at run time (dlopen) and only when a group with distinct devices is created: liboctpipe.so itself has no
+// link dependency on it, and a process that already holds an RCCL (PyTorch brings its own copy) reuses that one.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/octpipe.h"
+
+namespace {
+
+thread_local std::string g_groupError;
+int gfail(int code, const std::string& msg) { g_groupError = msg; return code; }
+
+// the handful of RCCL entry points used (signatures of rccl/rccl.h; ncclUint8 = 1, ncclSuccess = 0)
+typedef void* ncclComm_p;
+struct RcclApi {
+	void* lib = nullptr;
+	int (*CommInitAll)(ncclComm_p*, int, const int*) = nullptr;
+	int (*CommDestroy)(ncclComm_p) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_p, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+	bool ok() const { return CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast; }
+};
+
+bool loadRccl(RcclApi* api) {
+	const char* names[] = {"librccl.so.1", "librccl.so"};
+	for (const char* n : names) if (!api->lib) api->lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // an RCCL the process already holds
+	for (const char* n : names) if (!api->lib) api->lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+	if (!api->lib) return false;
+	api->CommInitAll = reinterpret_cast<decltype(api->CommInitAll)>(dlsym(api->lib, "ncclCommInitAll"));
+	api->CommDestroy = reinterpret_cast<decltype(api->CommDestroy)>(dlsym(api->lib, "ncclCommDestroy"));
+	api->GroupStart = reinterpret_cast<decltype(api->GroupStart)>(dlsym(api->lib, "ncclGroupStart"));
+	api->GroupEnd = reinterpret_cast<decltype(api->GroupEnd)>(dlsym(api->lib, "ncclGroupEnd"));
+	api->Broadcast = reinterpret_cast<decltype(api->Broadcast)>(dlsym(api->lib, "ncclBroadcast"));
+	api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(dlsym(api->lib, "ncclGetErrorString"));
+	return api->ok();
+}
+
+}  // namespace
+
+struct octpipe_group {
+	std::vector<int> devices;
+	std::vector<octpipe_t*> members;
+	std::vector<unsigned> first, count;  // B-scan slab of every member
+	OctPipeAcquisitionParams acq{};      // the whole buffer
+	OctPipeParams params{};
+	size_t bytesPerBscan = 0;            // raw bytes of one B-scan
+	size_t outPerBscan = 0;              // processed floats of one B-scan
+	bool calibrationPending = true;
+	bool fpnKnown = false;               // member 0 has determined a mean line that the others hold
+	bool useRccl = false;
+	RcclApi rccl;
+	std::vector<ncclComm_p> comms;
+	std::vector<void*> d_blob;           // one device staging buffer per member (RCCL path)
+	std::vector<hipStream_t> commStreams;
+	std::vector<unsigned char> blob;
+	void* pinned[2] = {nullptr, nullptr};
+	uint64_t broadcasts = 0;
+};
+
+namespace {
+
+// contiguous slabs, every slab starts on an even B-scan (same rule as octproz_amd/dist.py slab_bounds)
+void slabBounds(unsigned total, unsigned world, std::vector<unsigned>* first, std::vector<unsigned>* count) {
+	const unsigned pairs = (total + 1) / 2, base = pairs / world, extra = pairs % world;
+	unsigned start = 0;
+	for (unsigned r = 0; r < world; ++r) {
+		unsigned n = (base + (r < extra ? 1u : 0u)) * 2u;
+		if (n > total - start) n = total - start;
+		first->push_back(start);
+		count->push_back(n);
+		start += n;
+	}
+}
+
+int broadcastCalibration(octpipe_group* g) {
+	octpipe_t* root = g->members[0];
+	const size_t n = octpipe_calibration_size(root);
+	g->blob.resize(n);
+	int rc = octpipe_export_calibration(root, g->blob.data(), n);
+	if (rc) return gfail(rc, octpipe_last_error());
+	if (g->useRccl) {
+		// device-to-device over xGMI: root stages the blob in HBM, one grouped ncclBroadcast, every member reads it back
+		if (hipSetDevice(g->devices[0]) != hipSuccess || hipMemcpy(g->d_blob[0], g->blob.data(), n, hipMemcpyHostToDevice) != hipSuccess)
+			return gfail(OCTPIPE_ERR_DEVICE, "staging the calibration blob failed");
+		int e = g->rccl.GroupStart();
+		for (size_t i = 0; i < g->members.size() && e == 0; ++i)
+			if (g->members[i]) e = g->rccl.Broadcast(g->d_blob[i], g->d_blob[i], n, /*ncclUint8*/ 1, 0, g->comms[i], g->commStreams[i]);
+		const int e2 = g->rccl.GroupEnd();
+		if (e == 0) e = e2;
+		if (e != 0) return gfail(OCTPIPE_ERR_DEVICE, std::string("ncclBroadcast: ") + (g->rccl.GetErrorString ? g->rccl.GetErrorString(e) : "error"));
+		for (size_t i = 1; i < g->members.size(); ++i) {
+			if (!g->members[i]) continue;
+			std::vector<unsigned char> got(n);
+			if (hipSetDevice(g->devices[i]) != hipSuccess || hipStreamSynchronize(g->commStreams[i]) != hipSuccess ||
+			    hipMemcpy(got.data(), g->d_blob[i], n, hipMemcpyDeviceToHost) != hipSuccess)
+				return gfail(OCTPIPE_ERR_DEVICE, "reading the broadcast calibration blob failed");
+			if ((rc = octpipe_import_calibration(g->members[i], got.data(), n))) return gfail(rc, octpipe_last_error());
+		}
+		hipSetDevice(g->devices[0]);
+		hipStreamSynchronize(g->commStreams[0]);
+	} else {
+		for (size_t i = 1; i < g->members.size(); ++i)
+			if (g->members[i] && (rc = octpipe_import_calibration(g->members[i], g->blob.data(), n))) return gfail(rc, octpipe_last_error());
+	}
+	g->broadcasts++;
+	return OCTPIPE_OK;
+}
+
+// whether member 0 is going to (re)determine calibration data on the next buffer (cu:1518-1525, cu:1557-1561)
+bool rootWillCalibrate(const octpipe_group* g) {
+	const OctPipeParams& p = g->params;
+	return g->calibrationPending || (p.fixedPatternNoiseRemoval && (!g->fpnKnown || p.continuousFixedPatternNoiseDetermination || p.redetermineFixedPatternNoise)) ||
+	       (p.postProcessBackgroundRemoval && p.postProcessBackgroundRecordingRequested);
+}
+
+template <typename F>
+int forMembers(octpipe_group* g, F f) {
+	for (size_t i = 0; i < g->members.size(); ++i)
+		if (g->members[i]) { const int rc = f(i, g->members[i]); if (rc) return gfail(rc, octpipe_last_error()); }
+	return OCTPIPE_OK;
+}
+
+int processCommon(octpipe_group* g, const void* h_buffer, const void* const* d_slabs) {
+	auto enqueue = [&](size_t i, octpipe_t* m) -> int {
+		if (h_buffer) return octpipe_process_async(m, static_cast<const char*>(h_buffer) + (size_t)g->first[i] * g->bytesPerBscan);
+		return octpipe_process_device(m, d_slabs[i]);
+	};
+	if (rootWillCalibrate(g)) {
+		// member 0 first: its slab starts with the buffer's first B-scans, which is where the reference takes the estimate from
+		int rc = enqueue(0, g->members[0]);
+		if (rc) return gfail(rc, octpipe_last_error());
+		if ((rc = octpipe_synchronize(g->members[0]))) return gfail(rc, octpipe_last_error());
+		if ((rc = broadcastCalibration(g))) return rc;
+		g->calibrationPending = false;
+		if (g->params.fixedPatternNoiseRemoval) g->fpnKnown = true;
+		g->params.redetermineFixedPatternNoise = 0;
+		g->params.postProcessBackgroundRecordingRequested = 0;
+		for (size_t i = 1; i < g->members.size(); ++i)
+			if (g->members[i] && (rc = enqueue(i, g->members[i]))) return gfail(rc, octpipe_last_error());
+	} else {
+		int rc = forMembers(g, enqueue);
+		if (rc) return rc;
+	}
+	if (h_buffer) return forMembers(g, [](size_t, octpipe_t* m) { return octpipe_wait_input(m); });
+	return OCTPIPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* octpipe_group_last_error(void) { return g_groupError.c_str(); }
+
+int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
+                         void* h_buffer1, void* h_buffer2) {
+	if (!out || !devices || n <= 0 || !acq || !params) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*out = nullptr;
+	octpipe_group* g = new octpipe_group();
+	g->devices.assign(devices, devices + n);
+	g->acq = *acq;
+	g->params = *params;
+	slabBounds(acq->bscansPerBuffer, (unsigned)n, &g->first, &g->count);
+	g->members.assign((size_t)n, nullptr);
+	*out = g;
+	if (g->count[0] == 0) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "no B-scans for member 0");
+	for (int i = 0; i < n; ++i) {
+		if (g->count[i] == 0) continue;  // fewer B-scan pairs than members: the surplus members stay empty
+		OctPipeAcquisitionParams a = *acq;
+		a.bscansPerBuffer = g->count[i];
+		OctPipeParams p = *params;
+		if (i > 0) {  // only member 0 determines calibration data; the others receive it
+			p.redetermineFixedPatternNoise = 0;
+			p.continuousFixedPatternNoiseDetermination = 0;
+			p.postProcessBackgroundRecordingRequested = 0;
+		}
+		const int rc = octpipe_create(&g->members[i], devices[i], &a, &p, nullptr, nullptr);
+		if (rc) return gfail(rc, octpipe_last_error());
+	}
+	size_t raw0 = 0;
+	octpipe_raw_buffer_bytes(g->members[0], &raw0);
+	g->bytesPerBscan = raw0 / g->count[0];
+	g->outPerBscan = (size_t)(acq->samplesPerLine / 2) * acq->ascansPerBscan;
+	// ring slots: pinned once, portable across the members' devices (cu:1135-1136)
+	void* hb[2] = {h_buffer1, h_buffer2};
+	for (int k = 0; k < 2; ++k)
+		if (hb[k]) {
+			if (hipSetDevice(devices[0]) != hipSuccess || hipHostRegister(hb[k], g->bytesPerBscan * acq->bscansPerBuffer, hipHostRegisterPortable) != hipSuccess)
+				return gfail(OCTPIPE_ERR_DEVICE, "pinning the ring slots failed");
+			g->pinned[k] = hb[k];
+		}
+	// RCCL communicator when every member has its own device
+	bool distinct = n > 0;
+	for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (devices[i] == devices[j]) distinct = false;
+	for (int i = 0; i < n; ++i) if (!g->members[i]) distinct = false;
+	if (distinct && loadRccl(&g->rccl)) {
+		g->comms.assign((size_t)n, nullptr);
+		const int e = g->rccl.CommInitAll(g->comms.data(), n, devices);
+		if (e == 0) {
+			g->useRccl = true;
+			const size_t nb = octpipe_calibration_size(g->members[0]);
+			g->d_blob.assign((size_t)n, nullptr);
+			g->commStreams.assign((size_t)n, nullptr);
+			for (int i = 0; i < n; ++i) {
+				if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc(&g->d_blob[i], nb) != hipSuccess ||
+				    hipStreamCreateWithFlags(&g->commStreams[i], hipStreamNonBlocking) != hipSuccess)
+					return gfail(OCTPIPE_ERR_DEVICE, "allocating the calibration staging buffers failed");
+			}
+		} else {
+			g->comms.clear();
+		}
+	}
+	return OCTPIPE_OK;
+}
+
+int octpipe_group_destroy(octpipe_group_t* g) {
+	if (!g) return OCTPIPE_OK;
+	for (size_t i = 0; i < g->members.size(); ++i) if (g->members[i]) octpipe_synchronize(g->members[i]);
+	if (g->useRccl) {
+		for (size_t i = 0; i < g->comms.size(); ++i) {
+			hipSetDevice(g->devices[i]);
+			if (g->commStreams[i]) { hipStreamSynchronize(g->commStreams[i]); hipStreamDestroy(g->commStreams[i]); }
+			if (g->d_blob[i]) hipFree(g->d_blob[i]);
+			if (g->comms[i]) g->rccl.CommDestroy(g->comms[i]);
+		}
+	}
+	for (int k = 0; k < 2; ++k) if (g->pinned[k]) hipHostUnregister(g->pinned[k]);
+	for (octpipe_t* m : g->members) octpipe_destroy(m);
+	delete g;
+	return OCTPIPE_OK;
+}
+
+int octpipe_group_size(const octpipe_group_t* g) { return g ? (int)g->members.size() : 0; }
+octpipe_t* octpipe_group_member(octpipe_group_t* g, int i) { return (g && i >= 0 && i < (int)g->members.size()) ? g->members[i] : nullptr; }
+const char* octpipe_group_backend(const octpipe_group_t* g) { return !g ? "" : (g->useRccl ? "rccl" : "copy"); }
+uint64_t octpipe_group_broadcast_count(const octpipe_group_t* g) { return g ? g->broadcasts : 0; }
+
+int octpipe_group_slab(const octpipe_group_t* g, int i, unsigned* firstBscan, unsigned* bscanCount) {
+	if (!g || i < 0 || i >= (int)g->members.size()) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "member index out of range");
+	if (firstBscan) *firstBscan = g->first[i];
+	if (bscanCount) *bscanCount = g->count[i];
+	return OCTPIPE_OK;
+}
+
+int octpipe_group_set_params(octpipe_group_t* g, const OctPipeParams* params) {
+	if (!g || !params) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	const int pendingRedetermine = g->params.redetermineFixedPatternNoise, pendingRecord = g->params.postProcessBackgroundRecordingRequested;
+	g->params = *params;
+	g->params.redetermineFixedPatternNoise |= pendingRedetermine;
+	g->params.postProcessBackgroundRecordingRequested |= pendingRecord;
+	return forMembers(g, [&](size_t i, octpipe_t* m) {
+		OctPipeParams p = *params;
+		if (i > 0) { p.redetermineFixedPatternNoise = 0; p.continuousFixedPatternNoiseDetermination = 0; p.postProcessBackgroundRecordingRequested = 0; }
+		return octpipe_set_params(m, &p);
+	});
+}
+
+// curves go to every member directly (they are host data); a changed curve does not invalidate the mean line in the
+// reference either (cu:1433-1445 only re-upload the LUTs)
+int octpipe_group_update_resample_curve(octpipe_group_t* g, const float* c, int n) {
+	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
+	return forMembers(g, [&](size_t, octpipe_t* m) { return octpipe_update_resample_curve(m, c, n); });
+}
+int octpipe_group_update_dispersion_curve(octpipe_group_t* g, const float* c, int n) {
+	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
+	return forMembers(g, [&](size_t, octpipe_t* m) { return octpipe_update_dispersion_curve(m, c, n); });
+}
+int octpipe_group_update_window_curve(octpipe_group_t* g, const float* c, int n) {
+	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
+	return forMembers(g, [&](size_t, octpipe_t* m) { return octpipe_update_window_curve(m, c, n); });
+}
+int octpipe_group_update_postprocess_background(octpipe_group_t* g, const float* b, int n) {
+	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
+	return forMembers(g, [&](size_t, octpipe_t* m) { return octpipe_update_postprocess_background(m, b, n); });
+}
+int octpipe_group_set_mean_line(octpipe_group_t* g, const float* meanLineComplex, int pin) {
+	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
+	g->fpnKnown = true;
+	return forMembers(g, [&](size_t, octpipe_t* m) { return octpipe_set_mean_line(m, meanLineComplex, pin); });
+}
+
+int octpipe_group_process(octpipe_group_t* g, const void* h_buffer) {
+	if (!g) return gfail(OCTPIPE_ERR_NOT_INITIALIZED, "group is not initialized");
+	if (!h_buffer) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null input buffer");
+	return processCommon(g, h_buffer, nullptr);
+}
+
+int octpipe_group_process_device(octpipe_group_t* g, const void* const* d_slabs) {
+	if (!g) return gfail(OCTPIPE_ERR_NOT_INITIALIZED, "group is not initialized");
+	if (!d_slabs) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null slab list");
+	for (size_t i = 0; i < g->members.size(); ++i) if (g->members[i] && !d_slabs[i]) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null slab pointer");
+	return processCommon(g, nullptr, d_slabs);
+}
+
+int octpipe_group_broadcast_calibration(octpipe_group_t* g) {
+	if (!g) return gfail(OCTPIPE_ERR_NOT_INITIALIZED, "group is not initialized");
+	int rc = octpipe_synchronize(g->members[0]);
+	if (rc) return gfail(rc, octpipe_last_error());
+	return broadcastCalibration(g);
+}
+
+int octpipe_group_synchronize(octpipe_group_t* g) {
+	if (!g) return gfail(OCTPIPE_ERR_NOT_INITIALIZED, "group is not initialized");
+	return forMembers(g, [](size_t, octpipe_t* m) { return octpipe_synchronize(m); });
+}
+
+// the processed buffer of the slot written last, slabs back to back: [B][A][N/2] float32 like one unsharded handle
+int octpipe_group_copy_processed_to_host(octpipe_group_t* g, float* dst) {
+	if (!g || !dst) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	return forMembers(g, [&](size_t i, octpipe_t* m) {
+		unsigned slot = 0;
+		int rc = octpipe_get_processed_device(m, nullptr, nullptr, &slot);
+		if (rc) return rc;
+		const size_t n = (size_t)g->count[i] * g->outPerBscan;
+		return octpipe_copy_processed_to_host(m, dst + (size_t)g->first[i] * g->outPerBscan, n, n * slot);
+	});
+}
+
+}  // extern "C"

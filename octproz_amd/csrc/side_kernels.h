@@ -89,15 +89,6 @@ __global__ void oct_minvar_select_kernel(const float4* seg, int width, int segs,
 }
 
 // ------------------------------------------------------------------ post pass: sinusoidal correction + background removal
-// s[k] = (A/pi) acos(1 - 2k/A), cu:516-521
-__global__ void oct_fill_sinus_curve_kernel(float* curve, int length) {
-	const int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k < length) {
-		const float arg = (float)(1.0 - ((2.0 * (float)k) / (float)length));
-		curve[k] = (float)(((float)length / 3.14159265358979323846) * acosf(arg));
-	}
-}
-
 struct PostPassArgs {
 	const float* in;     // SINUS: the scratch slot the fused kernel wrote; else == out (in place, elementwise)
 	float* out;          // the buffer's slot in the processed volume

@@ -226,3 +226,105 @@ class Pipeline:
     @property
     def handle(self):
         return self._h
+
+
+class PipelineGroup:
+    """octpipe_group_* (include/octpipe.h): one buffer per call, B-scan slabs over several GPUs of the node from one process."""
+
+    def __init__(self, params: OctAlgorithmParameters, devices, h_buffer1=None, h_buffer2=None):
+        self.params = params
+        self._lib = _lib.lib()
+        self._g = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        acq, pod = params.acquisition(), params.pod()
+        self._keep = (h_buffer1, h_buffer2)
+        b1 = h_buffer1.ctypes.data if h_buffer1 is not None else None
+        b2 = h_buffer2.ctypes.data if h_buffer2 is not None else None
+        rc = self._lib.octpipe_group_create(C.byref(self._g), devs, len(devices), C.byref(acq), C.byref(pod), b1, b2)
+        if rc != 0:
+            msg = self._lib.octpipe_group_last_error()
+            if self._g:
+                self._lib.octpipe_group_destroy(self._g)
+                self._g = C.c_void_p()
+            raise _lib.OctPipeError(rc, msg.decode() if msg else "")
+        self.N, self.S = int(params.samplesPerLine), params.samplesPerBuffer
+        self._sync_params(force_curves=True)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.OctPipeError(rc, (self._lib.octpipe_group_last_error() or b"").decode())
+
+    def _sync_params(self, force_curves=False):
+        p = self.params
+        for flag, upd, curve, setter in (("resampling", "resamplingUpdated", "resampleCurve", self._lib.octpipe_group_update_resample_curve),
+                                         ("dispersionCompensation", "dispersionUpdated", "dispersionCurve", self._lib.octpipe_group_update_dispersion_curve),
+                                         ("windowing", "windowUpdated", "windowCurve", self._lib.octpipe_group_update_window_curve)):
+            c = getattr(p, curve)
+            if getattr(p, flag) and (getattr(p, upd) or force_curves) and c is not None:
+                c = np.ascontiguousarray(c, dtype=np.float32)
+                self._check(setter(self._g, c.ctypes.data, len(c)))
+                setattr(p, upd, False)
+        if p.postProcessBackgroundRemoval and p.postProcessBackgroundUpdated and p.postProcessBackground is not None:
+            c = np.ascontiguousarray(p.postProcessBackground, dtype=np.float32)
+            self._check(self._lib.octpipe_group_update_postprocess_background(self._g, c.ctypes.data, len(c)))
+            p.postProcessBackgroundUpdated = False
+        pod = p.pod()
+        self._check(self._lib.octpipe_group_set_params(self._g, C.byref(pod)))
+        p.redetermineFixedPatternNoise = 0
+        p.postProcessBackgroundRecordingRequested = 0
+
+    @property
+    def backend(self):
+        return self._lib.octpipe_group_backend(self._g).decode()
+
+    @property
+    def broadcasts(self):
+        return int(self._lib.octpipe_group_broadcast_count(self._g))
+
+    @property
+    def size(self):
+        return self._lib.octpipe_group_size(self._g)
+
+    def slab(self, i):
+        f, n = C.c_uint(), C.c_uint()
+        self._check(self._lib.octpipe_group_slab(self._g, i, C.byref(f), C.byref(n)))
+        return f.value, n.value
+
+    def octCudaPipeline(self, h_inputSignal):
+        self._sync_params()
+        a = np.ascontiguousarray(h_inputSignal)
+        self._check(self._lib.octpipe_group_process(self._g, a.ctypes.data))
+
+    def process_device(self, slab_ptrs):
+        self._sync_params()
+        arr = (C.c_void_p * len(slab_ptrs))(*slab_ptrs)
+        self._check(self._lib.octpipe_group_process_device(self._g, arr))
+
+    def set_mean_line(self, m, pin=True):
+        m = np.ascontiguousarray(m, dtype=np.complex64)
+        self._check(self._lib.octpipe_group_set_mean_line(self._g, m.ctypes.data, 1 if pin else 0))
+
+    def synchronize(self):
+        self._check(self._lib.octpipe_group_synchronize(self._g))
+
+    def processed_host(self):
+        out = np.empty(self.S // 2, dtype=np.float32)
+        self._check(self._lib.octpipe_group_copy_processed_to_host(self._g, out.ctypes.data))
+        return out
+
+    @property
+    def handle(self):
+        return self._g
+
+    def close(self):
+        if self._g:
+            self._lib.octpipe_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    cleanupCuda = close
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

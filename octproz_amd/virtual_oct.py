@@ -162,6 +162,12 @@ class VirtualOCTSystem:
         rc = self._lib.octhost_processing_run(self._s, cb, None, int(max_buffers), float(max_seconds), C.byref(stats))
         return rc, stats
 
+    def run_group(self, group, max_buffers=0, max_seconds=0.0):
+        """the same loop with consume = octpipe_group_process (multi-GPU group)"""
+        stats = HostStats()
+        check(self._lib.octhost_processing_run_group(self._s, group.handle, int(max_buffers), float(max_seconds), C.byref(stats)))
+        return stats
+
     def run_pipeline(self, pipeline, max_buffers=0, max_seconds=0.0):
         stats = HostStats()
         check(self._lib.octhost_processing_run_pipeline(self._s, pipeline.handle, int(max_buffers), float(max_seconds), C.byref(stats)))

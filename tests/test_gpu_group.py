@@ -1,0 +1,112 @@
+"""The native multi-GPU group (octpipe_group_*, csrc/octpipe_group.hip): one host process, one buffer per call, B-scan slabs
+on several devices.  On the one-GPU test box the members share device 0 (copy path for the calibration blob) or the group has
+a single member (RCCL path: communicator, staging buffer and ncclBroadcast with one rank).  Invariant: the gathered output
+is identical, bit for bit, to one handle processing the whole buffer."""
+import numpy as np
+import pytest
+
+from octproz_amd import Pipeline, PipelineGroup, VirtualOCTSystem, synthetic_raw, v180_benchmark_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(p, raws):
+    import torch
+    q = Pipeline(p, device=0)
+    out = []
+    for r in raws:
+        d = torch.from_numpy(np.ascontiguousarray(r).view(np.int16)).to("cuda:0")
+        q.process_device(d.data_ptr()); q.synchronize()
+        out.append(q.processed_host().copy())
+    mean = q.mean_line()
+    q.close()
+    return out, mean
+
+
+@pytest.mark.parametrize("members,B", [(2, 8), (3, 10), (4, 6), (2, 2), (4, 2)])
+@pytest.mark.parametrize("flip", [0, 1])
+def test_group_on_one_device_equals_single_handle(members, B, flip):
+    N, A = 1024, 64
+    p = v180_benchmark_params(N, A, B)
+    p.bscanFlip = flip
+    raws = [synthetic_raw(N, A, B, seed=80 + i) for i in range(3)]
+    want, _ = _single(p, raws)
+    g = PipelineGroup(p, [0] * members)
+    assert g.backend == "copy" and g.size == members
+    slabs = [g.slab(i) for i in range(members)]
+    assert sum(n for _, n in slabs) == B and all(f % 2 == 0 for f, n in slabs if n)
+    for k, r in enumerate(raws):
+        g.octCudaPipeline(r)  # whole buffer in host memory: every member copies its own slab
+        g.synchronize()
+        assert np.array_equal(g.processed_host().view(np.uint32), want[k].view(np.uint32)), "buffer %d" % k
+    assert g.broadcasts == 1  # "once": the mean line is determined on the first buffer only (cu:1521)
+    g.close()
+
+
+def test_group_device_resident_slabs_and_continuous_fpn():
+    import torch
+    N, A, B = 512, 32, 8
+    p = v180_benchmark_params(N, A, B)
+    p.continuousFixedPatternNoiseDetermination = 1
+    raws = [synthetic_raw(N, A, B, seed=90 + i) for i in range(3)]
+    want, _ = _single(p, raws)
+    g = PipelineGroup(p, [0, 0])
+    for k, r in enumerate(raws):
+        d = torch.from_numpy(np.ascontiguousarray(r).view(np.int16)).to("cuda:0")
+        ptrs = [d.data_ptr() + g.slab(i)[0] * A * N * 2 for i in range(2)]
+        g.process_device(ptrs); g.synchronize()
+        assert np.array_equal(g.processed_host().view(np.uint32), want[k].view(np.uint32))
+    assert g.broadcasts == 3  # re-determined on every buffer -> re-broadcast every buffer
+    g.close()
+
+
+def test_group_redetermine_request_rebroadcasts():
+    N, A, B = 512, 32, 4
+    p = v180_benchmark_params(N, A, B)
+    raws = [synthetic_raw(N, A, B, seed=95 + i) for i in range(2)]
+    g = PipelineGroup(p, [0, 0])
+    g.octCudaPipeline(raws[0]); g.synchronize()
+    first = g.processed_host().copy()
+    g.octCudaPipeline(raws[1]); g.synchronize()
+    assert g.broadcasts == 1
+    p.redetermineFixedPatternNoise = 1
+    g.octCudaPipeline(raws[1]); g.synchronize()
+    assert g.broadcasts == 2
+    q = v180_benchmark_params(N, A, B)
+    want, _ = _single(q, [raws[1]])  # mean line determined on raws[1]
+    assert np.array_equal(g.processed_host().view(np.uint32), want[0].view(np.uint32))
+    assert not np.array_equal(first, want[0])
+    g.close()
+
+
+def test_single_member_group_uses_rccl():
+    """distinct devices -> RCCL communicator (ncclCommInitAll), staging buffers and a grouped ncclBroadcast, here with one rank"""
+    N, A, B = 1024, 32, 4
+    p = v180_benchmark_params(N, A, B)
+    raw = synthetic_raw(N, A, B, seed=99)
+    want, _ = _single(p, [raw])
+    g = PipelineGroup(p, [0])
+    assert g.backend == "rccl", "RCCL could not be bound or initialised: " + g.backend
+    g.octCudaPipeline(raw); g.synchronize()
+    assert g.broadcasts == 1
+    assert np.array_equal(g.processed_host().view(np.uint32), want[0].view(np.uint32))
+    g.close()
+
+
+def test_processing_loop_over_a_group():
+    """octhost_processing_run_group: the Processing::slot_start loop (processing.cpp:176-218) with a group as the consumer"""
+    N, A, B, n = 1024, 64, 8, 4
+    bufs = [synthetic_raw(N, A, B, seed=120 + i) for i in range(n)]
+    p = v180_benchmark_params(N, A, B)
+    want, mean = _single(p, bufs)
+    system = VirtualOCTSystem(12, N, A, B, data=np.concatenate([b.reshape(-1) for b in bufs]), buffers_from_file=n,
+                              copy_file_to_ram=True, sync_with_processing=True)
+    system.startAcquisition()
+    ring = system.buffer
+    g = PipelineGroup(p, [0, 0], ring.slot(0, np.uint16), ring.slot(1, np.uint16))
+    g._sync_params()
+    stats = system.run_group(g, max_buffers=2 * n + 1)
+    system.stopAcquisition()
+    assert stats.buffersProcessed == 2 * n + 1
+    assert np.array_equal(g.processed_host().view(np.uint32), want[(2 * n) % n].view(np.uint32))
+    g.close(); system.close()
