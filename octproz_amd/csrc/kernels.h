@@ -62,7 +62,7 @@ struct FusedArgs {
 // second pass) live in VGPRs for the whole persistent loop instead of being re-read from LDS for every A-scan; 8 waves
 // per workgroup (2 per SIMD, 256-register budget) instead of 15.
 #ifndef OCT_REGTAB
-#define OCT_REGTAB 0
+#define OCT_REGTAB 1
 #endif
 // OCT_PERM_EXCHANGE = 0: the exchange in front of the last radix-4 pass of the N = 1024 plan goes through LDS (packed twiddle
 // tables kept) instead of v_permlane32/16_swap.  OCT_REGTW3 = 1 (with OCT_REGTAB): the last pass' twiddles in VGPRs too.
@@ -70,30 +70,33 @@ struct FusedArgs {
 #define OCT_PERM_EXCHANGE 1
 #endif
 #ifndef OCT_REGTW3
-#define OCT_REGTW3 0
+#define OCT_REGTW3 1
 #endif
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
-template <> struct Cfg<10> { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = OCT_REGTAB ? 8 : 15; };
+template <> struct Cfg<10> { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 12; static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = OCT_REGTAB ? 8 : 15; };
 template <> struct Cfg<11> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 6; static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
 template <> struct Cfg<12> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 3; static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
 // per kernel variant: the cubic gather with precomputed weights trades waves for a larger table
 template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr bool CW = RS == RS_CUBIC && Cfg<LOG2N>::LDS_LUT && Cfg<LOG2N>::WAVES_CW > 0;
-	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::PLANAR) ? Cfg<LOG2N>::WAVES_ROLL : CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
 	static constexpr bool REGTAB = CW && LOG2N == 10 && OCT_REGTAB != 0;
-	static constexpr int MINW = (ROLL && Cfg<LOG2N>::PLANAR) ? (Cfg<LOG2N>::WAVES_ROLL + 3) / 4 : REGTAB ? 2 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
+	static constexpr int WAVES_PLAIN = CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
+	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
+	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0 && Cfg<LOG2N>::WAVES_ROLL < WAVES_PLAIN) ? Cfg<LOG2N>::WAVES_ROLL : WAVES_PLAIN;
+	static constexpr int MINW = REGTAB ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
+constexpr int ROLL_PAD = 128;  // largest window half-size served by the prefix-sum route; pads of the prefix array on both sides
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
 // LDS slice of one wave: the staged row (+ the prefix-sum array of the rolling average) and, later in
 // the iteration, the FFT exchange buffer: N complex padded by 1/16, or one float plane of that shape
 template <int N, bool ROLL = false> constexpr int wave_lds_bytes() {
 	constexpr int fft = (N + N / 16) * (Cfg<ilog2c(N)>::PLANAR ? 4 : 8);
-	constexpr int row = (N + 2 * ROW_OFF) * 4 + (ROLL ? N * 4 : 0);
+	constexpr int row = (N + 2 * ROW_OFF) * 4 + (ROLL ? (N + 2 * ROLL_PAD) * 4 : 0);
 	constexpr int m = fft > row ? fft : row;
 	return (m + 15) & ~15;
 }
@@ -156,6 +159,25 @@ OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 	}
 }
 
+// the four integer samples 4h..4h+3 of a uint16 chunk (after the optional >> 4), for the rolling-average prefix sums
+OCT_DEV uint4 chunk_to_uint(u32x4 c, int h, uint32_t s) {
+	const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
+	return uint4{(a & 0xffffu) >> s, (a >> 16) >> s, (b & 0xffffu) >> s, (b >> 16) >> s};
+}
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (no LDS, no bpermute)
+template <int CTRL, int ROW_MASK> OCT_DEV uint32_t dpp_add(uint32_t v) {
+	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+OCT_DEV uint32_t wave_inclusive_scan(uint32_t v) {
+	v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+	v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+	v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+	v = dpp_add<0x118, 0xF>(v);  // row_shr:8   -> inclusive scan inside every row of 16 lanes
+	v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+	v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+	return v;
+}
+
 // cu:258-271
 OCT_DEV float cubic_hermite(float y0, float y1, float y2, float y3, float pos) {
 	float a = -y0 + 3.0f * (y1 - y2) + y3;
@@ -192,7 +214,7 @@ constexpr int pad16c(int j) { return j + (j >> 4); }
 //   PACK == 2 (R = 16, NS = 16, one butterfly per lane): unit [c][k] = {w(2c, k), w(2c+1, k)}, c < 8, k = lane & 15
 //   PACK == 3 (R = 4, NS = 256, four butterflies per lane): unit [c][lane] = entries 2c, 2c+1 of the lane's
 //             12 twiddles, entry m*3 + t-1 = w(t, lane + 64 m)
-template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0, bool REGTW = false>
+template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0, bool REGTW = false, bool REGTW3 = false>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const f32x4* twr = nullptr) {
 	constexpr int P = N / 64, NB = P / R;
 	static_assert(NB >= 1, "radix larger than points per lane");
@@ -216,7 +238,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + lane;
 #pragma unroll
 		for (int c = 0; c < 6; c++) {
-			const f32x4 w = (REGTW && OCT_REGTW3) ? twr[8 + c] : tp[c * 64];
+			const f32x4 w = REGTW3 ? twr[8 + c] : tp[c * 64];
 			const int i0 = 2 * c, i1 = 2 * c + 1;
 			v[i0 / 3 + (i0 % 3 + 1) * NB] = octfft::cmul(v[i0 / 3 + (i0 % 3 + 1) * NB], f2{w.x, w.y});
 			v[i1 / 3 + (i1 % 3 + 1) * NB] = octfft::cmul(v[i1 / 3 + (i1 % 3 + 1) * NB], f2{w.z, w.w});
@@ -340,7 +362,7 @@ template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
 	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value;
 	return lane + 64 * m + u * (N / RL);
 }
-template <int LOG2N, bool PRUNE, bool REGTW = false>
+template <int LOG2N, bool PRUNE, bool REGTW = false, bool REGTW3 = false>
 OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane, const f32x4* twr = nullptr) {
 	constexpr int N = 1 << LOG2N;
 	typedef Plan<LOG2N> PL;
@@ -364,7 +386,7 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 		constexpr bool PX = OCT_PERM_EXCHANGE != 0;
 		fft_pass<N, R1, R0, true, !PX, false, 2, REGTW>(v, xbuf, tw, lane, twr);
 		if constexpr (PX) perm_exchange<P>(v);
-		fft_pass<N, R2, R0 * R1, !PX, false, PRUNE, 3, REGTW>(v, xbuf, tw + 8 * 16 * 2, lane, twr);
+		fft_pass<N, R2, R0 * R1, !PX, false, PRUNE, 3, REGTW, REGTW3>(v, xbuf, tw + 8 * 16 * 2, lane, twr);
 	} else if constexpr (R3 == 1) {
 		fft_pass<N, R1, R0, true, true, false>(v, xbuf, tw + T1, lane);
 		fft_pass<N, R2, R0 * R1, true, false, PRUNE>(v, xbuf, tw + T2, lane);
@@ -498,7 +520,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// REGTAB: the same table entries the LDS variant reads per A-scan, computed once per persistent wave
 	f32x4 cwR[REGTAB ? P : 1];
 	f2 wphR[REGTAB ? P : 1];
-	f32x4 tw2R[REGTAB ? (OCT_REGTW3 ? 14 : 8) : 1];
+	// the last pass' twiddles too where the register budget allows (plain uint16 kernel: 249 VGPRs, no spill)
+	constexpr bool TW3 = REGTAB && OCT_REGTW3 != 0 && !ROLL && INTYPE == IN_U16;
+	constexpr bool TW2 = REGTAB && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
+	f32x4 tw2R[TW2 ? (TW3 ? 14 : 8) : 1];
 	if constexpr (REGTAB) {
 #pragma unroll
 		for (int q = 0; q < P; q++) {
@@ -508,21 +533,88 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
 			cwR[q] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
 		}
+		if constexpr (TW2) {
 #pragma unroll
-		for (int c = 0; c < 8; c++) tw2R[c] = reinterpret_cast<const f32x4*>(tw)[c * 16 + (lane & 15)];
-		if constexpr (OCT_REGTW3 != 0) {
+			for (int c = 0; c < 8; c++) tw2R[c] = reinterpret_cast<const f32x4*>(tw)[c * 16 + (lane & 15)];
+		}
+		if constexpr (TW3) {
 #pragma unroll
 			for (int c = 0; c < 6; c++) tw2R[8 + c] = reinterpret_cast<const f32x4*>(tw)[8 * 16 + c * 64 + lane];
+		}
+	}
+	// rolling average: window lengths (and their reciprocals) of the lane's samples in the first and the last 256-sample chunk,
+	// the only ones a window of half-size <= ROLL_PAD can be clipped in; everywhere else the window holds 2 W samples
+	float rollCnt[ROLL ? 8 : 1], rollRc[ROLL ? 8 : 1];
+	if constexpr (ROLL) {
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const int j = 4 * lane + (e < 4 ? 0 : 256 * (NL - 1)) + (e & 3);
+			const int lo = max(0, j - a.rollingW + 1), hi = min(N - 1, j + a.rollingW);
+			rollCnt[e] = (float)(hi - lo + 1);
+			rollRc[e] = __fdiv_rn(1.0f, rollCnt[e]);
 		}
 	}
 	for (; line < a.numLines; line += wavesTotal) {
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
+			bool staged = false;
+			if constexpr (ROLL) {
+				// Rolling-average DC removal (cu:165-211): mean over [j-W+1, j+W] clipped to the A-scan.  The samples are integers
+				// <= 65535, so the reference's index-order float sum of up to 256 of them is exact (< 2^24) and equals an integer
+				// window sum.  For W <= ROLL_PAD the window sums come from one uint32 prefix-sum array per A-scan, built from the raw
+				// integers while they are still in registers (wave scan with DPP); the array is padded by W entries on both sides
+				// (0 in front, the total behind), so the clipped window [lo, hi] is P[j+W] - P[j-W] for every j without a clamp and
+				// every address is "lane base + immediate".  Each lane corrects the four consecutive samples it unpacked and the
+				// row is written once, already corrected.  The division is the exact IEEE quotient: with rc = RN(1/cnt),
+				// q0 = s rc, q = fma(fma(-q0, cnt, s), rc, q0) == RN(s / cnt) for all integer s < 2^24, cnt <= 256 (checked exhaustively,
+				// tests/test_luts.py), so the result is bit-identical to the ordered float loop.
+				const int W = a.rollingW;
+				if (W <= ROLL_PAD) {
+					staged = true;
+					uint32_t* pfx = reinterpret_cast<uint32_t*>(row + N + 2 * ROW_OFF);  // [ROLL_PAD | N | ROLL_PAD]
+					uint32_t base = 0;
 #pragma unroll
-			for (int i = 0; i < NL; i++) {
+					for (int i = 0; i < NL; i++) {
+						const uint4 x = chunk_to_uint(pre[i], 0, shift);
+						const uint32_t tot = x.x + x.y + x.z + x.w;
+						const uint32_t incl = wave_inclusive_scan(tot);
+						const uint32_t p0 = base + incl - tot + x.x, p1 = p0 + x.y, p2 = p1 + x.z;
+						*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + 4 * lane + 256 * i]) = uint4{p0, p1, p2, p2 + x.w};
+						base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+					}
+					// pads (the FFT exchange of the previous A-scan has run over them): 2 x 64 lanes x 2 entries on each side
+					*reinterpret_cast<uint2*>(&pfx[2 * lane]) = uint2{0u, 0u};
+					*reinterpret_cast<uint2*>(&pfx[ROLL_PAD + N + 2 * lane]) = uint2{base, base};
+					wave_sync_lds();
+					const uint32_t* hiP = pfx + ROLL_PAD + 4 * lane + W;      // P[j + W]
+					const uint32_t* loP = pfx + ROLL_PAD + 4 * lane - W;      // P[j - W]
+					const float cntIn = (float)(2 * W), rcIn = __fdiv_rn(1.0f, cntIn);
 #pragma unroll
-				for (int h = 0; h < SPL / 4; h++)
-					*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);
+					for (int i = 0; i < NL; i++) {
+						float o[4];
+						const uint4 x = chunk_to_uint(pre[i], 0, shift);  // (recomputed: cheaper than 16 live registers)
+						const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+						for (int c = 0; c < 4; c++) {
+							const float sum = (float)(hiP[256 * i + c] - loP[256 * i + c]);
+							float cnt = cntIn, rc = rcIn;
+							if (i == NL - 1) { cnt = rollCnt[4 + c]; rc = rollRc[4 + c]; }  // (NL == 1: the single chunk is clipped on both sides,
+							else if (i == 0) { cnt = rollCnt[c]; rc = rollRc[c]; }          //  its counts are the "last chunk" entries)
+							const float q0 = sum * rc;
+							const float q = __builtin_fmaf(__builtin_fmaf(-q0, cnt, sum), rc, q0);
+							o[c] = (float)xs[c] - q;
+						}
+						*reinterpret_cast<float4*>(&row[ROW_OFF + 4 * lane + 256 * i]) = float4{o[0], o[1], o[2], o[3]};
+					}
+				}
+			}
+			if (!staged) {
+#pragma unroll
+				for (int i = 0; i < NL; i++) {
+#pragma unroll
+					for (int h = 0; h < SPL / 4; h++)
+						*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);
+				}
 			}
 			const unsigned next = line + wavesTotal;  // prefetch the next row of this wave
 			if (next < a.numLines) {
@@ -545,61 +637,24 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 		wave_sync_lds();
 
-		// ---- rolling-average DC removal (cu:165-211): mean over [j-W+1, j+W] clipped to the A-scan
+		// ---- rolling average beyond the prefix-sum range: the reference's float accumulation in index order
 		if constexpr (ROLL) {
 			const int W = a.rollingW;
-			if (W <= 128) {
-				// The samples are integers <= 65535, so a float sum of up to 256 of them is exact whatever the
-				// order (< 2^24): the reference's index-order float sum equals an integer window sum, which
-				// comes from one uint32 prefix-sum array per A-scan (2 LDS reads per sample instead of 2W).
-				uint32_t* pfx = reinterpret_cast<uint32_t*>(row + N + 2 * ROW_OFF);
-				uint32_t incl[NL], tot[NL];
-#pragma unroll
-				for (int i = 0; i < NL; i++) {
-					const float4 x = *reinterpret_cast<const float4*>(&row[ROW_OFF + 4 * lane + 256 * i]);
-					tot[i] = incl[i] = (uint32_t)x.x + (uint32_t)x.y + (uint32_t)x.z + (uint32_t)x.w;
-				}
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-					for (int i = 0; i < NL; i++) {
-						const uint32_t y = (uint32_t)__shfl_up((int)incl[i], d, 64);
-						if (lane >= d) incl[i] += y;
-					}
-				}
-				uint32_t base = 0;
-#pragma unroll
-				for (int i = 0; i < NL; i++) {
-					const float4 x = *reinterpret_cast<const float4*>(&row[ROW_OFF + 4 * lane + 256 * i]);
-					const uint32_t p0 = base + incl[i] - tot[i] + (uint32_t)x.x, p1 = p0 + (uint32_t)x.y, p2 = p1 + (uint32_t)x.z;
-					*reinterpret_cast<uint4*>(&pfx[4 * lane + 256 * i]) = uint4{p0, p1, p2, p2 + (uint32_t)x.w};
-					base += (uint32_t)__builtin_amdgcn_readlane((int)incl[i], 63);
-				}
-				wave_sync_lds();
-				// every lane replaces only its own samples (the window sums come from pfx): in place
-#pragma unroll
-				for (int q = 0; q < P; q++) {
-					const int j = lane + 64 * q;
-					const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
-					const uint32_t sum = pfx[hi] - (lo > 0 ? pfx[lo - 1] : 0u);
-					rowl[64 * q] = rowl[64 * q] - __fdiv_rn((float)sum, (float)(hi - lo + 1));
-				}
-			} else {
-				// wide windows: the reference's float accumulation in index order
-				float r[P];
-#pragma unroll
+			if (W > ROLL_PAD) {
+				float* tmp = row + N + 2 * ROW_OFF;  // the prefix array's space: corrected samples, then copied back
+#pragma unroll 1
 				for (int q = 0; q < P; q++) {
 					const int j = lane + 64 * q;
 					const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
 					float sum = 0.0f;
 					for (int t = lo; t <= hi; t++) sum += row[ROW_OFF + t];
-					r[q] = rowl[64 * q] - __fdiv_rn(sum, (float)(hi - lo + 1));
+					tmp[j] = row[ROW_OFF + j] - __fdiv_rn(sum, (float)(hi - lo + 1));
 				}
 				wave_sync_lds();
-#pragma unroll
-				for (int q = 0; q < P; q++) rowl[64 * q] = r[q];
+#pragma unroll 1
+				for (int q = 0; q < P; q++) rowl[64 * q] = tmp[lane + 64 * q];
+				wave_sync_lds();
 			}
-			wave_sync_lds();
 		}
 		if constexpr (RS == RS_CUBIC) {
 			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
@@ -667,7 +722,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 
 		// ---- inverse FFT
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(2);
-		fft_wave<LOG2N, !SPECTRUM, REGTAB>(v, xbuf, tw, lane, tw2R);
+		fft_wave<LOG2N, !SPECTRUM, TW2, TW3>(v, xbuf, tw, lane, tw2R);
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(1);
 
 		if constexpr (SPECTRUM) {

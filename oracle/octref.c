@@ -37,6 +37,25 @@ void octref_set_num_threads(int n) {
 #endif
 }
 
+/* Checker for the rolling-average kernel's division (csrc/kernels.h): with rc = RN(1/c), q0 = s*rc,
+ * q = fma(fma(-q0, c, s), rc, q0) must equal the IEEE quotient RN(s/c) for integer window sums s < 2^24 and window
+ * lengths c <= 256.  Returns the number of (s, c) pairs, s = 0, stride, 2 stride, ..., for which it does not. */
+long octref_check_exact_division(int maxCount, unsigned stride) {
+	long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 1)
+	for (int c = 1; c <= maxCount; c++) {
+		const float fc = (float)c, rc = 1.0f / fc;
+		for (unsigned sidx = 0; sidx < (1u << 24); sidx += stride) {
+			const float fs = (float)sidx;
+			const float q0 = fs * rc;
+			const float e = fmaf(-q0, fc, fs);
+			const float q = fmaf(e, rc, q0);
+			if (q != fs / fc) bad++;
+		}
+	}
+	return bad;
+}
+
 /* ======================================================================================
  * Host-side curve generators
  * ====================================================================================*/

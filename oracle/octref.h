@@ -143,6 +143,7 @@ void octref_get_postproc_background_line(const octref_state* s, float* out, int 
 const octref_c32* octref_last_spectrum(const octref_state* s);
 int octref_num_threads(void);
 void octref_set_num_threads(int n);
+long octref_check_exact_division(int maxCount, unsigned stride);
 
 #ifdef __cplusplus
 }

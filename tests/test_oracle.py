@@ -201,3 +201,12 @@ def test_volume_view_index_map_from_first_principles():
         want[::-1, b + nr * B, :] = q[b].T  # z = W-1-r, y = a
     assert np.array_equal(vox, want)
     assert vox[W - 1, nr * B, 0] == 0 and vox[W - 2, nr * B, 0] == 255 and vox[W - 3, nr * B, 0] == 127
+
+
+def test_rolling_average_division_is_the_exact_quotient():
+    """the fused kernel divides the integer window sum by the window length with a reciprocal and one fma correction
+    (csrc/kernels.h); that is the IEEE quotient for every sum < 2^24 and every length <= 256 (exhaustive: 4.3e9 pairs)"""
+    import ctypes as C
+    L = octref.lib()
+    L.octref_check_exact_division.restype = C.c_long
+    assert L.octref_check_exact_division(256, 1) == 0

@@ -40,7 +40,7 @@ NOLDS = [
     # FFT
     ("for (int q = 0; q < P; q++) v[q] = rb[68 * q];", "for (int q = 0; q < P; q++) v[q] = opq2();"),
     ("const f32x4 w = REGTW ? twr[c] : tp[c * 16];", "const f32x4 w = opq4();"),
-    ("const f32x4 w = (REGTW && OCT_REGTW3) ? twr[8 + c] : tp[c * 64];", "const f32x4 w = opq4();"),
+    ("const f32x4 w = REGTW3 ? twr[8 + c] : tp[c * 64];", "const f32x4 w = opq4();"),
     ("for (int u = 0; u < R; u++) wb[pad16c(u * NS)] = v[m + u * NB];", "for (int u = 0; u < R; u++) sink2(v[m + u * NB]);"),
 ]
 NOVALU = [
