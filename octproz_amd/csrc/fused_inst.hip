@@ -2,6 +2,12 @@
 // (compiled once per OCT_LOG2N so the lengths build in parallel).
 #include "kernels.h"
 #include "launch.h"
+#if OCT_LOG2N == 8 || OCT_LOG2N == 9 || OCT_LOG2N == 11
+#define OCT_HAVE_REAL2N 1
+#include "real2n_kernel.h"
+#else
+#define OCT_HAVE_REAL2N 0
+#endif
 
 #ifndef OCT_LOG2N
 #error "compile with -DOCT_LOG2N=<8..12>"
@@ -71,6 +77,42 @@ hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool
 	case RS_CUBIC: return launch_out<IN_F32, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	default: return launch_out<IN_F32, RS_LANCZOS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	}
+}
+
+// real-input kernel of this length (real2n_kernel.h): uint16 input, no / linear / cubic resampling, no rolling average, no
+// dispersion compensation, image output.  hipErrorNotSupported where the length has none (1024 has its own, 4096 none).
+#if OCT_HAVE_REAL2N
+namespace {
+template <int RS, int MODE>
+hipError_t launch_real2n_one(const FusedArgs& a, hipStream_t stream) {
+	auto kernel = oct_real2n_kernel<kLog2N, RS, MODE>;
+	constexpr int waves = Real2Cfg<kLog2N>::WAVES;
+	constexpr size_t lds = real2n_lds_bytes<kLog2N>();
+	KernelLaunchInfo info;
+	hipError_t e = kernel_launch_info(kernel, waves * 64, lds, &info);
+	if (e != hipSuccess) return e;
+	const unsigned pairs = (a.numLines + 1u) / 2u;
+	const unsigned need = (pairs + waves - 1) / waves;
+	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);
+	if (blocks > need) blocks = need;
+	if (blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(waves * 64), lds, stream, a);
+	return hipGetLastError();
+}
+}  // namespace
+#endif
+hipError_t OCT_CAT(launch_real2n_, OCT_LOG2N)(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+#if OCT_HAVE_REAL2N
+	switch (rs) {
+	case RS_NONE: return logScale ? launch_real2n_one<RS_NONE, MODE_LOG>(a, stream) : launch_real2n_one<RS_NONE, 0>(a, stream);
+	case RS_LINEAR: return logScale ? launch_real2n_one<RS_LINEAR, MODE_LOG>(a, stream) : launch_real2n_one<RS_LINEAR, 0>(a, stream);
+	case RS_CUBIC: return logScale ? launch_real2n_one<RS_CUBIC, MODE_LOG>(a, stream) : launch_real2n_one<RS_CUBIC, 0>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
+#else
+	(void)rs; (void)logScale; (void)a; (void)stream;
+	return hipErrorNotSupported;
+#endif
 }
 
 // host-side description of the per-pass twiddle tables the kernel expects in FusedArgs::twiddle

@@ -40,6 +40,7 @@ hipError_t kernel_launch_info(K kernel, int threads, size_t ldsBytes, KernelLaun
 	hipError_t launch_fused_##L(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,              \
 	                            int requestedBlocks, hipStream_t stream, int* blocksUsed);                                   \
 	int fused_twiddle_plan_##L(int* radices);                                                                                \
+	hipError_t launch_real2n_##L(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);                             \
 	hipError_t launch_bluestein_##L(int rs, bool spectrum, bool logScale, const BluesteinArgs& a, hipStream_t stream);
 OCT_DECL_LAUNCH(8)
 OCT_DECL_LAUNCH(9)
@@ -51,6 +52,10 @@ OCT_DECL_LAUNCH(12)
 // N = 1024 / uint16 / image output without dispersion compensation (rs = RS_NONE, RS_LINEAR or RS_CUBIC): real FFT
 // input, two A-scans per complex transform (real2_kernel.h)
 hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
+
+// the other lengths with a real-input kernel (real2n_kernel.h)
+inline bool real2n_supported(int log2n) { return log2n == 8 || log2n == 9 || log2n == 11; }
+hipError_t launch_real2n(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 
 // power-of-two lengths run the direct FFT
 inline bool fused_supported(unsigned n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
@@ -71,6 +76,15 @@ inline hipError_t launch_fused(int log2n, int intype, int rs, bool roll, bool sp
 	case 11: return launch_fused_11(intype, rs, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	case 12: return launch_fused_12(intype, rs, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	default: return hipErrorInvalidValue;
+	}
+}
+
+inline hipError_t launch_real2n(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	switch (log2n) {
+	case 8: return launch_real2n_8(rs, logScale, a, stream);
+	case 9: return launch_real2n_9(rs, logScale, a, stream);
+	case 11: return launch_real2n_11(rs, logScale, a, stream);
+	default: return hipErrorNotSupported;
 	}
 }
 

@@ -317,9 +317,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		b.sA = a.sA;
 		b.sB = a.sB;
 		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
-	} else if (h->log2n == 10 && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum && !p.dispersionCompensation && !h->noReal2) {
+	} else if ((h->log2n == 10 || oct::real2n_supported(h->log2n)) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
+	           !p.dispersionCompensation && !h->noReal2) {
 		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
-		HIP_TRY(oct::launch_real2(rs, p.signalLogScaling != 0, a, h->stream));
+		if (h->log2n == 10) HIP_TRY(oct::launch_real2(rs, p.signalLogScaling != 0, a, h->stream));
+		else HIP_TRY(oct::launch_real2n(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
 	} else {
 		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, nullptr));
 	}

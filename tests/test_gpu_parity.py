@@ -206,6 +206,25 @@ def test_real_input_kernel_matches_oracle(case, A, B):
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("N", [256, 512, 2048])
+@pytest.mark.parametrize("case", list(REAL_INPUT_CASES))
+@pytest.mark.parametrize("A,B", [(24, 3), (7, 3), (1, 1)])
+def test_real_input_kernel_on_the_other_lengths(N, case, A, B):
+    """real2n_kernel.h: the same two-A-scans-per-transform scheme on the 4.4.4.4, 8.8.8 and (planar) 16.16.8 plans; and it
+    must agree with the general kernel of that length (OCTPIPE_NO_REAL2 route is covered by the chain tests) within tolerance"""
+    p = v180_benchmark_params(N, A, B)
+    REAL_INPUT_CASES[case](p)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + A * 10 + B)
+    if case == "bitshift":
+        raw = (raw.astype(np.uint32) * 16).astype(np.uint16)
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "real input %s N=%d %dx%d" % (case, N, A, B))
+    pipe.close(); o.close()
+
+
 @pytest.mark.parametrize("N", [256, 512, 2048, 4096])
 @pytest.mark.parametrize("case", ["linear", "lanczos", "rolling8", "rolling64_linear", "lin_scale", "flip", "nothing"])
 def test_chain_variants_on_the_other_lengths(N, case):
@@ -614,6 +633,11 @@ def test_full_size_real_input_kernel_1024x512x256():
     log(0) = -inf appears there on one side or the other depending on the last bit; compare_images treats -inf as the
     power 0 it stands for, so such a bin is held to the same linear-power tolerance as every other one."""
     _full_size(1024, 512, 256, dispersionCompensation=0)
+
+
+def test_full_size_real_input_kernel_config3_slab():
+    """config 3's length on the default-style settings: real-input kernel of N = 2048 on a 2048 x 1024 x 64 slab"""
+    _full_size(2048, 1024, 64, sample_lines=1024, dispersionCompensation=0)
 
 
 def test_full_size_config3_2048x1024x512():
