@@ -57,6 +57,10 @@ hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t s
 inline bool real2n_supported(int log2n) { return log2n == 8 || log2n == 9 || log2n == 11; }
 hipError_t launch_real2n(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 
+// N = 1664 = 32 x 4 x 13 (the reference recording's length): mixed-radix transform in registers (mixed1664.h)
+constexpr unsigned kMixedLength = 1664;
+hipError_t launch_mixed1664(int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream);
+
 // power-of-two lengths run the direct FFT
 inline bool fused_supported(unsigned n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
 // every other length up to 2048 runs Bluestein on the padded length 2^log2m >= 2n-1 (log2m in 8..12)

@@ -1,0 +1,255 @@
+// mixed1664.h -- the fused A-scan chain for N = 1664 = 32 x 4 x 13 samples per A-scan, the native length of the reference's
+// own test recording (performance/v100/performance_v100.md:101; cuFFT takes any length, cuda_code.cu:1140).  A mixed-radix
+// transform in registers instead of Bluestein's two padded 4096-point transforms (bluestein.h).
+//
+//   X[k] = sum_n x[n] e^{+2 pi i nk/N},   n = 52 n1 + n2 (n1 < 32, n2 < 52),   k = k1 + 32 k2 (k1 < 32, k2 < 52)
+//        = sum_n2 W_52^{n2 k2} [ W_1664^{n2 k1} sum_n1 x[52 n1 + n2] W_32^{n1 k1} ]                        (Cooley-Tukey 32 x 52)
+//   the 52-point transforms by the prime-factor map (gcd(4, 13) = 1, no twiddles):
+//        n2 = (13 a + 4 b) mod 52,  k2 = (13 c + 40 d) mod 52   ->   sum_a i^{ac} sum_b W_13^{bd} y[a][b]
+//
+// One wave64 per A-scan:
+//   A  lane n2 (52 lanes busy, the rest duplicate lane 51) gathers its 32 resampled, windowed, phase-corrected samples
+//      x[52 n1 + n2] from the staged row and transforms them in registers (two radix-16 transforms + one radix-2 step),
+//   B  multiplies by W_1664^{n2 k1} (table in LDS) and writes T[k1][n2] to the wave's LDS slice (pitch 54: the writes are
+//      unit-stride, the reads below hit 32 different banks per half wave),
+//   C  lane 2 k1 + h reads the 26 values y[a][b], a in {h, h+2}: two 13-point transforms in registers (real-symmetric form,
+//      102 packed operations each), the radix-2 step over (a, a+2) in the lane, and the last radix-2 step between the two
+//      lanes of a pair as ONE DPP multiply-add per component (v_fmac_f32 quad_perm:[1,0,3,2]): lane h = 0 ends with
+//      X[c = 0, 1][d], lane h = 1 with -X[c = 2, 3][d] (the sign is undone where it matters: the mean line of those bins is
+//      loaded negated, |.|^2 does not see it, the spectrum output multiplies it back).
+//   Only bins k < N/2 are kept: k2(c + 2, d) = k2(c, d) + 26, so for every (c, d) exactly one lane of a pair stores.
+// Algorithmic HBM traffic as for the other lengths: 2 N bytes in (uint16), 2 N bytes out.
+#pragma once
+#include "kernels.h"
+
+namespace oct {
+
+constexpr int MR_N = 1664, MR_N1 = 32, MR_N2 = 52, MR_PITCH = 54, MR_WAVES = 8;
+constexpr int MR_TABLE_BYTES = MR_N * 4 + MR_N * 8 + MR_N1 * MR_N2 * 8;                 // rho | window*phasor | W_1664^{n2 k1}
+constexpr int MR_SLICE_BYTES = MR_N1 * MR_PITCH * 8;                                    // T[32][54] complex >= the staged row
+constexpr int MR_LDS_BYTES = MR_TABLE_BYTES + MR_WAVES * MR_SLICE_BYTES;
+static_assert((MR_N + 2 * ROW_OFF + 256) * 4 <= MR_SLICE_BYTES, "staged row (plus the overshoot of the last chunk) fits the slice");
+static_assert(MR_LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
+
+namespace mr {
+
+// exp(+2 pi i m / 32), m = 0..15
+__device__ constexpr float kCos32[16] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                                         0.55557023301960222f, 0.38268343236508977f, 0.19509032201612827f, 0.0f, -0.19509032201612827f,
+                                         -0.38268343236508977f, -0.55557023301960222f, -0.70710678118654752f, -0.83146961230254524f,
+                                         -0.92387953251128674f, -0.98078528040323044f};
+__device__ constexpr float kSin32[16] = {0.0f, 0.19509032201612827f, 0.38268343236508977f, 0.55557023301960222f, 0.70710678118654752f,
+                                         0.83146961230254524f, 0.92387953251128674f, 0.98078528040323044f, 1.0f, 0.98078528040323044f,
+                                         0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960222f,
+                                         0.38268343236508977f, 0.19509032201612827f};
+// cos / sin (2 pi m / 13), m = 0..12
+__device__ constexpr float kCos13[13] = {1.0f, 0.88545602565320989f, 0.56806474673115580f, 0.12053668025532305f, -0.35460488704253562f,
+                                         -0.74851074817110110f, -0.97094181742605202f, -0.97094181742605202f, -0.74851074817110110f,
+                                         -0.35460488704253562f, 0.12053668025532305f, 0.56806474673115580f, 0.88545602565320989f};
+__device__ constexpr float kSin13[13] = {0.0f, 0.46472317204376854f, 0.82298386589365640f, 0.99270887409805400f, 0.93501624268541483f,
+                                         0.66312265824079520f, 0.23931566428755777f, -0.23931566428755777f, -0.66312265824079520f,
+                                         -0.93501624268541483f, -0.99270887409805400f, -0.82298386589365640f, -0.46472317204376854f};
+
+// in-place inverse 32-point transform of v[0..31] (natural order in and out): even / odd samples by the radix-16 kernel of
+// fft_regs.h (stride 2), then X[k] = E[k] + w^k O[k], X[k + 16] = E[k] - w^k O[k]
+OCT_DEV void dft32(f2 (&v)[32]) {
+	octfft::Dft<16, 2, false>::run(&v[0]);
+	octfft::Dft<16, 2, false>::run(&v[1]);
+	f2 o[32];
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const f2 e = v[2 * k], d = v[2 * k + 1];
+		f2 t;
+		if (k == 0) t = d;
+		else if (k == 8) t = f2{-d.y, d.x};
+		else t = f2{d.x * kCos32[k] - d.y * kSin32[k], d.x * kSin32[k] + d.y * kCos32[k]};
+		o[k] = e + t;
+		o[k + 16] = e - t;
+	}
+#pragma unroll
+	for (int k = 0; k < 32; k++) v[k] = o[k];
+}
+
+// inverse 13-point transform, x[0..12] -> X[0..12]:  X[d] = A_d + i B_d,  X[13-d] = A_d - i B_d  with
+// A_d = x0 + sum_j (x_j + x_{13-j}) cos(2 pi j d / 13),  B_d = sum_j (x_j - x_{13-j}) sin(2 pi j d / 13),  j = 1..6
+OCT_DEV void dft13(const f2 (&x)[13], f2 (&X)[13]) {
+	f2 a[7], b[7];
+#pragma unroll
+	for (int j = 1; j <= 6; j++) { a[j] = x[j] + x[13 - j]; b[j] = x[j] - x[13 - j]; }
+	X[0] = x[0] + ((a[1] + a[2]) + (a[3] + a[4])) + (a[5] + a[6]);
+#pragma unroll
+	for (int d = 1; d <= 6; d++) {
+		f2 A = x[0], B = f2{0.0f, 0.0f};
+#pragma unroll
+		for (int j = 1; j <= 6; j++) {
+			const int m = (j * d) % 13;
+			A += a[j] * kCos13[m];
+			B += b[j] * kSin13[m];
+		}
+		X[d] = octfft::add_i(A, B);
+		X[13 - d] = octfft::sub_i(A, B);
+	}
+}
+
+// value of the other lane of the pair (lane ^ 1) times s, added to acc:  acc + s * partner   (one v_fmac_f32 with DPP)
+OCT_DEV float pair_fma(float acc, float v, float s) {
+	const float p = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false));
+	return __builtin_fmaf(p, s, acc);
+}
+
+}  // namespace mr
+
+// INTYPE: IN_U16 (raw) or IN_F32 (prepared by oct_prepare_kernel: other containers / formats, rolling average).
+// RS: RS_NONE / RS_LINEAR / RS_CUBIC (Lanczos at this length stays on the Bluestein path).  MODE: MODE_SPECTRUM, MODE_LOG.
+template <int INTYPE, int RS, int MODE>
+__global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const FusedArgs a) {
+	constexpr int N = MR_N, N1 = MR_N1, N2 = MR_N2, THREADS = MR_WAVES * 64;
+	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
+	constexpr int CB = INTYPE == IN_U16 ? 8 : 16, NL = 7;  // 4 samples per lane and load: 7 x 256 >= 1664
+	static_assert(RS != RS_LANCZOS, "Lanczos: Bluestein path");
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float* rhoL = reinterpret_cast<float*>(smem);
+	f2* wphL = reinterpret_cast<f2*>(smem + N * 4);
+	f2* twB = reinterpret_cast<f2*>(smem + N * 12);
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	char* wbase = smem + MR_TABLE_BYTES + wave * MR_SLICE_BYTES;
+	float* row = reinterpret_cast<float*>(wbase);
+	f2* T = reinterpret_cast<f2*>(wbase);
+
+	for (int i = tid; i < N; i += THREADS) {
+		const float4 t = a.lut[i];
+		rhoL[i] = t.x;
+		wphL[i] = f2{t.y * t.z, t.y * t.w};  // window folded into the phasor
+	}
+	for (int i = tid; i < N1 * N2; i += THREADS) twB[i] = a.twiddle[i];  // [k1][n2]
+	__syncthreads();
+
+	const int n2 = lane < N2 ? lane : N2 - 1;  // lanes 52..63 duplicate lane 51 (same values to the same addresses)
+	const int k1 = lane >> 1, h = lane & 1;    // stage C: transform k1, half h of it
+	const float sg = h ? -1.0f : 1.0f;
+	// stage-C read addresses: y[a][b] = T[k1][(13 (h + 2 ai) + 4 b) mod 52]; with C = (26 ai + 4 b) mod 52 the index is
+	// C + 13 h, minus 52 when that passes 51: two lane bases (wrapped / not wrapped) + a compile-time offset per read
+	const f2* Tk = T + k1 * MR_PITCH;
+	const f2* baseNoWrap = Tk + 13 * h;
+	const f2* baseWrap = Tk + 13 * h - 52 * h;  // h = 0 never wraps: both bases coincide
+	// kept bins: for (ci, d) bin k = k1 + 32 (k2 mod 26), k2 = (13 ci + 40 d) mod 52, stored by lane h = (k2 >= 26)
+	f2 meanR[SPECTRUM ? 1 : 26];
+	if constexpr (!SPECTRUM) {
+#pragma unroll
+		for (int ci = 0; ci < 2; ci++)
+#pragma unroll
+			for (int d = 0; d < 13; d++) {
+				const int k2 = (13 * ci + 40 * d) % 52;
+				const bool mine = (k2 >= 26) == (h == 1);
+				meanR[ci * 13 + d] = (a.subtractMean && mine) ? a.meanLine[k1 + 32 * (k2 % 26)] * sg : f2{0.0f, 0.0f};
+			}
+	}
+
+	const unsigned wavesTotal = gridDim.x * (unsigned)MR_WAVES;
+	unsigned line = blockIdx.x * (unsigned)MR_WAVES + (unsigned)wave;
+	const unsigned rowBytes = (unsigned)N * (INTYPE == IN_U16 ? 2u : 4u);
+	const uint32_t shift = a.bitshift ? 4u : 0u;
+	u32x4 pre[NL];
+	auto prefetch = [&](unsigned ln) {
+		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * rowBytes, rowBytes);  // reads past the row give 0
+#pragma unroll
+		for (int i = 0; i < NL; i++) {
+			if constexpr (INTYPE == IN_U16) { const u32x2 t = buf_load64(rawR, lane * CB, i * 64 * CB); pre[i] = u32x4{t.x, t.y, 0u, 0u}; }
+			else pre[i] = __builtin_bit_cast(u32x4, buf_load128(rawR, lane * CB, i * 64 * CB));
+		}
+	};
+	if (line < a.numLines) prefetch(line);
+
+	for (; line < a.numLines; line += wavesTotal) {
+		// ---- stage the row in LDS as float32 (the last chunk overshoots the row inside the slice: harmless)
+#pragma unroll
+		for (int i = 0; i < NL; i++)
+			*reinterpret_cast<float4*>(&row[ROW_OFF + 4 * lane + 256 * i]) = chunk_to_float<INTYPE>(pre[i], 0, INTYPE == IN_U16 ? shift : 0u);
+		if (line + wavesTotal < a.numLines) prefetch(line + wavesTotal);
+		wave_sync_lds();
+		if constexpr (RS == RS_CUBIC) {
+			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
+			wave_sync_lds();
+		}
+
+		// ---- stage A: gather x[52 n1 + n2] (k-linearisation x window x phasor), 32-point transform over n1
+		__builtin_amdgcn_s_setprio(3);
+		f2 v[32];
+#pragma unroll
+		for (int q = 0; q < N1; q++) {
+			const int j = N2 * q + n2;
+			float y;
+			if constexpr (RS == RS_NONE) {
+				y = row[ROW_OFF + j];
+			} else {
+				const float rho = rhoL[j];
+				const int n1 = (int)rho;
+				const float frac = __builtin_amdgcn_fractf(rho);  // rho >= 0: == rho - (float)n1 exactly
+				const float* t = row + ROW_OFF - 1 + n1;
+				if constexpr (RS == RS_CUBIC) y = cubic_hermite(t[0], t[1], t[2], t[3], frac);
+				else y = t[1] + (t[2] - t[1]) * frac;
+			}
+			v[q] = wphL[j] * y;
+		}
+		wave_sync_lds();  // the row is dead from here on
+		__builtin_amdgcn_s_setprio(2);
+		mr::dft32(v);
+		// ---- stage B: twiddle, transpose through LDS
+#pragma unroll
+		for (int q = 1; q < N1; q++) v[q] = octfft::cmul(v[q], twB[q * N2 + n2]);
+#pragma unroll
+		for (int q = 0; q < N1; q++) T[q * MR_PITCH + n2] = v[q];
+		wave_sync_lds();
+
+		// ---- stage C: two 13-point transforms over b, radix 2 over (a, a+2) in the lane, radix 2 across the lane pair
+		f2 Y0[13], Y1[13];
+		{
+			f2 y[13];
+#pragma unroll
+			for (int b = 0; b < 13; b++) { constexpr int ai = 0; const int C = (26 * ai + 4 * b) % 52; y[b] = (C + 13 >= 52 ? baseWrap : baseNoWrap)[C]; }
+			mr::dft13(y, Y0);
+#pragma unroll
+			for (int b = 0; b < 13; b++) { constexpr int ai = 1; const int C = (26 * ai + 4 * b) % 52; y[b] = (C + 13 >= 52 ? baseWrap : baseNoWrap)[C]; }
+			mr::dft13(y, Y1);
+		}
+		wave_sync_lds();
+		__builtin_amdgcn_s_setprio(1);
+
+		unsigned orow = line;
+		if (a.flip) {
+			const unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
+			if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
+		}
+		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
+		const __amdgpu_buffer_rsrc_t specR = make_rsrc(a.spectrum + (size_t)line * N, N * 8u);
+		// lane offsets of the stores: this lane's k1 when its half is the one that keeps the bin, far out of range otherwise
+		// (a buffer store beyond the descriptor's size is dropped)
+		const int offEven = h == 0 ? k1 * 4 : 0x40000000, offOdd = h == 1 ? k1 * 4 : 0x40000000;
+#pragma unroll
+		for (int d = 0; d < 13; d++) {
+			const f2 s = Y0[d] + Y1[d], dd = Y0[d] - Y1[d];
+			const f2 w = h ? f2{-dd.y, dd.x} : dd;  // lane 1 contributes i (y1 - y3)
+			// lane 0: X[c=0] = s0 + s1, X[c=1] = d0 + i d1;   lane 1: -X[c=2] = s1 - s0, -X[c=3] = i d1 - d0
+			const f2 o[2] = {f2{mr::pair_fma(s.x, s.x, sg), mr::pair_fma(s.y, s.y, sg)}, f2{mr::pair_fma(w.x, w.x, sg), mr::pair_fma(w.y, w.y, sg)}};
+#pragma unroll
+			for (int ci = 0; ci < 2; ci++) {
+				const int k2 = (13 * ci + 40 * d) % 52;  // of lane 0; lane 1 holds k2 + 26 (mod 52)
+				if constexpr (SPECTRUM) {
+					const f2 z = o[ci] * sg;
+					const int kk = k1 + 32 * (h ? (k2 + 26) % 52 : k2);
+					__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, z), specR, kk * 8, 0, 0);
+				} else {
+					const f2 z = o[ci] - meanR[ci * 13 + d];
+					const float p = z.x * z.x + z.y * z.y;
+					const float f = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
+					buf_store32(a.sA * f + a.sB, outR, k2 >= 26 ? offOdd : offEven, 32 * (k2 % 26) * 4);
+				}
+			}
+		}
+		__builtin_amdgcn_s_setprio(0);
+		wave_sync_lds();
+	}
+}
+
+}  // namespace oct

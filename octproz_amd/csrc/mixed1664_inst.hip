@@ -1,0 +1,45 @@
+// mixed1664_inst.hip -- instantiates the mixed-radix kernel for N = 1664 (mixed1664.h)
+#include "launch.h"
+#include "mixed1664.h"
+
+namespace oct {
+
+namespace {
+template <int INTYPE, int RS, int MODE>
+hipError_t launch_mixed_one(const FusedArgs& a, hipStream_t stream) {
+	auto kernel = oct_mixed1664_kernel<INTYPE, RS, MODE>;
+	KernelLaunchInfo info;
+	hipError_t e = kernel_launch_info(kernel, MR_WAVES * 64, MR_LDS_BYTES, &info);
+	if (e != hipSuccess) return e;
+	const unsigned need = (a.numLines + MR_WAVES - 1) / MR_WAVES;
+	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);
+	if (blocks > need) blocks = need;
+	if (blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MR_WAVES * 64), MR_LDS_BYTES, stream, a);
+	return hipGetLastError();
+}
+template <int INTYPE, int RS>
+hipError_t launch_mixed_out(bool spectrum, bool logScale, const FusedArgs& a, hipStream_t st) {
+	if (spectrum) return launch_mixed_one<INTYPE, RS, MODE_SPECTRUM>(a, st);
+	if (logScale) return launch_mixed_one<INTYPE, RS, MODE_LOG>(a, st);
+	return launch_mixed_one<INTYPE, RS, 0>(a, st);
+}
+template <int INTYPE>
+hipError_t launch_mixed_rs(int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t st) {
+	switch (rs) {
+	case RS_NONE: return launch_mixed_out<INTYPE, RS_NONE>(spectrum, logScale, a, st);
+	case RS_LINEAR: return launch_mixed_out<INTYPE, RS_LINEAR>(spectrum, logScale, a, st);
+	case RS_CUBIC: return launch_mixed_out<INTYPE, RS_CUBIC>(spectrum, logScale, a, st);
+	default: return hipErrorInvalidValue;  // Lanczos: Bluestein path
+	}
+}
+}  // namespace
+
+// intype: IN_U16 or IN_F32 (prepared); rs: RS_NONE / RS_LINEAR / RS_CUBIC; FusedArgs::twiddle = W_1664^{n2 k1} as [k1][n2]
+hipError_t launch_mixed1664(int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (intype == IN_U16) return launch_mixed_rs<IN_U16>(rs, spectrum, logScale, a, stream);
+	if (intype == IN_F32) return launch_mixed_rs<IN_F32>(rs, spectrum, logScale, a, stream);
+	return hipErrorInvalidValue;
+}
+
+}  // namespace oct

@@ -78,6 +78,9 @@ struct octpipe {
 	float* d_dispBscan = nullptr;
 	float* d_dispEnFace = nullptr;
 	uint8_t* d_volumeView = nullptr;  // [N/2][B*buffersPerVolume][A] uint8, lazily (cu:914-941 into a plain buffer)
+	bool mixed = false;        // samplesPerLine == 1664: mixed-radix kernel (mixed1664.h); Bluestein stays for Lanczos
+	float4* d_lutPlain = nullptr;  // mixed: the LUT without the Bluestein chirp folded in
+	f2* d_twMixed = nullptr;       // mixed: W_1664^{n2 k1}, [32][52]
 	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
 	f2* d_filter = nullptr;    // [M] Bluestein filter spectrum
 	f2* d_outChirp = nullptr;  // [N] c[k] / M
@@ -142,7 +145,7 @@ int gridFor(size_t n, int block = 256) {
 // exactly what the reference's 8-way kernel selection does (cu:1448-1511): x*1.0f == x.
 int uploadLut(octpipe* h) {
 	const int N = h->N;
-	std::vector<float4> lut(N);
+	std::vector<float4> lut(N), plain(h->mixed ? N : 0);
 	const OctPipeParams& p = h->params;
 	for (int j = 0; j < N; ++j) {
 		float rho = p.resampling ? h->resample[j] : (float)j;
@@ -155,6 +158,7 @@ int uploadLut(octpipe* h) {
 		e.y = p.windowing ? h->window[j] : 1.0f;
 		e.z = p.dispersionCompensation ? h->phase[2 * j] : 1.0f;
 		e.w = p.dispersionCompensation ? h->phase[2 * j + 1] : 0.0f;
+		if (h->mixed) plain[j] = e;
 		if (h->bluestein) {  // fold the input chirp c[j] = e^{+i pi j^2 / N} into the phasor (float64 product)
 			const double ang = 3.14159265358979323846 * (double)(((long long)j * j) % (2LL * N)) / (double)N;
 			const double cr = cos(ang), ci = sin(ang), pr = e.z, pi = e.w;
@@ -164,6 +168,7 @@ int uploadLut(octpipe* h) {
 		lut[j] = e;
 	}
 	HIP_TRY(hipMemcpyAsync(h->d_lut, lut.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
+	if (h->mixed) HIP_TRY(hipMemcpyAsync(h->d_lutPlain, plain.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));  // lut is a stack vector
 	h->lutDirty = false;
 	return OCTPIPE_OK;
@@ -232,6 +237,21 @@ int uploadBluesteinTables(octpipe* h) {
 	return OCTPIPE_OK;
 }
 
+// twiddles between the 32-point and the 52-point stage of the N = 1664 plan: W^{n2 k1}, W = e^{+2 pi i / 1664}, as [k1][n2]
+int uploadMixedTables(octpipe* h) {
+	const int N = 1664, N1 = 32, N2 = 52;
+	std::vector<f2> tw((size_t)N1 * N2);
+	for (int k1 = 0; k1 < N1; ++k1)
+		for (int n2 = 0; n2 < N2; ++n2) {
+			const double ang = 2.0 * 3.14159265358979323846 * (double)((k1 * n2) % N) / (double)N;
+			tw[(size_t)k1 * N2 + n2] = f2{(float)cos(ang), (float)sin(ang)};
+		}
+	HIP_TRY(hipMalloc((void**)&h->d_twMixed, sizeof(f2) * tw.size()));
+	HIP_TRY(hipMemcpy(h->d_twMixed, tw.data(), sizeof(f2) * tw.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&h->d_lutPlain, sizeof(float4) * N));
+	return OCTPIPE_OK;
+}
+
 // bytes of one raw buffer: S * bytesPerSample, 1.5 B/sample for the packed formats
 size_t rawBytes(const octpipe* h) {
 	switch (h->sampleFormat) {
@@ -260,7 +280,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		   : p.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS ? oct::RS_LANCZOS : oct::RS_LINEAR;
 	}
 	a.raw = d_raw;
-	if (needsPrepared(h)) {
+	// N = 1664: the mixed-radix kernel takes uint16 directly; other containers / formats and the rolling average come prepared
+	const bool useMixed = h->mixed && rs != oct::RS_LANCZOS;
+	const bool mixedDirect = useMixed && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
+	if (needsPrepared(h) && !mixedDirect) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
 		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(h->S)), dim3(256), 0, h->stream, d_raw, h->d_prepared,
@@ -298,7 +321,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (h->bluestein) {
+	if (useMixed) {
+		a.lut = h->d_lutPlain;
+		a.twiddle = h->d_twMixed;
+		HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
+	} else if (h->bluestein) {
 		oct::BluesteinArgs b{};
 		b.samples = h->d_prepared;
 		b.out = out;
@@ -591,6 +618,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	if (!oct::fused_supported(acq->samplesPerLine)) {
 		h->bluestein = true;
 		h->log2n = oct::bluestein_log2m(acq->samplesPerLine);
+		h->mixed = acq->samplesPerLine == oct::kMixedLength && getenv("OCTPIPE_NO_MIXED") == nullptr;  // (A/B switch: Bluestein for 1664 too)
 	}
 	h->resample.assign(h->N, 0.0f);
 	h->dispersion.assign(h->N, 0.0f);
@@ -617,6 +645,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	if ((rc = ensure((void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
 	if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
+	if (h->mixed && (rc = uploadMixedTables(h))) return rc;
 	{  // cu:1093
 		std::vector<float> sc((size_t)h->A);
 		octhost::sinusoidal_curve((unsigned)h->A, sc.data());
@@ -650,7 +679,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp};
+	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed};
 	for (void* b : bufs) if (b) hipFree(b);
 	if (h->copyStream) hipStreamDestroy(h->copyStream);
 	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);

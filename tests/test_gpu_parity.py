@@ -277,6 +277,57 @@ def test_non_power_of_two_lengths_bluestein(N, interp):
     pipe.close(); o.close()
 
 
+MIXED_CASES = ["v180", "linear", "no_dispersion", "no_window", "resample_only", "window_dispersion_only", "nothing", "rolling8",
+               "rolling64_linear", "lin_scale", "scale_coeff_addend", "flip", "no_fpn", "gauss_window"]
+
+
+@pytest.mark.parametrize("case", MIXED_CASES)
+@pytest.mark.parametrize("A,B", [(24, 3), (7, 3)])
+def test_mixed_radix_1664_chain_matches_oracle(case, A, B):
+    """N = 1664 = 32 x 4 x 13 (the reference recording's length) runs the mixed-radix kernel (mixed1664.h): image and full
+    spectrum against the oracle's O(N^2) float64 DFT; ragged line counts; the rolling-average cases take the prepared
+    float32 route of the same kernel"""
+    if (A, B) != (24, 3) and case not in ("v180", "flip", "nothing"):
+        pytest.skip("ragged line count on three cases only")
+    N = 1664
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    CASES[case](p)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=1664 + len(case))
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "N=1664 %s" % case)
+    if not p.bscanFlip:
+        spec = pipe.debug_spectrum(d.data_ptr(), A * B)
+        ospec = o.last_spectrum().reshape(-1, N).copy()
+        if p.fixedPatternNoiseRemoval:
+            ospec[:, :N // 2] += o.mean_line()[:N // 2]
+        common.compare_spectra(spec, ospec, N, case)
+    pipe.close(); o.close()
+
+
+def test_mixed_radix_1664_agrees_with_the_bluestein_route(monkeypatch):
+    """the same settings through both transforms of this length (OCTPIPE_NO_MIXED=1 keeps Bluestein): same image within the
+    float tolerance, and the other sample containers go through the prepared route of the mixed kernel"""
+    N, A, B = 1664, 24, 2
+    p = v180_benchmark_params(N, A, B)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=5)
+    o, pipe, d, want, got = run_both(p, raw)
+    monkeypatch.setenv("OCTPIPE_NO_MIXED", "1")
+    blue = Pipeline(p, device=0)
+    monkeypatch.delenv("OCTPIPE_NO_MIXED")
+    blue.set_mean_line(o.mean_line(), pin=True)
+    blue.process_device(d.data_ptr()); blue.synchronize()
+    common.compare_images(blue.processed_host(), want, p, "bluestein")
+    common.compare_images(got, blue.processed_host(), p, "mixed vs bluestein")
+    assert not np.array_equal(got, blue.processed_host())  # two different transforms really ran
+    pipe.debug_force_prepared(True)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    assert np.array_equal(pipe.processed_host().view(np.uint32), got.view(np.uint32))  # prepared float32 route == uint16 route
+    pipe.close(); blue.close(); o.close()
+
+
 def test_non_power_of_two_fpn_determination_and_flip():
     N, A, B = 1664, 24, 4
     p = v180_benchmark_params(N, A, B)
