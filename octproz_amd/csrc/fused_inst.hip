@@ -71,6 +71,22 @@ hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool
 		}
 	}
 	if (roll) return hipErrorInvalidValue;
+#if OCT_LOG2N >= 9
+	// packed 12-bit rows read straight from the raw buffer (1.5 B per sample); N = 256 holds half a chunk per lane: prepared route
+	if (intype == IN_P12U || intype == IN_P12S) {
+		if (rs == RS_LANCZOS) return hipErrorInvalidValue;
+		const bool sgn = intype == IN_P12S;
+		switch (rs) {
+		case RS_NONE: return sgn ? launch_out<IN_P12S, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed)
+		                         : launch_out<IN_P12U, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		case RS_LINEAR: return sgn ? launch_out<IN_P12S, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed)
+		                           : launch_out<IN_P12U, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		default: return sgn ? launch_out<IN_P12S, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed)
+		                    : launch_out<IN_P12U, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		}
+	}
+#endif
+	if (intype != IN_F32) return hipErrorInvalidValue;
 	switch (rs) {
 	case RS_NONE: return launch_out<IN_F32, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	case RS_LINEAR: return launch_out<IN_F32, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);

@@ -26,7 +26,7 @@
 
 namespace oct {
 
-enum { IN_U8 = 0, IN_U16 = 1, IN_U32 = 2, IN_F32 = 3 };
+enum { IN_U8 = 0, IN_U16 = 1, IN_U32 = 2, IN_F32 = 3, IN_P12U = 4, IN_P12S = 5 };  // P12: packed 12 bit (Mono12p), unsigned / two's complement
 enum { RS_NONE = 0, RS_LINEAR = 1, RS_CUBIC = 2, RS_LANCZOS = 3 };
 
 struct FusedArgs {
@@ -121,6 +121,10 @@ OCT_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
 OCT_DEV f32x4 buf_load128(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vbase + (c & 4095), c & ~4095, 0));
 }
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+OCT_DEV u32x3 buf_load96(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
+	return __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(r, vbase + (c & 4095), c & ~4095, 0));
+}
 OCT_DEV u32x2 buf_load64(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, vbase + (c & 4095), c & ~4095, 0));
 }
@@ -138,10 +142,14 @@ template <int N> struct Chunk<IN_U16, N> {
 	typedef u32x4 T;  // SPL = 4 uses .x/.y only
 };
 template <int N> struct Chunk<IN_F32, N> { static constexpr int SPL = 4, BYTES = 16; typedef u32x4 T; };
+// packed 12 bit: 8 samples in 12 bytes per lane (one buffer_load_dwordx3), 1.5 N bytes per row instead of 2 N
+template <int N> struct Chunk<IN_P12U, N> { static constexpr int SPL = 8, BYTES = 12; typedef u32x4 T; };
+template <int N> struct Chunk<IN_P12S, N> { static constexpr int SPL = 8, BYTES = 12; typedef u32x4 T; };
 
 template <int INTYPE, int N>
 OCT_DEV u32x4 load_chunk(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
 	if constexpr (Chunk<INTYPE, N>::BYTES == 8) { const u32x2 t = buf_load64(r, voff, imm); return u32x4{t.x, t.y, 0u, 0u}; }
+	else if constexpr (Chunk<INTYPE, N>::BYTES == 12) { const u32x3 t = buf_load96(r, voff, imm); return u32x4{t.x, t.y, t.z, 0u}; }
 	else return __builtin_bit_cast(u32x4, buf_load128(r, voff, imm));
 }
 
@@ -152,6 +160,21 @@ OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 		const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
 		if (s == 0) return float4{(float)(a & 0xffffu), (float)(a >> 16), (float)(b & 0xffffu), (float)(b >> 16)};
 		return float4{(float)((a & 0xffffu) >> s), (float)((a >> 16) >> s), (float)((b & 0xffffu) >> s), (float)((b >> 16) >> s)};
+	} else if constexpr (INTYPE == IN_P12U || INTYPE == IN_P12S) {
+		// include/octpipe.h OCTPIPE_FORMAT_*12_PACKED: consecutive 12-bit fields of a little-endian bit stream,
+		// 8 samples in the 96 bits (c.x, c.y, c.z); h selects samples 0..3 or 4..7; the >> 4 is arithmetic for signed data
+		uint32_t v0, v1, v2, v3;
+		if (h == 0) {
+			v0 = c.x & 0xfffu; v1 = (c.x >> 12) & 0xfffu; v2 = (c.x >> 24) | ((c.y & 0xfu) << 8); v3 = (c.y >> 4) & 0xfffu;
+		} else {
+			v0 = (c.y >> 16) & 0xfffu; v1 = (c.y >> 28) | ((c.z & 0xffu) << 4); v2 = (c.z >> 8) & 0xfffu; v3 = c.z >> 20;
+		}
+		if constexpr (INTYPE == IN_P12U) {
+			return float4{(float)(v0 >> s), (float)(v1 >> s), (float)(v2 >> s), (float)(v3 >> s)};
+		} else {
+			const int i0 = (int)(v0 << 20) >> 20, i1 = (int)(v1 << 20) >> 20, i2 = (int)(v2 << 20) >> 20, i3 = (int)(v3 << 20) >> 20;
+			return float4{(float)(i0 >> s), (float)(i1 >> s), (float)(i2 >> s), (float)(i3 >> s)};
+		}
 	} else {
 		// (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)
 		const f32x4 f = __builtin_bit_cast(f32x4, c);
@@ -448,7 +471,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (64 * SPL);
 	static_assert(!(RS == RS_LANCZOS && INTYPE != IN_F32), "Lanczos needs the prepared float buffer");
-	static_assert(!(ROLL && INTYPE == IN_F32), "prepared input is already DC-corrected");
+	static_assert(!(ROLL && INTYPE != IN_U16), "in-kernel rolling average: uint16 rows only (everything else comes prepared)");
+	static_assert(N / (64 * SPL) >= 1, "a row holds at least one chunk per lane");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* tw = reinterpret_cast<f2*>(smem);
 	f2* meanL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>());
@@ -521,7 +545,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	f32x4 cwR[REGTAB ? P : 1];
 	f2 wphR[REGTAB ? P : 1];
 	// the last pass' twiddles too where the register budget allows (plain uint16 kernel: 249 VGPRs, no spill)
-	constexpr bool TW3 = REGTAB && OCT_REGTW3 != 0 && !ROLL && INTYPE == IN_U16;
+	constexpr bool TW3 = REGTAB && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32;
 	constexpr bool TW2 = REGTAB && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
 	f32x4 tw2R[TW2 ? (TW3 ? 14 : 8) : 1];
 	if constexpr (REGTAB) {

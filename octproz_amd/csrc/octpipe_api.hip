@@ -283,7 +283,12 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	// N = 1664: the mixed-radix kernel takes uint16 directly; other containers / formats and the rolling average come prepared
 	const bool useMixed = h->mixed && rs != oct::RS_LANCZOS;
 	const bool mixedDirect = useMixed && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
-	if (needsPrepared(h) && !mixedDirect) {
+	// packed 12-bit rows are decoded inside the fused kernel (1.5 B per sample from HBM) wherever the general kernel runs on
+	// raw rows; the prepared float32 route remains for N = 256, the rolling average, Lanczos and the non-power-of-two lengths
+	const bool packed = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED || h->sampleFormat == OCTPIPE_FORMAT_INT12_PACKED;
+	const bool packedDirect = packed && !h->bluestein && !h->forcePrepared && h->log2n >= 9 && !roll && rs != oct::RS_LANCZOS;
+	if (packedDirect) intype = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED ? oct::IN_P12U : oct::IN_P12S;
+	if (needsPrepared(h) && !mixedDirect && !packedDirect) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
 		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(h->S)), dim3(256), 0, h->stream, d_raw, h->d_prepared,

@@ -100,6 +100,60 @@ def test_packed_input_gives_the_image_of_the_same_samples_in_uint16():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [512, 1024, 2048, 4096])
+@pytest.mark.parametrize("interp", ["cubic", "linear", "none"])
+def test_fused_packed_12bit_route_is_bit_identical(N, interp):
+    """OCTPIPE_FORMAT_UINT12_PACKED rows are decoded inside the fused kernel (1.5 B per sample read from HBM): the image
+    must equal, bit for bit, (a) the image of the same samples delivered as uint16 and (b) the packed buffer through the
+    prepared float32 route (oct_prepare_kernel, pinned bit-exactly against the oracle above)"""
+    from octproz_amd import INTERPOLATION, Pipeline, synthetic_raw, v180_benchmark_params
+    A, B = 24, 2
+    raw16 = synthetic_raw(N, A, B, seed=N)
+    raw16[0, 0, :6] = [0, 4095, 1, 2048, 4094, 7]
+    packed = pack12(raw16.reshape(-1))
+    p = v180_benchmark_params(N, A, B)
+    if interp == "linear":
+        p.resamplingInterpolation = INTERPOLATION.LINEAR
+    if interp == "none":
+        p.resampling = 0
+    p.update_all_curves()
+    ref = Pipeline(p, device=0)
+    d16 = _dev(raw16)
+    ref.process_device(d16.data_ptr()); ref.synchronize()
+    want, ml = ref.processed_host(), ref.mean_line()
+    pk = Pipeline(p, device=0, sample_format=FORMATS["uint12p"])
+    dp = _dev(packed)
+    pk.process_device(dp.data_ptr()); pk.synchronize()   # determines its own mean line through the packed spectrum kernel
+    assert np.array_equal(np.ascontiguousarray(pk.mean_line()).view(np.uint32), np.ascontiguousarray(ml).view(np.uint32))
+    got = pk.processed_host()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    pk.debug_force_prepared(True)
+    pk.process_device(dp.data_ptr()); pk.synchronize()
+    assert np.array_equal(pk.processed_host().view(np.uint32), got.view(np.uint32))
+    ref.close(); pk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bitshift", [0, 1])
+def test_fused_signed_packed_route_equals_prepared_route(bitshift):
+    from octproz_amd import Pipeline, v180_benchmark_params
+    N, A, B = 1024, 24, 2
+    v, raw = make("int12p", N * A * B, 17)
+    p = v180_benchmark_params(N, A, B)
+    p.bitshift = bitshift
+    a = Pipeline(p, device=0, sample_format=FORMATS["int12p"])
+    d = _dev(raw)
+    a.process_device(d.data_ptr()); a.synchronize()
+    fused, ml = a.processed_host(), a.mean_line()
+    a.debug_force_prepared(True)
+    a.set_mean_line(ml, pin=True)
+    a.process_device(d.data_ptr()); a.synchronize()
+    assert np.array_equal(a.processed_host().view(np.uint32), fused.view(np.uint32))
+    assert np.isfinite(fused).mean() > 0.99
+    a.close()
+
+
+@pytest.mark.gpu
 def test_signed_input_is_the_unsigned_image_of_the_offset_samples_without_dc():
     """int16 samples x - 2048 differ from uint16 samples x only in the DC term, which the rolling-average
     background removal takes out exactly (integer-valued floats, exact sums): identical images"""
