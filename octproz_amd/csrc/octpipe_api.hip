@@ -77,6 +77,7 @@ struct octpipe {
 	float4* d_segs = nullptr;
 	float* d_dispBscan = nullptr;
 	float* d_dispEnFace = nullptr;
+	uint64_t displaySig = 0;          // display settings of the last full extraction from the volume (0 = none yet)
 	uint8_t* d_volumeView = nullptr;  // [N/2][B*buffersPerVolume][A] uint8, lazily (cu:914-941 into a plain buffer)
 	bool mixed = false;        // samplesPerLine == 1664: mixed-radix kernel (mixed1664.h); Bluestein stays for Lanczos
 	float4* d_lutPlain = nullptr;  // mixed: the LUT without the Bluestein chirp folded in
@@ -269,6 +270,18 @@ bool needsPrepared(const octpipe* h) {
 }
 
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
+// Signature of the display settings: while it is unchanged only the buffer just written can have changed the frames, and
+// the extraction (cu:1571-1578) is restricted to it: the en-face pixels of its A-scans (every pixel depends on its own
+// A-scan alone) and the B-scan frame only when the displayed B-scan(s) lie in it.  With several buffers per volume this
+// keeps the extraction from re-reading the whole volume for every buffer.
+uint64_t displaySignature(const OctPipeParams& p) {
+	uint64_t s = 1469598103934665603ull;
+	const uint32_t f[] = {(uint32_t)p.bscanViewEnabled, (uint32_t)p.enFaceViewEnabled, p.frameNr, p.functionFramesBscan, (uint32_t)p.displayFunctionBscan,
+	                      p.frameNrEnFaceView, p.functionFramesEnFaceView, (uint32_t)p.displayFunctionEnFaceView};
+	for (uint32_t v : f) { s ^= v; s *= 1099511628211ull; }
+	return s | 1ull;
+}
+
 int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt) {
 	const OctPipeParams& p = h->params;
 	oct::FusedArgs a{};
@@ -425,7 +438,8 @@ void launchDisplayB(int mb, int me, const oct::DisplayArgs& d, unsigned eb, hipS
 }
 // bscan / enface: which frames to extract; a display function other than averaging / MIP with frames > 1 leaves the frame
 // untouched like the reference's switch (cu:826-846)
-int updateDisplay(octpipe* h, bool bscan, unsigned frameNrB, unsigned framesB, int fnB, bool enface, unsigned frameNrE, unsigned framesE, int fnE) {
+int updateDisplay(octpipe* h, bool bscan, unsigned frameNrB, unsigned framesB, int fnB, bool enface, unsigned frameNrE, unsigned framesE, int fnE,
+                  bool currentBufferOnly = false) {
 	oct::DisplayArgs d{};
 	d.dispBscan = h->d_dispBscan; d.dispEnFace = h->d_dispEnFace; d.vol = h->d_processed;
 	d.bscansPerVolume = (unsigned)h->B * h->acq.buffersPerVolume;
@@ -440,9 +454,20 @@ int updateDisplay(octpipe* h, bool bscan, unsigned frameNrB, unsigned framesB, i
 	if (mb < 0) bscan = false;
 	if (me < 0) enface = false;
 	if (!bscan && !enface) return OCTPIPE_OK;
+	d.enFaceFirst = 0;
+	d.enFaceCount = d.nEnFace;
+	if (currentBufferOnly) {
+		const unsigned slot = h->bufferNumberInVolume, B = (unsigned)h->B;
+		d.enFaceFirst = slot * B * (unsigned)h->A;
+		d.enFaceCount = B * (unsigned)h->A;
+		// the B-scan frame reads B-scans frameNr .. frameNr + frames - 1 (those that exist): untouched unless one lies in this buffer
+		const unsigned lastB = d.frameNrBscan + (framesB > 1 ? framesB - 1 : 0);
+		if (d.frameNrBscan >= (slot + 1) * B || lastB < slot * B) bscan = false;
+		if (!bscan && !enface) return OCTPIPE_OK;
+	}
 	const int vec = (d.nBscan % 4 == 0) ? 4 : 1;
 	d.bscanBlocks = bscan ? (unsigned)((d.nBscan / vec + 255) / 256) : 0u;
-	const unsigned eb = enface ? (d.nEnFace + 255) / 256 : 0u;
+	const unsigned eb = enface ? (d.enFaceCount + 255) / 256 : 0u;
 	if (vec == 4) launchDisplayB<4>(mb, me, d, eb, h->stream);
 	else launchDisplayB<1>(mb, me, d, eb, h->stream);
 	HIP_TRY(hipGetLastError());
@@ -520,8 +545,11 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	}
 
 	if (p.bscanViewEnabled || p.enFaceViewEnabled) {  // cu:1571-1578, both frames in one launch
+		const uint64_t sig = displaySignature(p);
+		const bool incremental = sig == h->displaySig && getenv("OCTPIPE_FULL_DISPLAY") == nullptr;
 		if ((rc = updateDisplay(h, p.bscanViewEnabled != 0, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan,
-		                        p.enFaceViewEnabled != 0, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView))) return rc;
+		                        p.enFaceViewEnabled != 0, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView, incremental))) return rc;
+		h->displaySig = sig;
 	}
 	if (p.volumeViewEnabled) {  // cu:1579-1582
 		const unsigned W = (unsigned)(N / 2), BV = (unsigned)B * h->acq.buffersPerVolume;

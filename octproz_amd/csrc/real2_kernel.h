@@ -12,7 +12,12 @@
 
 namespace oct {
 
-constexpr int REAL2_WAVES = 15;
+// Like the general kernel of this length (kernels.h, OCT_REGTAB) the lane-invariant tables live in VGPRs for the whole
+// persistent loop: tap weights, window, packed twiddles of the second and third pass; 8 waves per workgroup (2 per SIMD).
+#ifndef OCT_REAL2_REGTAB
+#define OCT_REAL2_REGTAB 1
+#endif
+constexpr int REAL2_WAVES = OCT_REAL2_REGTAB ? 8 : 15;
 constexpr int REAL2_ROW1 = 4224;  // byte offset of the second staged row inside the wave's slice
 constexpr int REAL2_TABLE_BYTES = (8 * 16 + 6 * 64) * 16 + 1024 * 16 + 1024 * 4;  // packed twiddles | tap weights | window
 constexpr int REAL2_LDS_BYTES = REAL2_TABLE_BYTES + REAL2_WAVES * wave_lds_bytes<1024>();
@@ -21,10 +26,10 @@ static_assert(REAL2_ROW1 + (1024 + 2 * ROW_OFF) * 4 <= wave_lds_bytes<1024>(), "
 static_assert(513 * 8 <= wave_lds_bytes<1024>(), "mirror buffer fits the slice");
 
 template <int RS, int MODE>
-__global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(REAL2_WAVES * 64, OCT_REAL2_REGTAB ? 2 : 4) void oct_real2_kernel(const FusedArgs a) {
 	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
 	constexpr int N = 1024, P = 16, THREADS = REAL2_WAVES * 64;
-	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0;
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, REGTAB = OCT_REAL2_REGTAB != 0;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* tw = reinterpret_cast<f2*>(smem);
 	f32x4* cwL = reinterpret_cast<f32x4*>(smem + tw_lds_bytes<10>());
@@ -36,6 +41,7 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
 	fill_twiddles<10>(tw, a.twiddle, tid, THREADS);
+	if constexpr (!REGTAB)
 	for (int i = tid; i < N; i += THREADS) {
 		const float4 t = a.lut[i];
 		const double p = (double)__builtin_amdgcn_fractf(t.x);
@@ -58,6 +64,32 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 	if constexpr (RS != RS_NONE) {
 #pragma unroll
 		for (int q = 0; q < P; q++) tapA[q] = tapBase + 4u * (uint32_t)(int)a.lut[lane + 64 * q].x;
+	}
+	f32x4 cwR[REGTAB && RS == RS_CUBIC ? P : 1];
+	float fracR[REGTAB && RS == RS_LINEAR ? P : 1], winR[REGTAB ? P : 1];
+	constexpr bool TW2 = REGTAB && RS != RS_CUBIC, TW3 = TW2;  // the cubic variant spends its registers on the tap weights
+	f32x4 twR[TW2 ? 14 : 1];
+	if constexpr (REGTAB) {
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+			const float4 t = a.lut[lane + 64 * q];
+			winR[q] = t.y * t.z;
+			const double p = (double)__builtin_amdgcn_fractf(t.x);
+			if constexpr (RS == RS_CUBIC) {
+				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+				// the (real) window is folded into the tap weights: one rounding of difference, no multiply after the gather
+				const double wn = (double)winR[q];
+				cwR[q] = f32x4{(float)(wn * w0), (float)(wn * (1.0 - w0 - w2 - w3)), (float)(wn * w2), (float)(wn * w3)};
+			} else if constexpr (RS == RS_LINEAR) {
+				fracR[q] = (float)p;
+			}
+		}
+		if constexpr (TW2) {
+#pragma unroll
+			for (int c = 0; c < 8; c++) twR[c] = reinterpret_cast<const f32x4*>(tw)[c * 16 + (lane & 15)];
+#pragma unroll
+			for (int c = 0; c < 6; c++) twR[8 + c] = reinterpret_cast<const f32x4*>(tw)[8 * 16 + c * 64 + lane];
+		}
 	}
 	f2 mean2[8];  // twice the mean A-line at the lane's kept bins lane + 64 m + 256 u, u < 2
 #pragma unroll
@@ -105,14 +137,22 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 		f32x4 win4;
 #pragma unroll
 		for (int q = 0; q < P; q++) {
-			if ((q & 3) == 0) win4 = winL[lane + 64 * (q >> 2)];
-			const float w = (q & 3) == 0 ? win4.x : (q & 3) == 1 ? win4.y : (q & 3) == 2 ? win4.z : win4.w;
+			float w;
+			if constexpr (REGTAB) {
+				w = winR[q];
+			} else {
+				if ((q & 3) == 0) win4 = winL[lane + 64 * (q >> 2)];
+				w = (q & 3) == 0 ? win4.x : (q & 3) == 1 ? win4.y : (q & 3) == 2 ? win4.z : win4.w;
+			}
 			float y0, y1;
 			if constexpr (RS == RS_NONE) {
 				y0 = row[ROW_OFF + lane + 64 * q];
 				y1 = row[REAL2_ROW1 / 4 + ROW_OFF + lane + 64 * q];
 			} else {
-				const f32x4 cw = cwL[lane + 64 * q];
+				f32x4 cw;
+				if constexpr (!REGTAB) cw = cwL[lane + 64 * q];
+				else if constexpr (RS == RS_CUBIC) cw = cwR[q];
+				else cw = f32x4{fracR[q], 0.0f, 0.0f, 0.0f};
 				lds_cfloat* t0 = (lds_cfloat*)(uintptr_t)(tapA[q]);
 				lds_cfloat* t1 = (lds_cfloat*)(uintptr_t)(tapA[q] + (uint32_t)REAL2_ROW1);
 				if constexpr (RS == RS_CUBIC) {
@@ -123,12 +163,13 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 					y1 = t1[1] + (t1[2] - t1[1]) * cw.x;
 				}
 			}
-			v[q] = f2{w * y0, w * y1};
+			if constexpr (REGTAB && RS == RS_CUBIC) v[q] = f2{y0, y1};  // window already inside the weights
+			else v[q] = f2{w * y0, w * y1};
 		}
 		wave_sync_lds();  // the rows are dead from here on
 
 		__builtin_amdgcn_s_setprio(2);
-		fft_wave<10, false>(v, xbuf, tw, lane);  // Z[lane + 64 m + 256 u] in v[m + 4 u], all u
+		fft_wave<10, false, TW2, TW3>(v, xbuf, tw, lane, twR);  // Z[lane + 64 m + 256 u] in v[m + 4 u], all u
 
 		// ---- mirror exchange: Z[N - k] of the kept bins k < N/2 comes from the upper half (and Z[0] for k = 0)
 		{
@@ -172,6 +213,7 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, 4) void oct_real2_kernel(const Fu
 				buf_store32(sA * f1 + sB, out0, lane * 4, (64 * m + 256 * u) * 4);
 				buf_store32(sA * f2v + sB, out1, lane * 4, (64 * m + 256 * u) * 4);
 			}
+
 		__builtin_amdgcn_s_setprio(0);
 		wave_sync_lds();
 	}

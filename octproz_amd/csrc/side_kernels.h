@@ -307,6 +307,8 @@ struct DisplayArgs {
 	unsigned bscansPerVolume, nBscan, frameNrBscan, framesBscan;
 	unsigned frameWidth, nEnFace, frameNrEnFace, framesEnFace;
 	unsigned bscanBlocks;
+	unsigned enFaceFirst, enFaceCount;  // A-scans of the volume whose en-face pixel is (re)computed: the whole volume, or only the
+	                                    // buffer just written (every pixel depends on its own A-scan alone)
 };
 template <int MODE_B, int VEC_B, int MODE_E>
 __global__ __launch_bounds__(256) void oct_display_frames_kernel(const DisplayArgs a) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void oct_display_frames_kernel(const DisplayAr
 		if (u * VEC_B < a.nBscan) display_bscan_unit<MODE_B, VEC_B>(u, a.dispBscan, a.vol, a.bscansPerVolume, a.nBscan, a.frameNrBscan, a.framesBscan);
 	} else {
 		const unsigned i = (blockIdx.x - a.bscanBlocks) * blockDim.x + threadIdx.x;
-		if (i < a.nEnFace) display_enface_unit<MODE_E>(i, a.dispEnFace, a.vol, a.frameWidth, a.nEnFace, a.frameNrEnFace, a.framesEnFace);
+		if (i < a.enFaceCount) display_enface_unit<MODE_E>(a.enFaceFirst + i, a.dispEnFace, a.vol, a.frameWidth, a.nEnFace, a.frameNrEnFace, a.framesEnFace);
 	}
 }
 

@@ -163,3 +163,59 @@ def test_display_frames_every_function_bit_exact(N, A, B):
     pipe.change_displayed_bscan_frame(0, 4, 7); pipe.synchronize()
     assert np.array_equal(_fetch(pb, nb, np.float32), before)
     pipe.close()
+
+
+@pytest.mark.parametrize("N,A,B,bpv,mut", [
+    (1024, 33, 4, 1, {}), (1024, 16, 4, 3, {"bscanFlip": 1}), (1024, 24, 2, 1, {"dispersionCompensation": 0}),
+    (1024, 24, 3, 2, {"dispersionCompensation": 0, "bscanFlip": 1}), (512, 20, 4, 2, {}), (2048, 12, 2, 1, {"signalLogScaling": 0}),
+    (4096, 6, 2, 1, {}), (256, 9, 6, 1, {"resampling": 0}), (1024, 20, 2, 1, {"backgroundRemoval": 1, "rollingAverageWindowSize": 16}),
+])
+def test_incremental_display_extraction_equals_the_extraction_from_the_whole_volume(N, A, B, bpv, mut):
+    """While the display settings are unchanged the extraction (cu:1571-1578) is restricted to the buffer just written (its
+    en-face pixels; the B-scan frame only when the displayed B-scan lies in it): after every buffer both frames must equal,
+    bit for bit, what cu:810-912 extract from the whole current volume -- general and real-input kernels, flip, several
+    buffers per volume (B-scan frame in another slot), changed frame numbers in between."""
+    p = v180_benchmark_params(N, A, B, buffers_per_volume=bpv)
+    _grey(p)
+    for k, v in mut.items():
+        setattr(p, k, v)
+    p.update_all_curves()
+    p.frameNr, p.frameNrEnFaceView = (B * bpv) // 2, N // 4 + 3
+    pipe = Pipeline(p, device=0)
+    (pb, nb), (pe, ne) = pipe.display_buffers()
+    W, BV = N // 2, B * bpv
+    vol = np.zeros(BV * A * W, np.float32)
+    for k in range(2 * bpv + 3):
+        if k == bpv + 2:  # the user moves both views: one full extraction, then the kernel keeps the new frames current
+            p.frameNr, p.frameNrEnFaceView = 1, 7
+        raw = synthetic_raw(N, A, B, seed=700 + k)
+        d = _dev(raw)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        _, _, nr = pipe.processed_device()
+        vol[nr * A * B * W:(nr + 1) * A * B * W] = pipe.processed_host()
+        want_b = octref.display_bscan(vol, BV, nb, p.frameNr, 1, 0)
+        want_e = octref.display_enface(vol, W, ne, p.frameNrEnFaceView, 1, 0)
+        assert np.array_equal(_fetch(pb, nb, np.float32).view(np.uint32), want_b.view(np.uint32)), "B-scan frame after buffer %d" % k
+        assert np.array_equal(_fetch(pe, ne, np.float32).view(np.uint32), want_e.view(np.uint32)), "en-face frame after buffer %d" % k
+    pipe.close()
+
+
+def test_full_display_extraction_switch(monkeypatch):
+    """OCTPIPE_FULL_DISPLAY=1 extracts from the whole volume on every buffer (A/B switch): same frames"""
+    N, A, B = 1024, 16, 2
+    p = v180_benchmark_params(N, A, B)
+    _grey(p)
+    raws = [synthetic_raw(N, A, B, seed=800 + k) for k in range(3)]
+    frames = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("OCTPIPE_FULL_DISPLAY", env)
+        pipe = Pipeline(p, device=0)
+        (pb, nb), (pe, ne) = pipe.display_buffers()
+        for r in raws:
+            d = _dev(r)
+            pipe.process_device(d.data_ptr()); pipe.synchronize()
+        frames.append((_fetch(pb, nb, np.float32), _fetch(pe, ne, np.float32)))
+        pipe.close()
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    assert np.array_equal(frames[0][1].view(np.uint32), frames[1][1].view(np.uint32))
