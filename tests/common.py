@@ -102,3 +102,32 @@ def compare_spectra(got, want, n, what=""):
     err = float((np.abs(g - w) / scale).max())
     assert err <= SPECTRUM_RTOL, "%s: spectrum error %.3e > %.1e" % (what, err, SPECTRUM_RTOL)
     return err
+
+
+def check_min_variance_mean(mean, spectrum, n, what="", segs=9):
+    """Principled check of a fixed-pattern-noise mean line (cu:523-565) determined in float32 from `spectrum` ([H, n] complex,
+    the un-subtracted spectra of the H lines used): per depth bin the result must be the mean of ONE of the 9 segments, and
+    that segment's variance must be minimal up to what float32 accumulation can resolve -- the single-pass variance
+    E|z|^2 - |Ez|^2 of ~56 float32 terms carries an absolute error of about 56 eps E|z|^2, so segments whose float64
+    variances lie closer than that are legitimately interchangeable.  Every bin is checked; returns the
+    number of bins where a segment other than the float64 minimum was (legitimately) taken."""
+    z = np.asarray(spectrum).reshape(-1, n).astype(np.complex128)
+    seg_w = z.shape[0] // segs
+    assert seg_w >= 1
+    zs = z[:seg_w * segs].reshape(segs, seg_w, n)
+    m = zs.mean(axis=1)                       # [segs, n]
+    e2 = (np.abs(zs) ** 2).mean(axis=1)
+    var = e2 - np.abs(m) ** 2
+    half = n // 2
+    got = np.asarray(mean).astype(np.complex128)[:half]
+    vmin = var.min(axis=0)
+    slack = 64 * seg_w * np.finfo(np.float32).eps * e2.max(axis=0)
+    admissible = var <= (vmin + slack)[None, :]
+    scale = np.abs(z).max(axis=0) + 1e-30
+    err = np.abs(m[:, :half] - got[None, :]) / scale[None, :half]
+    ok = (admissible[:, :half] & (err <= 1e-5)).any(axis=0)
+    assert ok.all(), "%s: %d of %d bins are not the mean of a minimum-variance segment (worst bin %d)" % (
+        what, int((~ok).sum()), half, int(np.argmin(ok)))
+    best = var[:, :half].argmin(axis=0)
+    taken = np.where(admissible[:, :half] & (err <= 1e-5), np.arange(segs)[:, None], segs).min(axis=0)
+    return int((taken != best).sum())

@@ -210,3 +210,21 @@ def test_rolling_average_division_is_the_exact_quotient():
     L = octref.lib()
     L.octref_check_exact_division.restype = C.c_long
     assert L.octref_check_exact_division(256, 1) == 0
+
+
+def test_min_variance_checker_accepts_the_oracle_and_catches_a_wrong_bin():
+    """tests/common.check_min_variance_mean is what the GPU tests hold an unpinned mean line to"""
+    import common
+    from octproz_amd import synthetic_raw, v180_benchmark_params
+    N, A, B = 512, 64, 2
+    p = v180_benchmark_params(N, A, B)
+    o = common.make_oracle(p)
+    o.process(synthetic_raw(N, A, B, seed=8))
+    spec = o.last_spectrum().reshape(-1, N)[:A].copy()
+    spec[:, :N // 2] += o.mean_line()[:N // 2]  # undo the subtraction
+    assert common.check_min_variance_mean(o.mean_line(), spec, N, "oracle") < N // 20
+    bad = o.mean_line().copy()
+    bad[37] += 50.0
+    with pytest.raises(AssertionError):
+        common.check_min_variance_mean(bad, spec, N, "perturbed")
+    o.close()
