@@ -66,6 +66,14 @@ struct FusedArgs {
 #endif
 // OCT_PERM_EXCHANGE = 0: the exchange in front of the last radix-4 pass of the N = 1024 plan goes through LDS (packed twiddle
 // tables kept) instead of v_permlane32/16_swap.  OCT_REGTW3 = 1 (with OCT_REGTAB): the last pass' twiddles in VGPRs too.
+// OCT_REGLIN: the same register-table structure for the N = 1024 variants without cubic weights (linear / no resampling)
+#ifndef OCT_REGLIN
+#define OCT_REGLIN 1
+#endif
+// OCT_NONE12: without resampling the register-table kernel needs 166 VGPRs: 12 waves per workgroup (3 per SIMD) instead of 8
+#ifndef OCT_NONE12
+#define OCT_NONE12 1
+#endif
 #ifndef OCT_PERM_EXCHANGE
 #define OCT_PERM_EXCHANGE 1
 #endif
@@ -82,10 +90,11 @@ template <> struct Cfg<12> { static constexpr bool PLANAR = true; static constex
 template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr bool CW = RS == RS_CUBIC && Cfg<LOG2N>::LDS_LUT && Cfg<LOG2N>::WAVES_CW > 0;
 	static constexpr bool REGTAB = CW && LOG2N == 10 && OCT_REGTAB != 0;
-	static constexpr int WAVES_PLAIN = CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
+	static constexpr bool REGLIN = !CW && LOG2N == 10 && OCT_REGLIN != 0 && (RS == RS_LINEAR || RS == RS_NONE) && !ROLL;
+	static constexpr int WAVES_PLAIN = REGLIN ? (RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
 	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
 	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0 && Cfg<LOG2N>::WAVES_ROLL < WAVES_PLAIN) ? Cfg<LOG2N>::WAVES_ROLL : WAVES_PLAIN;
-	static constexpr int MINW = REGTAB ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
+	static constexpr int MINW = (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
@@ -448,9 +457,9 @@ OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
 	}
 }
 template <int LOG2N> constexpr int mean_lds_bytes() { return Cfg<LOG2N>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
-template <int LOG2N, int RS> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
+template <int LOG2N, int RS, bool ROLL = false> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB || KCfg<LOG2N, RS, ROLL>::REGLIN) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
 template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
-	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
+	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
 }
 
 // MODE bits of the kernel template
@@ -466,6 +475,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	constexpr int N = 1 << LOG2N, P = N / 64;
 	constexpr int WAVES = KCfg<LOG2N, RS, (MODE & MODE_ROLL) != 0>::WAVES, THREADS = WAVES * 64;
 	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = Cfg<LOG2N>::MEAN_REGS, REGTAB = KCfg<LOG2N, RS>::REGTAB;
+	constexpr bool REGLIN = KCfg<LOG2N, RS, (MODE & 1) != 0>::REGLIN && RS != RS_LANCZOS;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	typedef Chunk<INTYPE, N> CH;
@@ -481,7 +491,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + N * (CW ? 16 : 4));
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
-	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS>() + wave * wave_lds_bytes<N, ROLL>();
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * wave_lds_bytes<N, ROLL>();
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
@@ -489,7 +499,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
 	if constexpr (!MEAN_REGS)
 		for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
-	if constexpr (LDS_LUT && !REGTAB) {
+	if constexpr (LDS_LUT && !REGTAB && !REGLIN) {
 		for (int i = tid; i < N; i += THREADS) {
 			const float4 t = a.lut[i];
 			// window folded into the phasor (one rounding of difference).  CW: the values of samples lane+64q and
@@ -543,10 +553,23 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	}
 	// REGTAB: the same table entries the LDS variant reads per A-scan, computed once per persistent wave
 	f32x4 cwR[REGTAB ? P : 1];
-	f2 wphR[REGTAB ? P : 1];
+	f2 wphR[REGTAB || REGLIN ? P : 1];
+	float fracR[REGLIN && RS == RS_LINEAR ? P : 1];
+	uint32_t tapL[REGLIN && RS == RS_LINEAR ? P : 1];
+	if constexpr (REGLIN) {
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+			const float4 t = a.lut[lane + 64 * q];
+			wphR[q] = f2{t.y * t.z, t.y * t.w};
+			if constexpr (RS == RS_LINEAR) {
+				fracR[q] = __builtin_amdgcn_fractf(t.x);
+				tapL[q] = tapBase + 4u * (uint32_t)(int)t.x + 4u;
+			}
+		}
+	}
 	// the last pass' twiddles too where the register budget allows (plain uint16 kernel: 249 VGPRs, no spill)
-	constexpr bool TW3 = REGTAB && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32;
-	constexpr bool TW2 = REGTAB && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
+	constexpr bool TW3 = (REGTAB || REGLIN) && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32;
+	constexpr bool TW2 = (REGTAB || REGLIN) && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
 	f32x4 tw2R[TW2 ? (TW3 ? 14 : 8) : 1];
 	if constexpr (REGTAB) {
 #pragma unroll
@@ -557,14 +580,14 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
 			cwR[q] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
 		}
-		if constexpr (TW2) {
+	}
+	if constexpr (TW2) {
 #pragma unroll
-			for (int c = 0; c < 8; c++) tw2R[c] = reinterpret_cast<const f32x4*>(tw)[c * 16 + (lane & 15)];
-		}
-		if constexpr (TW3) {
+		for (int c = 0; c < 8; c++) tw2R[c] = reinterpret_cast<const f32x4*>(tw)[c * 16 + (lane & 15)];
+	}
+	if constexpr (TW3) {
 #pragma unroll
-			for (int c = 0; c < 6; c++) tw2R[8 + c] = reinterpret_cast<const f32x4*>(tw)[8 * 16 + c * 64 + lane];
-		}
+		for (int c = 0; c < 6; c++) tw2R[8 + c] = reinterpret_cast<const f32x4*>(tw)[8 * 16 + c * 64 + lane];
 	}
 	// rolling average: window lengths (and their reciprocals) of the lane's samples in the first and the last 256-sample chunk,
 	// the only ones a window of half-size <= ROLL_PAD can be clipped in; everywhere else the window holds 2 W samples
@@ -702,6 +725,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			if constexpr (REGTAB) {
 				cw = cwR[q];
 				wph = wphR[q];
+			} else if constexpr (REGLIN) {
+				wph = wphR[q];
 			} else if constexpr (CW) {
 				cw = cwL[lane + 64 * q];
 				if ((q & 1) == 0) wph2 = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];
@@ -721,6 +746,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + 4u * (uint32_t)n1);
 				// rho >= 0: fract(rho) == rho - (float)n1 exactly (cu:293 `nx - n1`)
 				y = cubic_hermite(t[0], t[1], t[2], t[3], __builtin_amdgcn_fractf(L.x));
+			} else if constexpr (RS == RS_LINEAR && REGLIN) {
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapL[q]);
+				y = t[0] + (t[1] - t[0]) * fracR[q];
 			} else if constexpr (RS == RS_LINEAR) {
 				const int n1 = (int)L.x;
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapBase + 4u * (uint32_t)n1 + 4u);
@@ -735,7 +763,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				for (int i = -7; i <= 8; i++) sum += t[i] * lanczos8(L.x - (float)(n0 + i));
 				y = sum;
 			}
-			if constexpr (LDS_LUT) {
+			if constexpr (LDS_LUT || REGLIN) {
 				v[q] = wph * y;
 			} else {
 				const float yw = y * L.y;
