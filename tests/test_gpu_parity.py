@@ -657,7 +657,23 @@ def _full_size(N, A, B, sample_lines=192, **settings):
     # (2) idempotence: same input, same bits
     pipe.process_device(d.data_ptr()); pipe.synchronize()
     assert np.array_equal(pipe.processed_host().view(np.uint32), full.reshape(-1).view(np.uint32))
-    # (3) the oracle on the first, a middle and the last B-scan
+    # (3) EVERY A-scan of the buffer against the float64 model evaluated on the device (tests/torch_model.py)
+    import torch_model
+    out_ptr, _, nr = pipe.processed_device()
+    worst = (0.0, 0.0)
+    step = max(2, (8192 // A) & ~1)
+    hip = __import__("ctypes").CDLL("libamdhip64.so")
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        want_t = torch_model.model_image(d, p, mean, b0, nb, d.device)
+        got_t = torch.empty((nb * A, N // 2), dtype=torch.float32, device=d.device)
+        src = out_ptr + (nr * B * A + b0 * A) * (N // 2) * 4
+        assert hip.hipMemcpy(__import__("ctypes").c_void_p(got_t.data_ptr()), __import__("ctypes").c_void_p(src),
+                             __import__("ctypes").c_size_t(got_t.numel() * 4), 3) == 0  # device to device
+        r = torch_model.compare_every_line(got_t, want_t, p, "B-scans %d..%d vs float64 model" % (b0, b0 + nb - 1))
+        worst = (max(worst[0], r[0]), max(worst[1], r[1]))
+    print("every A-scan vs float64 model: max linear-power error %.2e, max dB error %.2e" % worst)
+    # (4) the oracle on the first, a middle and the last B-scan
     raw = d.cpu().numpy().view(np.uint16)
     for b in (0, B // 2 - 1, B - 1):
         nb = max(1, sample_lines // A)
@@ -690,6 +706,12 @@ def test_full_size_real_input_kernel_1024x512x256():
 def test_full_size_real_input_kernel_config3_slab():
     """config 3's length on the default-style settings: real-input kernel of N = 2048 on a 2048 x 1024 x 64 slab"""
     _full_size(2048, 1024, 64, sample_lines=1024, dispersionCompensation=0)
+
+
+def test_full_size_n1664_mixed_radix_512x128():
+    """the reference recording's A-scan length at a production-sized buffer: every A-scan against the float64 model,
+    sharded == unsharded, idempotent, oracle samples"""
+    _full_size(1664, 512, 128, sample_lines=64)
 
 
 def test_full_size_config3_2048x1024x512():
