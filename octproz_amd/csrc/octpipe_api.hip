@@ -5,6 +5,7 @@
 // the handle instead of module globals (cu:39-105), and every failure is a status code instead
 // of exit(EXIT_FAILURE) (helper_cuda.h:583-590).  There is no CPU fallback: without a HIP device
 // octpipe_create fails with OCTPIPE_ERR_NO_DEVICE.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -79,6 +80,15 @@ struct octpipe {
 	float* d_dispEnFace = nullptr;
 	uint64_t displaySig = 0;          // display settings of the last full extraction from the volume (0 = none yet)
 	uint8_t* d_volumeView = nullptr;  // [N/2][B*buffersPerVolume][A] uint8, lazily (cu:914-941 into a plain buffer)
+	bool libfft = false;       // no fused kernel for this length: gather -> hipFFT -> epilogue through a complex buffer (side_kernels.h)
+	f2* d_cplx = nullptr;      // libfft: [A*B][N] complex
+	void* fftLib = nullptr;
+	int (*fftPlan1d)(void**, int, int, int) = nullptr;       // hipfftHandle is an opaque pointer
+	int (*fftSetStream)(void*, hipStream_t) = nullptr;
+	int (*fftExecC2C)(void*, void*, void*, int) = nullptr;
+	int (*fftDestroy)(void*) = nullptr;
+	void* fftPlan[2] = {nullptr, nullptr};
+	size_t fftPlanBatch[2] = {0, 0};
 	bool mixed = false;        // samplesPerLine == 1664: mixed-radix kernel (mixed1664.h); Bluestein stays for Lanczos
 	float4* d_lutPlain = nullptr;  // mixed: the LUT without the Bluestein chirp folded in
 	f2* d_twMixed = nullptr;       // mixed: W_1664^{n2 k1}, [32][52]
@@ -238,6 +248,48 @@ int uploadBluesteinTables(octpipe* h) {
 	return OCTPIPE_OK;
 }
 
+// hipFFT for the lengths without a fused kernel, bound at run time (no link dependency; a process that already holds the
+// library -- PyTorch brings a copy -- reuses it)
+int bindFftLibrary(octpipe* h) {
+	const char* names[] = {"libhipfft.so.0", "libhipfft.so"};
+	for (const char* n : names) if (!h->fftLib) h->fftLib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+	for (const char* n : names) if (!h->fftLib) h->fftLib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+	if (!h->fftLib) return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine outside 256..4096 / 8..2047 needs libhipfft.so, which could not be loaded");
+	h->fftPlan1d = reinterpret_cast<decltype(h->fftPlan1d)>(dlsym(h->fftLib, "hipfftPlan1d"));
+	h->fftSetStream = reinterpret_cast<decltype(h->fftSetStream)>(dlsym(h->fftLib, "hipfftSetStream"));
+	h->fftExecC2C = reinterpret_cast<decltype(h->fftExecC2C)>(dlsym(h->fftLib, "hipfftExecC2C"));
+	h->fftDestroy = reinterpret_cast<decltype(h->fftDestroy)>(dlsym(h->fftLib, "hipfftDestroy"));
+	if (!h->fftPlan1d || !h->fftSetStream || !h->fftExecC2C || !h->fftDestroy) return fail(OCTPIPE_ERR_UNSUPPORTED, "libhipfft.so lacks the C2C entry points");
+	return OCTPIPE_OK;
+}
+
+// gather -> batched inverse C2C -> epilogue for `lines` A-scans of the prepared float32 buffer (cufftExecC2C cu:1514-1515)
+int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, bool logScale) {
+	const size_t lines = a.numLines, N = (size_t)h->N;
+	int rc = ensure((void**)&h->d_cplx, sizeof(f2) * (size_t)h->A * h->B * N);
+	if (rc) return rc;
+	f2* work = spectrum ? a.spectrum : h->d_cplx;
+	hipLaunchKernelGGL(oct::oct_lib_gather_kernel, dim3(gridFor(lines * N)), dim3(256), 0, h->stream, reinterpret_cast<const float*>(a.raw), work, a.lut,
+	                   h->N, lines, (size_t)a.linesInBuffer, rs);
+	HIP_TRY(hipGetLastError());
+	int slot = -1;
+	for (int i = 0; i < 2; ++i) if (h->fftPlanBatch[i] == lines) slot = i;
+	if (slot < 0) {
+		slot = h->fftPlanBatch[0] == 0 ? 0 : 1;
+		if (h->fftPlanBatch[slot]) { HIP_TRY(hipStreamSynchronize(h->stream)); h->fftDestroy(h->fftPlan[slot]); h->fftPlanBatch[slot] = 0; }
+		if (h->fftPlan1d(&h->fftPlan[slot], h->N, 0x29 /* HIPFFT_C2C */, (int)lines) != 0) return fail(OCTPIPE_ERR_DEVICE, "hipfftPlan1d failed");
+		if (h->fftSetStream(h->fftPlan[slot], h->stream) != 0) return fail(OCTPIPE_ERR_DEVICE, "hipfftSetStream failed");
+		h->fftPlanBatch[slot] = lines;
+	}
+	if (h->fftExecC2C(h->fftPlan[slot], work, work, 1 /* HIPFFT_BACKWARD: e^{+2 pi i nk/N}, unnormalised */) != 0) return fail(OCTPIPE_ERR_DEVICE, "hipfftExecC2C failed");
+	if (!spectrum) {
+		hipLaunchKernelGGL(oct::oct_lib_epilogue_kernel, dim3(gridFor(lines * (N / 2))), dim3(256), 0, h->stream, work, a.out, a.meanLine, h->N, lines,
+		                   a.ascansPerBscan, a.linesInBuffer, a.flip, a.subtractMean, a.sA, a.sB, logScale ? 1 : 0);
+		HIP_TRY(hipGetLastError());
+	}
+	return OCTPIPE_OK;
+}
+
 // twiddles between the 32-point and the 52-point stage of the N = 1664 plan: W^{n2 k1}, W = e^{+2 pi i / 1664}, as [k1][n2]
 int uploadMixedTables(octpipe* h) {
 	const int N = 1664, N1 = 32, N2 = 52;
@@ -266,7 +318,7 @@ size_t rawBytes(const octpipe* h) {
 }
 
 bool needsPrepared(const octpipe* h) {
-	return h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
+	return h->libfft || h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
 }
 
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
@@ -299,7 +351,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	// packed 12-bit rows are decoded inside the fused kernel (1.5 B per sample from HBM) wherever the general kernel runs on
 	// raw rows; the prepared float32 route remains for N = 256, the rolling average, Lanczos and the non-power-of-two lengths
 	const bool packed = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED || h->sampleFormat == OCTPIPE_FORMAT_INT12_PACKED;
-	const bool packedDirect = packed && !h->bluestein && !h->forcePrepared && h->log2n >= 9 && !roll && rs != oct::RS_LANCZOS;
+	const bool packedDirect = packed && !h->bluestein && !h->libfft && !h->forcePrepared && h->log2n >= 9 && !roll && rs != oct::RS_LANCZOS;
 	if (packedDirect) intype = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED ? oct::IN_P12U : oct::IN_P12S;
 	if (needsPrepared(h) && !mixedDirect && !packedDirect) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
@@ -339,7 +391,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (useMixed) {
+	if (h->libfft) {
+		int rc = launchLibFft(h, a, rs, spectrum, p.signalLogScaling != 0);
+		if (rc) return rc;
+	} else if (useMixed) {
 		a.lut = h->d_lutPlain;
 		a.twiddle = h->d_twMixed;
 		HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
@@ -627,8 +682,9 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "packed 12-bit buffers need an even number of samples");
 	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
-	if (!oct::fused_supported(acq->samplesPerLine) && oct::bluestein_log2m(acq->samplesPerLine) < 0)
-		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must be 256, 512, 1024, 2048, 4096 or any other length in 8..2047 in this build");
+	const bool needLibFft = !oct::fused_supported(acq->samplesPerLine) && oct::bluestein_log2m(acq->samplesPerLine) < 0;
+	if (needLibFft && (acq->samplesPerLine < 8 || acq->samplesPerLine > 65536))
+		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must lie in 8..65536");
 	int count = 0;
 	int rc = octpipe_device_count(&count);
 	if (rc) return rc;
@@ -648,7 +704,9 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	h->sampleFormat = sampleFormat;  // input decode only; the output quantiser keeps following bitDepth
 	h->log2n = 0;
 	while ((1 << h->log2n) < h->N) h->log2n++;
-	if (!oct::fused_supported(acq->samplesPerLine)) {
+	if (needLibFft) {
+		h->libfft = true;
+	} else if (!oct::fused_supported(acq->samplesPerLine)) {
 		h->bluestein = true;
 		h->log2n = oct::bluestein_log2m(acq->samplesPerLine);
 		h->mixed = acq->samplesPerLine == oct::kMixedLength && getenv("OCTPIPE_NO_MIXED") == nullptr;  // (A/B switch: Bluestein for 1664 too)
@@ -676,7 +734,8 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	if ((rc = ensure((void**)&h->d_sinusCurve, sizeof(float) * h->A))) return rc;
 	if ((rc = ensure((void**)&h->d_dispBscan, sizeof(float) * ((size_t)h->N * h->A / 2)))) return rc;
 	if ((rc = ensure((void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
-	if ((rc = uploadTwiddles(h))) return rc;
+	if (h->libfft) { if ((rc = bindFftLibrary(h))) return rc; }
+	else if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
 	if (h->mixed && (rc = uploadMixedTables(h))) return rc;
 	{  // cu:1093
@@ -709,6 +768,8 @@ int octpipe_destroy(octpipe_t* h) {
 		if (h->h2dDone[i]) hipEventDestroy(h->h2dDone[i]);
 		if (h->slotFree[i]) hipEventDestroy(h->slotFree[i]);
 	}
+	for (int i = 0; i < 2; ++i) if (h->fftPlanBatch[i] && h->fftDestroy) h->fftDestroy(h->fftPlan[i]);
+	if (h->d_cplx) hipFree(h->d_cplx);
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,

@@ -322,3 +322,71 @@ __global__ __launch_bounds__(256) void oct_display_frames_kernel(const DisplayAr
 }
 
 }  // namespace oct
+
+namespace oct {
+
+// ------------------------------------------------------------------ library-FFT route (lengths without a fused kernel)
+// samplesPerLine > 4096, or not a power of two above 2047: the reference hands such lengths to cuFFT like any other
+// (cu:1140); here they take the reference's own pass structure -- gather (k-linearisation x window x phasor, cu:213-489) ->
+// batched inverse C2C (hipFFT, bound with dlopen) -> epilogue (cu:567-584, cu:699-741, flip cu:787-807) -- through a complex
+// buffer in HBM.  A completeness route: ~28 B of traffic per sample instead of 4.
+__global__ __launch_bounds__(256) void oct_lib_gather_kernel(const float* samples, f2* out, const float4* lut, int N, size_t lines, size_t linesInBuffer, int rs) {
+	const size_t total = lines * (size_t)N, S = linesInBuffer * (size_t)N;
+	for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		const size_t line = idx / (size_t)N;
+		const int j = (int)(idx - line * (size_t)N);
+		const float4 L = lut[j];
+		const float* row = samples + line * (size_t)N;
+		float y;
+		if (rs == 0) {
+			y = row[j];
+		} else if (rs == 1) {  // cu:213-231
+			const int n1 = (int)L.x;
+			y = row[n1] + (row[n1 + 1] - row[n1]) * (L.x - (float)n1);
+		} else if (rs == 2) {  // cu:258-295
+			const int n1 = (int)L.x, n0 = abs(n1 - 1);
+			const float y0 = row[n0], y1 = row[n1], y2 = row[n1 + 1], y3 = row[n1 + 2], pos = L.x - (float)n1;
+			const float a = -y0 + 3.0f * (y1 - y2) + y3, b = 2.0f * y0 - 5.0f * y1 + 4.0f * y2 - y3, c = -y0 + y2;
+			y = 0.5f * pos * (a * pos * pos + b * pos + c) + y1;
+		} else {  // cu:297-326: taps cross line borders, the offset of the first line is 8
+			long long off = (long long)line * N;
+			if (off < 8) off = 8;
+			if (off > (long long)S - 9) off = (long long)S - 9;
+			const int n0 = (int)L.x;
+			float sum = 0.0f;
+			for (int i = -7; i <= 8; i++) {
+				const long long gi = off + n0 + i;
+				const float t = (gi >= 0 && gi < (long long)S) ? samples[gi] : 0.0f;
+				const float x = L.x - (float)(n0 + i), ax = fabsf(x);
+				const float PI_F = 3.141592654f, PI_OVER_8 = 0.3926990817f;
+				const float k = (ax < 0.00001f) ? 1.0f : (sinf(PI_F * ax) / (PI_F * ax)) * (sinf(PI_OVER_8 * ax) / (PI_OVER_8 * ax));
+				sum += t * k;
+			}
+			y = sum;
+		}
+		const float yw = y * L.y;
+		out[idx] = f2{yw * L.z, yw * L.w};
+	}
+}
+
+__global__ __launch_bounds__(256) void oct_lib_epilogue_kernel(const f2* Z, float* out, const f2* meanLine, int N, size_t lines, unsigned ascansPerBscan,
+                                                               unsigned linesInBuffer, int flip, int subtractMean, float sA, float sB, int logScale) {
+	const int W = N / 2;
+	const size_t total = lines * (size_t)W;
+	for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		const size_t line = idx / (size_t)W;
+		const int k = (int)(idx - line * (size_t)W);
+		f2 z = Z[line * (size_t)N + k];
+		if (subtractMean) z = z - meanLine[k];
+		const float p = z.x * z.x + z.y * z.y;
+		const float s = logScale ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
+		size_t orow = line;
+		if (flip) {
+			const unsigned b = (unsigned)(line / ascansPerBscan), as = (unsigned)(line - (size_t)b * ascansPerBscan);
+			if ((b & 1u) == 0u && (b + 2u) * ascansPerBscan <= linesInBuffer) orow = (size_t)b * ascansPerBscan + (ascansPerBscan - 1u - as);
+		}
+		out[orow * (size_t)W + k] = sA * s + sB;
+	}
+}
+
+}  // namespace oct

@@ -76,7 +76,7 @@ def test_no_cpu_fallback_without_device():
 def test_unsupported_length_is_reported():
     L = _lib.lib()
     h = C.c_void_p()
-    acq = _lib.AcquisitionParams(5000, 8, 2, 1, 12)  # not a power of two and beyond the Bluestein range
+    acq = _lib.AcquisitionParams(70000, 8, 2, 1, 12)  # beyond every route (fused <= 4096, Bluestein <= 2047, library FFT <= 65536)
     p = OctAlgorithmParameters().pod()
     rc = L.octpipe_create(C.byref(h), 0, C.byref(acq), C.byref(p), None, None)
     assert rc == 5 and not h.value

@@ -277,6 +277,44 @@ def test_non_power_of_two_lengths_bluestein(N, interp):
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("N", [8192, 3000, 2500, 16384])
+@pytest.mark.parametrize("case", ["v180", "linear", "lanczos", "rolling8", "flip", "nothing", "lin_scale", "no_dispersion"])
+def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
+    """samplesPerLine > 4096 or a non-power of two above 2047: gather -> hipFFT (batched inverse C2C) -> epilogue through a
+    complex buffer, the reference's own pass structure (cu:1448-1543); image and spectrum against the oracle"""
+    if N == 16384 and case not in ("v180", "flip"):
+        pytest.skip("longest length on two cases")
+    A, B = 20, 2
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    CASES[case](p)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + len(case))
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "N=%d %s" % (N, case))
+    if not p.bscanFlip:
+        spec = pipe.debug_spectrum(d.data_ptr(), A * B)
+        ospec = o.last_spectrum().reshape(-1, N).copy()
+        if p.fixedPatternNoiseRemoval:
+            ospec[:, :N // 2] += o.mean_line()[:N // 2]
+        common.compare_spectra(spec, ospec, N, case)
+    pipe.close(); o.close()
+
+
+def test_library_fft_route_determines_its_own_mean_line():
+    N, A, B = 8192, 24, 2
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=81)
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    common.check_min_variance_mean(pipe.mean_line(), pipe.debug_spectrum(d.data_ptr(), A), N, "N=8192 mean line")
+    assert np.isfinite(pipe.processed_host()).mean() > 0.99
+    pipe.close()
+
+
 MIXED_CASES = ["v180", "linear", "no_dispersion", "no_window", "resample_only", "window_dispersion_only", "nothing", "rolling8",
                "rolling64_linear", "lin_scale", "scale_coeff_addend", "flip", "no_fpn", "gauss_window"]
 
