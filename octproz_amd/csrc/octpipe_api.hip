@@ -682,7 +682,8 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "packed 12-bit buffers need an even number of samples");
 	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
-	const bool needLibFft = !oct::fused_supported(acq->samplesPerLine) && oct::bluestein_log2m(acq->samplesPerLine) < 0;
+	// OCTPIPE_FORCE_LIBFFT=1: every length through the library route (measurement: the reference's multi-pass structure on this GPU)
+	const bool needLibFft = (!oct::fused_supported(acq->samplesPerLine) && oct::bluestein_log2m(acq->samplesPerLine) < 0) || getenv("OCTPIPE_FORCE_LIBFFT") != nullptr;
 	if (needLibFft && (acq->samplesPerLine < 8 || acq->samplesPerLine > 65536))
 		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must lie in 8..65536");
 	int count = 0;
