@@ -125,6 +125,9 @@ typedef struct OctHostCurveSettings {
  * NULL; the acquisition group is "Virtual OCT System" (stored as Virtual%20OCT%20System). */
 int octhost_load_settings_ini(const char* path, OctPipeParams* params, OctHostCurveSettings* curves,
                               OctHostVirtualParams* vsys, char* vsysFilePath, size_t vsysFilePathSize);
+/* Writes the same file (the keys above; what the Recorder's "save meta info" leg stores next to a recording). */
+int octhost_save_settings_ini(const char* path, const OctPipeParams* params, const OctHostCurveSettings* curves,
+                              const OctHostVirtualParams* vsys, const char* vsysFilePath, const char* timestamp);
 /* "index;value" CSV with one header line (src/octalgorithmparametersmanager.cpp:12-45).  *count
  * receives the number of data lines even when it exceeds capacity. */
 int octhost_load_curve_csv(const char* path, float* out, unsigned capacity, unsigned* count);

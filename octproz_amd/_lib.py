@@ -114,7 +114,7 @@ OCTHOST_SYMBOLS = [
     "octhost_system_start", "octhost_system_stop", "octhost_system_running", "octhost_system_buffer",
     "octhost_system_acquisition_params", "octhost_last_error",
     "octhost_processing_run", "octhost_processing_run_pipeline", "octhost_processing_run_group",
-    "octhost_load_settings_ini", "octhost_load_curve_csv", "octhost_save_curve_csv",
+    "octhost_load_settings_ini", "octhost_save_settings_ini", "octhost_load_curve_csv", "octhost_save_curve_csv",
     "octhost_recorder_create", "octhost_recorder_destroy", "octhost_recorder_init", "octhost_recorder_record",
     "octhost_recorder_abort", "octhost_recorder_state", "octhost_recorder_path", "octhost_recorder_error", "octhost_timestamp",
 ]
@@ -159,6 +159,7 @@ def lib():
         L.octhost_buffer_set_curr_index.restype = None
         L.octhost_system_acquisition_params.argtypes = [C.c_void_p, C.c_void_p]
         L.octhost_load_settings_ini.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.octhost_save_settings_ini.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
         L.octhost_load_curve_csv.argtypes = [C.c_char_p, C.c_void_p, C.c_uint, C.c_void_p]
         L.octhost_save_curve_csv.argtypes = [C.c_char_p, C.c_void_p, C.c_uint]
         L.octhost_recorder_create.restype = C.c_void_p

@@ -140,6 +140,42 @@ int octhost_load_settings_ini(const char* path, OctPipeParams* params, OctHostCu
 	return OCTPIPE_OK;
 }
 
+// Writer of the same file (the Recorder's "save meta info" leg stores the settings next to a recording, and OCTproZ reads the
+// file back at start-up): the keys octhost_load_settings_ini understands, QSettings syntax (true / false, %20 in group names).
+int octhost_save_settings_ini(const char* path, const OctPipeParams* params, const OctHostCurveSettings* curves,
+                              const OctHostVirtualParams* vsys, const char* vsysFilePath, const char* timestamp) {
+	if (!path || !params) return OCTPIPE_ERR_INVALID_ARGUMENT;
+	FILE* f = fopen(path, "w");
+	if (!f) return OCTPIPE_ERR_INVALID_ARGUMENT;
+	auto B = [](int v) { return v ? "true" : "false"; };
+	fprintf(f, "[General]\ntimestamp=%s\n\n", timestamp ? timestamp : "");
+	fprintf(f, "[record]\nsave_as_32_bit_float=%s\n\n", B(params->streamFloatToHost));
+	fprintf(f, "[processing]\n");
+	fprintf(f, "addend=%.9g\nbitshift=%s\ncoeff=%.9g\n", params->signalAddend, B(params->bitshift), params->signalMultiplicator);
+	fprintf(f, "dispersion_compensation=%s\n", B(params->dispersionCompensation));
+	if (curves) for (int i = 0; i < 4; ++i) fprintf(f, "dispersion_compensation_d%d=%.9g\n", i, curves->d[i]);
+	fprintf(f, "fixed_pattern_removal=%s\nfixed_pattern_removal_continuously=%s\nfixed_pattern_removal_bscans=%u\n", B(params->fixedPatternNoiseRemoval),
+	        B(params->continuousFixedPatternNoiseDetermination), params->bscansForNoiseDetermination);
+	fprintf(f, "flip_bscans=%s\nlog=%s\nmax=%.9g\nmin=%.9g\n", B(params->bscanFlip), B(params->signalLogScaling), params->signalGrayscaleMax, params->signalGrayscaleMin);
+	fprintf(f, "resampling=%s\n", B(params->resampling));
+	if (curves) for (int i = 0; i < 4; ++i) fprintf(f, "resampling_c%d=%.9g\n", i, curves->c[i]);
+	fprintf(f, "resampling_interpolation=%d\nsinusoidal_scan_correction=%s\n", params->resamplingInterpolation, B(params->sinusoidalScanCorrection));
+	if (curves) fprintf(f, "window_center_position=%.9g\nwindow_fill_factor=%.9g\nwindow_type=%d\n", curves->windowCenter, curves->windowFillFactor, curves->windowType);
+	fprintf(f, "windowing=%s\nbackground_removal=%s\nbackground_removal_window_size=%d\n", B(params->windowing), B(params->backgroundRemoval), params->rollingAverageWindowSize);
+	if (curves) fprintf(f, "custom_resampling=%s\ncustom_resampling_filepath=%s\npost_processing_background_filepath=%s\n", B(curves->customResampling),
+	                    curves->customResamplingFilePath, curves->postBackgroundFilePath);
+	fprintf(f, "post_processing_background_removal=%s\npost_processing_background_removal_offset=%.9g\npost_processing_background_removal_weight=%.9g\n\n",
+	        B(params->postProcessBackgroundRemoval), params->postProcessBackgroundOffset, params->postProcessBackgroundWeight);
+	fprintf(f, "[streaming]\nstreaming_enabled=%s\nstreaming_skip=%u\n\n", B(params->streamToHost), params->streamingBuffersToSkip);
+	if (vsys) {
+		fprintf(f, "[Virtual%%20OCT%%20System]\nbit_depth=%u\nbuffers_from_file=%u\nbuffers_per_volume=%u\ndepth=%u\nfile_path=%s\nheight=%u\nwait_time=%u\nwidth=%u\n",
+		        vsys->bitDepth, vsys->buffersFromFile, vsys->buffersPerVolume, vsys->depth, vsysFilePath ? vsysFilePath : "", vsys->height, vsys->waitTimeUs, vsys->width);
+		fprintf(f, "copy_file_to_ram=%s\nbscan_offset=%u\nsync_with_processing=%s\n", B(vsys->copyFileToRam), vsys->bscanOffset, B(vsys->syncWithProcessing));
+	}
+	fclose(f);
+	return OCTPIPE_OK;
+}
+
 int octhost_load_curve_csv(const char* path, float* out, unsigned capacity, unsigned* count) {
 	if (!path || !count) return OCTPIPE_ERR_INVALID_ARGUMENT;
 	*count = 0;

@@ -232,3 +232,22 @@ def load_settings_ini(path, params=None):
             "buffers_per_volume": vs.buffersPerVolume, "buffers_from_file": vs.buffersFromFile, "bscan_offset": vs.bscanOffset,
             "wait_time_us": vs.waitTimeUs, "copy_file_to_ram": bool(vs.copyFileToRam), "sync_with_processing": bool(vs.syncWithProcessing)}
     return p, vsys
+
+
+def save_settings_ini(path, p, vsys=None, timestamp=""):
+    """Write an OCTproZ settings.ini (sidebar.h:47-94 key names) for an OctAlgorithmParameters; `vsys` as returned by
+    load_settings_ini (optional)."""
+    from ._lib import CurveSettings, VirtualParams
+    pod = p.pod()
+    cs = CurveSettings()
+    cs.c[:] = [p.c0, p.c1, p.c2, p.c3]
+    cs.d[:] = [p.d0, p.d1, p.d2, p.d3]
+    cs.windowType, cs.windowCenter, cs.windowFillFactor = int(p.window), p.windowCenter, p.windowFillFactor
+    cs.customResampling = 1 if p.useCustomResampleCurve else 0
+    v = vsys or {}
+    vs = VirtualParams(None, int(v.get("bit_depth", p.bitDepth)), int(v.get("width", p.samplesPerLine)), int(v.get("height", p.ascansPerBscan)),
+                       int(v.get("depth", p.bscansPerBuffer)), int(v.get("buffers_per_volume", p.buffersPerVolume)), int(v.get("buffers_from_file", 2)),
+                       int(v.get("bscan_offset", 0)), int(v.get("wait_time_us", 0)), 1 if v.get("copy_file_to_ram", True) else 0,
+                       1 if v.get("sync_with_processing", True) else 0)
+    check(_lib.lib().octhost_save_settings_ini(path.encode(), C.byref(pod), C.byref(cs), C.byref(vs), str(v.get("file_path", "")).encode(),
+                                               timestamp.encode()))

@@ -105,3 +105,32 @@ def test_custom_resampling_curve_from_settings(tmp_path):
     open(ini, "w").write(V180_INI.replace("custom_resampling=false", "custom_resampling=true").replace("custom_resampling_filepath=", "custom_resampling_filepath=" + csv))
     p, _ = P.load_settings_ini(ini)
     assert p.useCustomResampleCurve and np.array_equal(p.resampleCurve, np.arange(1024, dtype=np.float32) * 0.5)
+
+
+def test_settings_ini_round_trip(tmp_path):
+    """octhost_save_settings_ini writes what octhost_load_settings_ini (and OCTproZ) reads: every processing field, the curve
+    coefficients and the virtual-system group survive a round trip, booleans as true / false, the group name %20-escaped"""
+    from octproz_amd.params import load_settings_ini, save_settings_ini, v180_benchmark_params
+    p = v180_benchmark_params(2048, 300, 7, buffers_per_volume=3)
+    p.bitshift, p.bscanFlip, p.backgroundRemoval, p.rollingAverageWindowSize = 1, 1, 1, 33
+    p.postProcessBackgroundRemoval, p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 1, 0.75, -0.125
+    p.streamToHost, p.streamingBuffersToSkip, p.sinusoidalScanCorrection = 1, 4, 1
+    p.signalMultiplicator, p.signalAddend = 2.5, -0.25
+    path = str(tmp_path / "settings.ini")
+    vs = {"file_path": "/data/rec.raw", "buffers_from_file": 5, "bscan_offset": 3, "wait_time_us": 11, "copy_file_to_ram": False, "sync_with_processing": True}
+    save_settings_ini(path, p, vs, timestamp="20250504_141131540")
+    text = open(path).read()
+    assert "[Virtual%20OCT%20System]" in text and "bitshift=true" in text and "timestamp=20250504_141131540" in text
+    q, vsys = load_settings_ini(path)
+    for name in ("bitshift", "bscanFlip", "signalLogScaling", "sinusoidalScanCorrection", "signalGrayscaleMin", "signalGrayscaleMax", "signalMultiplicator",
+                 "signalAddend", "backgroundRemoval", "rollingAverageWindowSize", "resampling", "resamplingInterpolation", "dispersionCompensation", "windowing",
+                 "fixedPatternNoiseRemoval", "continuousFixedPatternNoiseDetermination", "bscansForNoiseDetermination", "postProcessBackgroundRemoval",
+                 "postProcessBackgroundWeight", "postProcessBackgroundOffset", "streamToHost", "streamingBuffersToSkip", "samplesPerLine", "ascansPerBscan",
+                 "bscansPerBuffer", "buffersPerVolume", "bitDepth"):
+        assert getattr(q, name) == getattr(p, name), name
+    for name in ("c0", "c1", "c2", "c3", "d0", "d1", "d2", "d3", "windowCenter", "windowFillFactor"):
+        assert np.float32(getattr(q, name)) == np.float32(getattr(p, name)), name
+    assert int(q.window) == int(p.window)
+    assert np.array_equal(q.resampleCurve, p.resampleCurve) and np.array_equal(q.windowCurve, p.windowCurve) and np.array_equal(q.dispersionCurve, p.dispersionCurve)
+    assert vsys["file_path"] == "/data/rec.raw" and vsys["buffers_from_file"] == 5 and vsys["bscan_offset"] == 3 and vsys["wait_time_us"] == 11
+    assert vsys["copy_file_to_ram"] is False and vsys["sync_with_processing"] is True
