@@ -44,6 +44,7 @@ struct FusedArgs {
 	int flip;
 	int subtractMean;
 	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
+	const float* lanczosW;   // RS_LANCZOS: [N][16] tap weights L(rho_j - (n0_j + i)), i = -7..8 (cu:297-326), the same for every A-scan
 };
 
 // Per-length launch shape.  WAVES = A-scans in flight per workgroup; all waves of a workgroup share
@@ -521,6 +522,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	const unsigned wavesTotal = gridDim.x * (unsigned)WAVES;
 	unsigned line = blockIdx.x * (unsigned)WAVES + (unsigned)wave;
 	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16u);
+	const __amdgpu_buffer_rsrc_t lanczosR = make_rsrc(a.lanczosW, N * 64u);
 	const unsigned rowBytes = (unsigned)(N / SPL) * CB;
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 	u32x4 pre[NL];
@@ -676,10 +678,18 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			long long off = (long long)line * N;
 			if (off < 8) off = 8;
 			if (off > S - 9) off = S - 9;
-			const float* g = reinterpret_cast<const float*>(a.raw);
-			for (int t = lane; t < N + 16; t += 64) {
-				long long gi = off - 8 + t;
-				row[ROW_OFF - 8 + t] = (gi >= 0 && gi < S) ? g[gi] : 0.0f;
+			// 16-byte loads through a descriptor that ends with the buffer: reads past it return 0
+			const float* g = reinterpret_cast<const float*>(a.raw) + (off - 8);
+			const long long left = (S - (off - 8)) * 4;
+			const __amdgpu_buffer_rsrc_t haloR = make_rsrc(g, (uint32_t)(left < (long long)(N + 16) * 4 ? left : (long long)(N + 16) * 4));
+			constexpr int UNITS = (N + 16) / 4;
+#pragma unroll
+			for (int i = 0; i < (UNITS + 63) / 64; i++) {
+				const int u = lane + 64 * i;
+				if (u < UNITS) {
+					const f32x4 f = buf_load128(haloR, u * 16, 0);
+					*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 4 * u]) = float4{f.x, f.y, f.z, f.w};
+				}
 			}
 		}
 		wave_sync_lds();
@@ -756,11 +766,16 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			} else if constexpr (RS == RS_NONE) {
 				y = rowl[64 * q];
 			} else {
+				// the 16 weights depend on the sample index only: read from the table the host computed (64 B per sample, L2-resident)
+				// instead of 32 sinf evaluations per sample and A-scan; same summation order as cu:313-321
 				const int n0 = (int)L.x;
 				const float* t = &row[ROW_OFF + n0];
+				f32x4 w[4];
+#pragma unroll
+				for (int c = 0; c < 4; c++) w[c] = buf_load128(lanczosR, lane * 64, q * 4096 + c * 16);
 				float sum = 0.0f;
 #pragma unroll
-				for (int i = -7; i <= 8; i++) sum += t[i] * lanczos8(L.x - (float)(n0 + i));
+				for (int i = -7; i <= 8; i++) sum += t[i] * w[(i + 7) >> 2][(i + 7) & 3];
 				y = sum;
 			}
 			if constexpr (LDS_LUT || REGLIN) {

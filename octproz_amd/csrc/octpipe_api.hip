@@ -90,6 +90,7 @@ struct octpipe {
 	void* fftPlan[2] = {nullptr, nullptr};
 	size_t fftPlanBatch[2] = {0, 0};
 	bool mixed = false;        // samplesPerLine == 1664: mixed-radix kernel (mixed1664.h); Bluestein stays for Lanczos
+	float* d_lanczosW = nullptr;   // [N][16] Lanczos tap weights (uploaded with the LUT while that interpolation is selected)
 	float4* d_lutPlain = nullptr;  // mixed: the LUT without the Bluestein chirp folded in
 	f2* d_twMixed = nullptr;       // mixed: W_1664^{n2 k1}, [32][52]
 	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
@@ -180,6 +181,24 @@ int uploadLut(octpipe* h) {
 	}
 	HIP_TRY(hipMemcpyAsync(h->d_lut, lut.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
 	if (h->mixed) HIP_TRY(hipMemcpyAsync(h->d_lutPlain, plain.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
+	if (p.resampling && p.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS) {
+		// cu:297-326: L(t) = sinc(pi t) sinc(pi t / 8) at t = rho_j - (n0_j + i), i = -7..8, float32 like the reference's device code;
+		// the weights depend on the sample index only, so they are evaluated once per curve instead of per A-scan
+		std::vector<float> w((size_t)N * 16);
+		const float PI_F = 3.141592654f, PI_OVER_8 = 0.3926990817f;
+		for (int j = 0; j < N; ++j) {
+			const float rho = lut[j].x;
+			const int n0 = (int)rho;
+			for (int i = -7; i <= 8; ++i) {
+				const float x = rho - (float)(n0 + i), ax = fabsf(x);
+				const float s1 = sinf(PI_F * ax) / (PI_F * ax), s8 = sinf(PI_OVER_8 * ax) / (PI_OVER_8 * ax);
+				w[(size_t)j * 16 + (size_t)(i + 7)] = (ax < 0.00001f) ? 1.0f : (s1 * s8);
+			}
+		}
+		if (!h->d_lanczosW) HIP_TRY(hipMalloc((void**)&h->d_lanczosW, sizeof(float) * w.size()));
+		HIP_TRY(hipMemcpyAsync(h->d_lanczosW, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice, h->stream));
+		HIP_TRY(hipStreamSynchronize(h->stream));
+	}
 	HIP_TRY(hipStreamSynchronize(h->stream));  // lut is a stack vector
 	h->lutDirty = false;
 	return OCTPIPE_OK;
@@ -375,6 +394,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	a.rollingW = p.rollingAverageWindowSize;
 	a.flip = p.bscanFlip;
 	a.subtractMean = p.fixedPatternNoiseRemoval;
+	a.lanczosW = h->d_lanczosW;
 	// cu:718 / cu:739 rewritten as one multiply-add on log2(P) resp. sqrt(P); constants in double
 	const double half = (double)(h->N / 2), range = (double)p.signalGrayscaleMax - (double)p.signalGrayscaleMin;
 	const double coeff = p.signalMultiplicator, addend = p.signalAddend, mn = p.signalGrayscaleMin;
@@ -774,7 +794,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed};
+	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_lanczosW};
 	for (void* b : bufs) if (b) hipFree(b);
 	if (h->copyStream) hipStreamDestroy(h->copyStream);
 	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);
@@ -785,7 +805,8 @@ int octpipe_destroy(octpipe_t* h) {
 int octpipe_set_params(octpipe_t* h, const OctPipeParams* params) {
 	if (!h || !params) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	const OctPipeParams& o = h->params;
-	if (o.resampling != params->resampling || o.windowing != params->windowing || o.dispersionCompensation != params->dispersionCompensation)
+	if (o.resampling != params->resampling || o.windowing != params->windowing || o.dispersionCompensation != params->dispersionCompensation ||
+	    o.resamplingInterpolation != params->resamplingInterpolation)
 		h->lutDirty = true;
 	// one-shot requests stay pending until the pipeline has consumed them (cu:1524, cu:1561),
 	// even if the caller's next snapshot no longer carries them
