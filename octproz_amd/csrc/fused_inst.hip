@@ -86,6 +86,33 @@ hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool
 		}
 	}
 #endif
+	// 8-bit containers (bitDepth <= 8, cu:109-118) and two's complement 16 bit straight from the raw buffer
+	if (intype == IN_U8 || intype == IN_I16) {
+		if (rs == RS_LANCZOS) return hipErrorInvalidValue;
+#if OCT_LOG2N >= 9
+		const bool u8 = intype == IN_U8;
+#else
+		if (intype == IN_U8) return hipErrorInvalidValue;  // N = 256: half a chunk per lane -> prepared route
+		const bool u8 = false;
+#endif
+		switch (rs) {
+		case RS_NONE:
+#if OCT_LOG2N >= 9
+			if (u8) return launch_out<IN_U8, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+#endif
+			return launch_out<IN_I16, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		case RS_LINEAR:
+#if OCT_LOG2N >= 9
+			if (u8) return launch_out<IN_U8, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+#endif
+			return launch_out<IN_I16, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		default:
+#if OCT_LOG2N >= 9
+			if (u8) return launch_out<IN_U8, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+#endif
+			return launch_out<IN_I16, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		}
+	}
 	if (intype != IN_F32) return hipErrorInvalidValue;
 	switch (rs) {
 	case RS_NONE: return launch_out<IN_F32, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);

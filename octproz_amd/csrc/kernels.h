@@ -26,7 +26,7 @@
 
 namespace oct {
 
-enum { IN_U8 = 0, IN_U16 = 1, IN_U32 = 2, IN_F32 = 3, IN_P12U = 4, IN_P12S = 5 };  // P12: packed 12 bit (Mono12p), unsigned / two's complement
+enum { IN_U8 = 0, IN_U16 = 1, IN_U32 = 2, IN_F32 = 3, IN_P12U = 4, IN_P12S = 5, IN_I16 = 6 };  // P12: packed 12 bit (Mono12p), unsigned / two's complement
 enum { RS_NONE = 0, RS_LINEAR = 1, RS_CUBIC = 2, RS_LANCZOS = 3 };
 
 struct FusedArgs {
@@ -152,6 +152,8 @@ template <int N> struct Chunk<IN_U16, N> {
 	typedef u32x4 T;  // SPL = 4 uses .x/.y only
 };
 template <int N> struct Chunk<IN_F32, N> { static constexpr int SPL = 4, BYTES = 16; typedef u32x4 T; };
+template <int N> struct Chunk<IN_I16, N> { static constexpr int SPL = 4, BYTES = 8; typedef u32x4 T; };   // two's complement 16 bit (OCTPIPE_FORMAT_INT16)
+template <int N> struct Chunk<IN_U8, N> { static constexpr int SPL = 8, BYTES = 8; typedef u32x4 T; };    // bitDepth <= 8 (cu:109-118): 8 samples per 8-byte load
 // packed 12 bit: 8 samples in 12 bytes per lane (one buffer_load_dwordx3), 1.5 N bytes per row instead of 2 N
 template <int N> struct Chunk<IN_P12U, N> { static constexpr int SPL = 8, BYTES = 12; typedef u32x4 T; };
 template <int N> struct Chunk<IN_P12S, N> { static constexpr int SPL = 8, BYTES = 12; typedef u32x4 T; };
@@ -170,6 +172,13 @@ OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 		const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
 		if (s == 0) return float4{(float)(a & 0xffffu), (float)(a >> 16), (float)(b & 0xffffu), (float)(b >> 16)};
 		return float4{(float)((a & 0xffffu) >> s), (float)((a >> 16) >> s), (float)((b & 0xffffu) >> s), (float)((b >> 16) >> s)};
+	} else if constexpr (INTYPE == IN_I16) {
+		const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
+		const int i0 = (int)(a << 16) >> 16, i1 = (int)a >> 16, i2 = (int)(b << 16) >> 16, i3 = (int)b >> 16;  // arithmetic >> 4 for signed data
+		return float4{(float)(i0 >> s), (float)(i1 >> s), (float)(i2 >> s), (float)(i3 >> s)};
+	} else if constexpr (INTYPE == IN_U8) {
+		const uint32_t a = h ? c.y : c.x;  // samples 0..3 in c.x, 4..7 in c.y
+		return float4{(float)((a & 0xffu) >> s), (float)(((a >> 8) & 0xffu) >> s), (float)(((a >> 16) & 0xffu) >> s), (float)((a >> 24) >> s)};
 	} else if constexpr (INTYPE == IN_P12U || INTYPE == IN_P12S) {
 		// include/octpipe.h OCTPIPE_FORMAT_*12_PACKED: consecutive 12-bit fields of a little-endian bit stream,
 		// 8 samples in the 96 bits (c.x, c.y, c.z); h selects samples 0..3 or 4..7; the >> 4 is arithmetic for signed data

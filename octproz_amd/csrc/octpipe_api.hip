@@ -372,7 +372,13 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	const bool packed = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED || h->sampleFormat == OCTPIPE_FORMAT_INT12_PACKED;
 	const bool packedDirect = packed && !h->bluestein && !h->libfft && !h->forcePrepared && h->log2n >= 9 && !roll && rs != oct::RS_LANCZOS;
 	if (packedDirect) intype = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED ? oct::IN_P12U : oct::IN_P12S;
-	if (needsPrepared(h) && !mixedDirect && !packedDirect) {
+	// likewise 8-bit containers (bitDepth <= 8, the reference's own rule cu:109-118; N >= 512) and two's complement 16 bit
+	const bool plainFused = !h->bluestein && !h->libfft && !h->forcePrepared && !roll && rs != oct::RS_LANCZOS;
+	const bool u8Direct = plainFused && h->sampleFormat == OCTPIPE_FORMAT_AUTO && h->bytesPerSample == 1 && h->log2n >= 9;
+	const bool i16Direct = plainFused && h->sampleFormat == OCTPIPE_FORMAT_INT16;
+	if (u8Direct) intype = oct::IN_U8;
+	if (i16Direct) intype = oct::IN_I16;
+	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
 		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(h->S)), dim3(256), 0, h->stream, d_raw, h->d_prepared,

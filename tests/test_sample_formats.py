@@ -134,6 +134,37 @@ def test_fused_packed_12bit_route_is_bit_identical(N, interp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["uint8", "int16"])
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+@pytest.mark.parametrize("bitshift", [0, 1])
+def test_fused_uint8_and_int16_routes_equal_the_prepared_route(kind, N, bitshift):
+    """8-bit containers (bitDepth <= 8, cu:109-118) and two's complement 16-bit samples are unpacked inside the fused kernel;
+    the image must equal the prepared float32 route (oct_prepare_kernel, pinned bit-exactly against the oracle) bit for bit"""
+    from octproz_amd import Pipeline, v180_benchmark_params
+    A, B = 24, 2
+    rng = np.random.default_rng(N + bitshift)
+    p = v180_benchmark_params(N, A, B)
+    p.bitshift = bitshift
+    if kind == "uint8":
+        raw = rng.integers(0, 255, N * A * B, endpoint=True).astype(np.uint8)
+        p.bitDepth, fmt = 8, 0
+    else:
+        raw = rng.integers(-32768, 32767, N * A * B, endpoint=True).astype(np.int16)
+        p.bitDepth, fmt = 16, FORMATS["int16"]
+    raw[:4] = [0, raw.max(), raw.min(), 1]
+    a = Pipeline(p, device=0, sample_format=fmt)
+    d = _dev(raw)
+    a.process_device(d.data_ptr()); a.synchronize()
+    fused, ml = a.processed_host(), a.mean_line()
+    a.debug_force_prepared(True)
+    a.set_mean_line(ml, pin=True)
+    a.process_device(d.data_ptr()); a.synchronize()
+    assert np.array_equal(a.processed_host().view(np.uint32), fused.view(np.uint32))
+    assert np.isfinite(fused).mean() > 0.99
+    a.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bitshift", [0, 1])
 def test_fused_signed_packed_route_equals_prepared_route(bitshift):
     from octproz_amd import Pipeline, v180_benchmark_params
