@@ -41,6 +41,7 @@ struct FusedArgs {
 	unsigned ascansPerBscan;
 	int bitshift;
 	int rollingW;            // window half-size of the rolling average (ROLL variants)
+	int rollExact;           // 2 W x (largest sample value) < 2^24: integer window sums equal the reference's float sums
 	int flip;
 	int subtractMean;
 	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
@@ -99,7 +100,7 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 };
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
-constexpr int ROLL_PAD = 128;  // largest window half-size served by the prefix-sum route; pads of the prefix array on both sides
+constexpr int ROLL_PAD = 256;  // largest window half-size served by the prefix-sum route; pads of the prefix array on both sides
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
 // LDS slice of one wave: the staged row (+ the prefix-sum array of the rolling average) and, later in
@@ -624,10 +625,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				// (0 in front, the total behind), so the clipped window [lo, hi] is P[j+W] - P[j-W] for every j without a clamp and
 				// every address is "lane base + immediate".  Each lane corrects the four consecutive samples it unpacked and the
 				// row is written once, already corrected.  The division is the exact IEEE quotient: with rc = RN(1/cnt),
-				// q0 = s rc, q = fma(fma(-q0, cnt, s), rc, q0) == RN(s / cnt) for all integer s < 2^24, cnt <= 256 (checked exhaustively,
-				// tests/test_luts.py), so the result is bit-identical to the ordered float loop.
+				// q0 = s rc, q = fma(fma(-q0, cnt, s), rc, q0) == RN(s / cnt) for all integer s < 2^24, cnt <= 512 (checked exhaustively,
+				// tests/test_oracle.py), so the result is bit-identical to the ordered float loop.
 				const int W = a.rollingW;
-				if (W <= ROLL_PAD) {
+				if (W <= ROLL_PAD && a.rollExact) {
 					staged = true;
 					uint32_t* pfx = reinterpret_cast<uint32_t*>(row + N + 2 * ROW_OFF);  // [ROLL_PAD | N | ROLL_PAD]
 					uint32_t base = 0;
@@ -640,9 +641,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 						*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + 4 * lane + 256 * i]) = uint4{p0, p1, p2, p2 + x.w};
 						base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 					}
-					// pads (the FFT exchange of the previous A-scan has run over them): 2 x 64 lanes x 2 entries on each side
-					*reinterpret_cast<uint2*>(&pfx[2 * lane]) = uint2{0u, 0u};
-					*reinterpret_cast<uint2*>(&pfx[ROLL_PAD + N + 2 * lane]) = uint2{base, base};
+					// pads (the FFT exchange of the previous A-scan has run over them): 64 lanes x 4 entries on each side
+					static_assert(ROLL_PAD == 256, "pad writes: four entries per lane");
+					*reinterpret_cast<uint4*>(&pfx[4 * lane]) = uint4{0u, 0u, 0u, 0u};
+					*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + N + 4 * lane]) = uint4{base, base, base, base};
 					wave_sync_lds();
 					const uint32_t* hiP = pfx + ROLL_PAD + 4 * lane + W;      // P[j + W]
 					const uint32_t* loP = pfx + ROLL_PAD + 4 * lane - W;      // P[j - W]
@@ -706,7 +708,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		// ---- rolling average beyond the prefix-sum range: the reference's float accumulation in index order
 		if constexpr (ROLL) {
 			const int W = a.rollingW;
-			if (W > ROLL_PAD) {
+			if (W > ROLL_PAD || !a.rollExact) {
 				float* tmp = row + N + 2 * ROW_OFF;  // the prefix array's space: corrected samples, then copied back
 #pragma unroll 1
 				for (int q = 0; q < P; q++) {

@@ -398,6 +398,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	a.ascansPerBscan = (unsigned)h->A;
 	a.bitshift = p.bitshift;
 	a.rollingW = p.rollingAverageWindowSize;
+	{  // integer window sums are the reference's float sums while every partial sum stays below 2^24
+		const unsigned bits = h->acq.bitDepth > 16 ? 16 : h->acq.bitDepth;
+		const uint64_t maxSample = ((1ull << bits) - 1ull) >> (p.bitshift ? 4 : 0);
+		a.rollExact = p.rollingAverageWindowSize > 0 && 2ull * (uint64_t)p.rollingAverageWindowSize * maxSample < (1ull << 24) ? 1 : 0;
+	}
 	a.flip = p.bscanFlip;
 	a.subtractMean = p.fixedPatternNoiseRemoval;
 	a.lanczosW = h->d_lanczosW;

@@ -78,6 +78,29 @@ def test_fused_unpack_equals_standalone_unpack_bitwise():
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("N,W,bits", [(1024, 200, 12), (1024, 256, 12), (2048, 250, 12), (512, 255, 10), (1024, 129, 16), (1024, 300, 12), (4096, 256, 12)])
+def test_rolling_average_wide_windows(N, W, bits):
+    """W <= 256 takes the prefix-sum route whenever 2 W x (largest sample) < 2^24 (12-bit data: always), the ordered float loop
+    otherwise (16-bit data beyond W = 128, W > 256): both must equal the standalone kernel's ordered sum bit for bit"""
+    A, B = 24, 2
+    rng = np.random.default_rng(W + bits)
+    hi = 2 ** bits - 1
+    raw = rng.integers(0, hi, size=(B, A, N), endpoint=True).astype(np.uint16)
+    raw[0, 0, :4] = [hi, 0, hi, 1]
+    raw[1, 3, :] = hi
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth, p.backgroundRemoval, p.rollingAverageWindowSize = bits, 1, W
+    pipe = Pipeline(p, device=0)
+    d = to_device(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    fused, ml = pipe.processed_host(), pipe.mean_line()
+    pipe.debug_force_prepared(True)
+    pipe.set_mean_line(ml, pin=True)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    assert np.array_equal(fused.view(np.uint32), pipe.processed_host().view(np.uint32))
+    pipe.close()
+
+
 @pytest.mark.parametrize("N,W", [(1024, 8), (1024, 100), (1024, 128), (1024, 200), (256, 32), (2048, 64)])
 def test_rolling_average_prefix_sum_route_is_bit_identical_to_the_ordered_float_sum(N, W):
     """W <= 128: the fused kernel takes window sums from an integer prefix-sum array; the standalone

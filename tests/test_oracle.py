@@ -205,11 +205,11 @@ def test_volume_view_index_map_from_first_principles():
 
 def test_rolling_average_division_is_the_exact_quotient():
     """the fused kernel divides the integer window sum by the window length with a reciprocal and one fma correction
-    (csrc/kernels.h); that is the IEEE quotient for every sum < 2^24 and every length <= 256 (exhaustive: 4.3e9 pairs)"""
+    (csrc/kernels.h); that is the IEEE quotient for every sum < 2^24 and every window length <= 512 (exhaustive: 8.6e9 pairs)"""
     import ctypes as C
     L = octref.lib()
     L.octref_check_exact_division.restype = C.c_long
-    assert L.octref_check_exact_division(256, 1) == 0
+    assert L.octref_check_exact_division(512, 1) == 0
 
 
 def test_min_variance_checker_accepts_the_oracle_and_catches_a_wrong_bin():
