@@ -672,6 +672,18 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	return OCTPIPE_OK;
 }
 
+bool fftLibraryAvailable() {
+	static int known = -1;
+	if (known < 0) {
+		void* l = dlopen("libhipfft.so.0", RTLD_NOW | RTLD_NOLOAD);
+		if (!l) l = dlopen("libhipfft.so", RTLD_NOW | RTLD_NOLOAD);
+		if (!l) l = dlopen("libhipfft.so.0", RTLD_NOW | RTLD_LOCAL);
+		if (!l) l = dlopen("libhipfft.so", RTLD_NOW | RTLD_LOCAL);
+		known = l ? 1 : 0;
+	}
+	return known == 1;
+}
+
 int setDevice(const octpipe* h) {
 	HIP_TRY(hipSetDevice(h->device));
 	return OCTPIPE_OK;
@@ -714,7 +726,13 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
 	// OCTPIPE_FORCE_LIBFFT=1: every length through the library route (measurement: the reference's multi-pass structure on this GPU)
-	const bool needLibFft = (!oct::fused_supported(acq->samplesPerLine) && oct::bluestein_log2m(acq->samplesPerLine) < 0) || getenv("OCTPIPE_FORCE_LIBFFT") != nullptr;
+	// Lengths that are neither a power of two nor 1664: Bluestein on the in-register FFT (bluestein.h, up to 2047) or the library
+	// route; measured on MI355X the library route is 1.4-3x faster (N = 600: 160 vs 91 M A-scans/s, N = 2000: 48 vs 16 M), so it
+	// is the default where hipFFT can be loaded and Bluestein the fallback (OCTPIPE_NO_LIBFFT=1 forces it).
+	const bool noFused = !oct::fused_supported(acq->samplesPerLine) && acq->samplesPerLine != oct::kMixedLength;
+	const bool bluesteinOk = oct::bluestein_log2m(acq->samplesPerLine) >= 0;
+	bool needLibFft = (noFused && (!bluesteinOk || getenv("OCTPIPE_NO_LIBFFT") == nullptr)) || getenv("OCTPIPE_FORCE_LIBFFT") != nullptr;
+	if (needLibFft && bluesteinOk && getenv("OCTPIPE_FORCE_LIBFFT") == nullptr && !fftLibraryAvailable()) needLibFft = false;
 	if (needLibFft && (acq->samplesPerLine < 8 || acq->samplesPerLine > 65536))
 		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must lie in 8..65536");
 	int count = 0;

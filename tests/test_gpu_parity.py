@@ -279,9 +279,15 @@ def test_every_supported_length(N):
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("route", ["library", "bluestein"])
 @pytest.mark.parametrize("N", [1664, 1000, 1536, 300, 96, 2046])
 @pytest.mark.parametrize("interp", [INTERPOLATION.CUBIC, INTERPOLATION.LINEAR, INTERPOLATION.LANCZOS])
-def test_non_power_of_two_lengths_bluestein(N, interp):
+def test_non_power_of_two_lengths_bluestein(N, interp, route, monkeypatch):
+    # lengths that are neither a power of two nor 1664 take the library route by default (faster), Bluestein on the in-register
+    # FFT where hipFFT is not available or with OCTPIPE_NO_LIBFFT=1: both against the oracle
+    if route == "bluestein":
+        monkeypatch.setenv("OCTPIPE_NO_LIBFFT", "1")
+        monkeypatch.setenv("OCTPIPE_NO_MIXED", "1")
     """the reference gives any samplesPerLine to cuFFT (cu:1140); its own recording has 1664 samples"""
     if interp != INTERPOLATION.CUBIC and N not in (1664, 300):
         pytest.skip("interpolation variants on two lengths only")
@@ -389,8 +395,9 @@ def test_mixed_radix_1664_agrees_with_the_bluestein_route(monkeypatch):
     pipe.close(); blue.close(); o.close()
 
 
-def test_non_power_of_two_fpn_determination_and_flip():
-    N, A, B = 1664, 24, 4
+@pytest.mark.parametrize("N", [1664, 1000])
+def test_non_power_of_two_fpn_determination_and_flip(N):
+    A, B = 24, 4
     p = v180_benchmark_params(N, A, B)
     p.bscanFlip = 1
     raw = synthetic_raw(N, A, B, seed=77)
