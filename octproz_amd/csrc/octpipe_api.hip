@@ -120,6 +120,7 @@ struct octpipe {
 
 	bool timing = false;
 	bool noReal2 = getenv("OCTPIPE_NO_REAL2") != nullptr;  // A/B switch: keep real-input configurations on oct_fused_kernel
+	bool fullDisplay = getenv("OCTPIPE_FULL_DISPLAY") != nullptr;  // A/B switch: whole en-face frame for every buffer
 	std::vector<TimedLaunch> timed;
 	double timedMs = 0.0;
 	unsigned timedLaunches = 0;
@@ -632,7 +633,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 
 	if (p.bscanViewEnabled || p.enFaceViewEnabled) {  // cu:1571-1578, both frames in one launch
 		const uint64_t sig = displaySignature(p);
-		const bool incremental = sig == h->displaySig && getenv("OCTPIPE_FULL_DISPLAY") == nullptr;
+		const bool incremental = sig == h->displaySig && !h->fullDisplay;
 		if ((rc = updateDisplay(h, p.bscanViewEnabled != 0, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan,
 		                        p.enFaceViewEnabled != 0, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView, incremental))) return rc;
 		h->displaySig = sig;
