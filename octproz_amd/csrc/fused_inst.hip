@@ -93,7 +93,6 @@ hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool
 		const bool u8 = intype == IN_U8;
 #else
 		if (intype == IN_U8) return hipErrorInvalidValue;  // N = 256: half a chunk per lane -> prepared route
-		const bool u8 = false;
 #endif
 		switch (rs) {
 		case RS_NONE:

@@ -221,11 +221,11 @@ OCT_DEV uint32_t wave_inclusive_scan(uint32_t v) {
 	return v;
 }
 
-// cu:258-271
-OCT_DEV float cubic_hermite(float y0, float y1, float y2, float y3, float pos) {
-	float a = -y0 + 3.0f * (y1 - y2) + y3;
-	float b = 2.0f * y0 - 5.0f * y1 + 4.0f * y2 - y3;
-	float c = -y0 + y2;
+// cu:258-271; T = float, or a pair of floats (two rows interpolated at the same position with packed instructions)
+template <class T> OCT_DEV T cubic_hermite(T y0, T y1, T y2, T y3, float pos) {
+	T a = -y0 + 3.0f * (y1 - y2) + y3;
+	T b = 2.0f * y0 - 5.0f * y1 + 4.0f * y2 - y3;
+	T c = -y0 + y2;
 	float pos2 = pos * pos;
 	return 0.5f * pos * (a * pos2 + b * pos + c) + y1;
 }

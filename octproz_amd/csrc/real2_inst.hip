@@ -9,12 +9,13 @@ template <int RS, int MODE>
 hipError_t launch_real2_one(const FusedArgs& a, hipStream_t stream) {
 	auto kernel = oct_real2_kernel<RS, MODE>;
 	KernelLaunchInfo info;
+	constexpr int REAL2_WAVES = real2_waves<RS>(), REAL2_LDS_BYTES = real2_lds_bytes<RS>();
 	hipError_t e = kernel_launch_info(kernel, REAL2_WAVES * 64, REAL2_LDS_BYTES, &info);
 	if (e != hipSuccess) return e;
 	const int numCU = info.numCU;
 	const unsigned pairs = (a.numLines + 1u) / 2u;
 	const unsigned need = (pairs + REAL2_WAVES - 1) / REAL2_WAVES;
-	unsigned blocks = (unsigned)numCU;  // ~156 KiB of LDS: one persistent workgroup per CU
+	unsigned blocks = (unsigned)numCU;  // 86-121 KiB of LDS and >= 164 VGPRs x 8-12 waves: one persistent workgroup per CU
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
 	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(REAL2_WAVES * 64), REAL2_LDS_BYTES, stream, a);

@@ -17,19 +17,45 @@ namespace oct {
 #ifndef OCT_REAL2_REGTAB
 #define OCT_REAL2_REGTAB 1
 #endif
-constexpr int REAL2_WAVES = OCT_REAL2_REGTAB ? 8 : 15;
+// OCT_REAL2_ILV: the two rows of the pair are staged interleaved, (row0[n], row1[n]) as one 8-byte element, so the taps of both
+// A-scans arrive as register pairs from half as many LDS reads (`ds_read2_b64`) and the gather runs on packed FP32.
+#ifndef OCT_REAL2_ILV
+#define OCT_REAL2_ILV 1
+#endif
+// Without resampling the kernel needs 164 VGPRs and can run 3 waves per SIMD (OCT_REAL2_NONE12, like OCT_NONE12 of the general
+// kernel); measured equal to 8 waves (1 130 M A-scans/s either way: 4.6 of the ~6.3 TB/s a copy reaches), so it stays off.
+#ifndef OCT_REAL2_NONE12
+#define OCT_REAL2_NONE12 0
+#endif
+template <int RS> constexpr int real2_waves() { return !OCT_REAL2_REGTAB ? 15 : (RS == RS_NONE && OCT_REAL2_NONE12 && OCT_REAL2_ILV) ? 12 : 8; }
+template <int RS> constexpr int real2_minw() { return !OCT_REAL2_REGTAB ? 4 : real2_waves<RS>() == 12 ? 3 : 2; }
 constexpr int REAL2_ROW1 = 4224;  // byte offset of the second staged row inside the wave's slice
 constexpr int REAL2_TABLE_BYTES = (8 * 16 + 6 * 64) * 16 + 1024 * 16 + 1024 * 4;  // packed twiddles | tap weights | window
-constexpr int REAL2_LDS_BYTES = REAL2_TABLE_BYTES + REAL2_WAVES * wave_lds_bytes<1024>();
-static_assert(REAL2_LDS_BYTES <= 160 * 1024, "LDS budget of a CU");
+template <int RS> constexpr int real2_lds_bytes() { return REAL2_TABLE_BYTES + real2_waves<RS>() * wave_lds_bytes<1024>(); }
+static_assert(real2_lds_bytes<RS_NONE>() <= 160 * 1024 && real2_lds_bytes<RS_CUBIC>() <= 160 * 1024, "LDS budget of a CU");
 static_assert(REAL2_ROW1 + (1024 + 2 * ROW_OFF) * 4 <= wave_lds_bytes<1024>(), "both staged rows fit the slice");
 static_assert(513 * 8 <= wave_lds_bytes<1024>(), "mirror buffer fits the slice");
+static_assert((1024 + 2 * ROW_OFF) * 8 <= wave_lds_bytes<1024>(), "the interleaved rows fit the slice");
+
+// (a.x, a.y) * w[H] and (a.x, a.y) * w[H] + c: one packed instruction, the scalar factor is one half of a register pair
+OCT_DEV f2 pk_scale(int H, f2 a, f2 w) {  // H is a constant after unrolling
+	f2 r;
+	if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
+	else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(w));
+	return r;
+}
+OCT_DEV f2 pk_scale_fma(int H, f2 a, f2 w, f2 c) {
+	f2 r;
+	if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+	else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+	return r;
+}
 
 template <int RS, int MODE>
-__global__ __launch_bounds__(REAL2_WAVES * 64, OCT_REAL2_REGTAB ? 2 : 4) void oct_real2_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_real2_kernel(const FusedArgs a) {
 	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
-	constexpr int N = 1024, P = 16, THREADS = REAL2_WAVES * 64;
-	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, REGTAB = OCT_REAL2_REGTAB != 0;
+	constexpr int N = 1024, P = 16, REAL2_WAVES = real2_waves<RS>(), THREADS = REAL2_WAVES * 64;
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, REGTAB = OCT_REAL2_REGTAB != 0, ILV = REGTAB && OCT_REAL2_ILV != 0;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* tw = reinterpret_cast<f2*>(smem);
 	f32x4* cwL = reinterpret_cast<f32x4*>(smem + tw_lds_bytes<10>());
@@ -58,30 +84,33 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, OCT_REAL2_REGTAB ? 2 : 4) void oc
 
 	// ---- loop invariants of the lane
 	typedef __attribute__((address_space(3))) const float lds_cfloat;
+	typedef __attribute__((address_space(3))) const f2 lds_cf2;
+	f2* rowp = reinterpret_cast<f2*>(wbase);  // ILV: element n = (row0[n], row1[n])
 	const uint32_t tapBase = __builtin_amdgcn_readfirstlane(
-	    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
+	    ILV ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f2*)(rowp + ROW_OFF - 1)
+	        : (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
 	uint32_t tapA[RS == RS_NONE ? 1 : P];
 	if constexpr (RS != RS_NONE) {
 #pragma unroll
-		for (int q = 0; q < P; q++) tapA[q] = tapBase + 4u * (uint32_t)(int)a.lut[lane + 64 * q].x;
+		for (int q = 0; q < P; q++) tapA[q] = tapBase + (ILV ? 8u : 4u) * (uint32_t)(int)a.lut[lane + 64 * q].x;
 	}
 	f32x4 cwR[REGTAB && RS == RS_CUBIC ? P : 1];
-	float fracR[REGTAB && RS == RS_LINEAR ? P : 1], winR[REGTAB ? P : 1];
-	constexpr bool TW2 = REGTAB && RS != RS_CUBIC, TW3 = TW2;  // the cubic variant spends its registers on the tap weights
+	f2 fracR[REGTAB && RS == RS_LINEAR ? P / 2 : 1], winR[REGTAB ? P / 2 : 1];  // sample q in half q & 1 of pair q >> 1
+	constexpr bool TW2 = REGTAB && (ILV || RS != RS_CUBIC), TW3 = TW2;  // without ILV the cubic variant spends its registers on the tap weights
 	f32x4 twR[TW2 ? 14 : 1];
 	if constexpr (REGTAB) {
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			const float4 t = a.lut[lane + 64 * q];
-			winR[q] = t.y * t.z;
+			winR[q >> 1][q & 1] = t.y * t.z;
 			const double p = (double)__builtin_amdgcn_fractf(t.x);
 			if constexpr (RS == RS_CUBIC) {
 				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
 				// the (real) window is folded into the tap weights: one rounding of difference, no multiply after the gather
-				const double wn = (double)winR[q];
+				const double wn = (double)winR[q >> 1][q & 1];
 				cwR[q] = f32x4{(float)(wn * w0), (float)(wn * (1.0 - w0 - w2 - w3)), (float)(wn * w2), (float)(wn * w3)};
 			} else if constexpr (RS == RS_LINEAR) {
-				fracR[q] = (float)p;
+				fracR[q >> 1][q & 1] = (float)p;
 			}
 		}
 		if constexpr (TW2) {
@@ -116,15 +145,28 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, OCT_REAL2_REGTAB ? 2 : 4) void oc
 
 	for (; pi < numPairs; pi += pairsStride) {
 		// ---- stage both raw rows in LDS as float32
+		if constexpr (ILV) {
 #pragma unroll
-		for (int i = 0; i < 8; i++) {
-			float* dst = reinterpret_cast<float*>(wbase + (i >> 2) * REAL2_ROW1) + ROW_OFF + 4 * lane + 256 * (i & 3);
-			*reinterpret_cast<float4*>(dst) = chunk_to_float<IN_U16>(u32x4{pre[i].x, pre[i].y, 0u, 0u}, 0, a.bitshift ? 4u : 0u);
+			for (int c = 0; c < 4; c++) {
+				const float4 r0 = chunk_to_float<IN_U16>(u32x4{pre[c].x, pre[c].y, 0u, 0u}, 0, a.bitshift ? 4u : 0u);
+				const float4 r1 = chunk_to_float<IN_U16>(u32x4{pre[4 + c].x, pre[4 + c].y, 0u, 0u}, 0, a.bitshift ? 4u : 0u);
+				float* dst = reinterpret_cast<float*>(rowp + ROW_OFF + 4 * lane + 256 * c);
+				*reinterpret_cast<float4*>(dst) = float4{r0.x, r1.x, r0.y, r1.y};
+				*reinterpret_cast<float4*>(dst + 4) = float4{r0.z, r1.z, r0.w, r1.w};
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				float* dst = reinterpret_cast<float*>(wbase + (i >> 2) * REAL2_ROW1) + ROW_OFF + 4 * lane + 256 * (i & 3);
+				*reinterpret_cast<float4*>(dst) = chunk_to_float<IN_U16>(u32x4{pre[i].x, pre[i].y, 0u, 0u}, 0, a.bitshift ? 4u : 0u);
+			}
 		}
 		if (pi + pairsStride < numPairs) prefetch(pi + pairsStride);
 		wave_sync_lds();
 		if constexpr (RS == RS_CUBIC) {
-			if (lane < 2) {  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
+			if constexpr (ILV) {
+				if (lane == 0) rowp[ROW_OFF - 1] = rowp[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
+			} else if (lane < 2) {
 				float* r = reinterpret_cast<float*>(wbase + lane * REAL2_ROW1);
 				r[ROW_OFF - 1] = r[ROW_OFF + 1];
 			}
@@ -139,12 +181,30 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, OCT_REAL2_REGTAB ? 2 : 4) void oc
 		for (int q = 0; q < P; q++) {
 			float w;
 			if constexpr (REGTAB) {
-				w = winR[q];
+				w = winR[q >> 1][q & 1];
 			} else {
 				if ((q & 3) == 0) win4 = winL[lane + 64 * (q >> 2)];
 				w = (q & 3) == 0 ? win4.x : (q & 3) == 1 ? win4.y : (q & 3) == 2 ? win4.z : win4.w;
 			}
 			float y0, y1;
+			if constexpr (ILV) {
+				f2 y;
+				if constexpr (RS == RS_NONE) {
+					y = rowp[ROW_OFF + lane + 64 * q];
+				} else {
+					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[q]);
+					if constexpr (RS == RS_CUBIC) {
+						const f2 w01 = f2{cwR[q].x, cwR[q].y}, w23 = f2{cwR[q].z, cwR[q].w};
+						y = pk_scale_fma(1, t[3], w23, pk_scale_fma(0, t[2], w23, pk_scale_fma(1, t[1], w01, pk_scale(0, t[0], w01))));
+					} else {  // f0 + (f1 - f0) p on both rows: the expression of oct_fused_kernel (kernels.h RS_LINEAR)
+						const f2 f0 = t[1];
+						y = pk_scale_fma(q & 1, t[2] - f0, fracR[q >> 1], f0);
+					}
+				}
+				if constexpr (RS == RS_CUBIC) v[q] = y;  // window already inside the weights
+				else v[q] = pk_scale(q & 1, y, winR[q >> 1]);
+				continue;
+			}
 			if constexpr (RS == RS_NONE) {
 				y0 = row[ROW_OFF + lane + 64 * q];
 				y1 = row[REAL2_ROW1 / 4 + ROW_OFF + lane + 64 * q];
@@ -152,7 +212,7 @@ __global__ __launch_bounds__(REAL2_WAVES * 64, OCT_REAL2_REGTAB ? 2 : 4) void oc
 				f32x4 cw;
 				if constexpr (!REGTAB) cw = cwL[lane + 64 * q];
 				else if constexpr (RS == RS_CUBIC) cw = cwR[q];
-				else cw = f32x4{fracR[q], 0.0f, 0.0f, 0.0f};
+				else cw = f32x4{fracR[q >> 1][q & 1], 0.0f, 0.0f, 0.0f};
 				lds_cfloat* t0 = (lds_cfloat*)(uintptr_t)(tapA[q]);
 				lds_cfloat* t1 = (lds_cfloat*)(uintptr_t)(tapA[q] + (uint32_t)REAL2_ROW1);
 				if constexpr (RS == RS_CUBIC) {

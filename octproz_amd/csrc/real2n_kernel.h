@@ -6,7 +6,8 @@
 //
 // One wave64 per PAIR of consecutive A-scans, N/64 complex points per lane; the per-length radix plan, the planar exchange of
 // the long transforms and the strided last-pass mapping are oct_fused_kernel's (kernels.h).  Differences to it: two staged
-// rows per wave (the gather reads both with the same resampling position, one table read serves both), the transform is not
+// rows per wave (at N = 2048 interleaved sample by sample: (row0[n], row1[n]) is one 8-byte LDS element, the taps of both
+// A-scans come as register pairs from one `ds_read2_b64` per two taps and the interpolation runs on packed FP32), the transform is not
 // pruned (Z[N-k] is needed), one extra "mirror" exchange through LDS (upper half of the spectrum written in bin order, read
 // back reversed: conflict-free), and a combine step in the epilogue.  The factor 1/2 is folded into the grey-scale constants.
 // The gather evaluates the reference's own expressions (cu:225-228 linear, cu:258-271 cubic) like the general kernel of
@@ -18,9 +19,12 @@
 namespace oct {
 
 template <int LOG2N> struct Real2Cfg;
-template <> struct Real2Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; };
-template <> struct Real2Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; };
-template <> struct Real2Cfg<11> { static constexpr int WAVES = 7,  MINW = 2; };  // LDS-bound: two 8.1 KiB rows per wave
+// ILV: the two rows staged interleaved (see above).  Measured against two separate rows on one box (cubic / linear / none):
+// N = 2048 +4.7 % / 0 / 0, N = 512 0 / 0 / 0, N = 256 -2 % throughout (the 32-byte-per-lane staging stores conflict two-way
+// and there is little interpolation work to save): on for N = 2048 only.
+template <> struct Real2Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool ILV = false; };
+template <> struct Real2Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool ILV = false; };
+template <> struct Real2Cfg<11> { static constexpr int WAVES = 7,  MINW = 2; static constexpr bool ILV = true; };  // LDS-bound: two 8.1 KiB rows per wave
 
 template <int LOG2N> constexpr int real2n_slice_bytes() {
 	constexpr int N = 1 << LOG2N;
@@ -39,7 +43,8 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 	constexpr int N = 1 << LOG2N, P = N / 64, WAVES = Real2Cfg<LOG2N>::WAVES, THREADS = WAVES * 64;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
 	constexpr int NL = N / 256;  // 8-byte chunks (4 samples) per lane and row
-	constexpr int ROW1 = (N + 2 * ROW_OFF);  // float offset of the second staged row
+	constexpr int ROW1 = (N + 2 * ROW_OFF);  // float offset of the second staged row (separate rows)
+	constexpr bool ILV = Real2Cfg<LOG2N>::ILV;
 	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0;
 	static_assert(real2n_lds_bytes<LOG2N>() <= 160 * 1024, "LDS budget of a CU");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,6 +55,7 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	char* wbase = smem + real2n_table_bytes<LOG2N>() + wave * real2n_slice_bytes<LOG2N>();
 	float* row = reinterpret_cast<float*>(wbase);
+	f2* rowp = reinterpret_cast<f2*>(wbase);  // ILV: element n = (row0[n], row1[n])
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
 	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
@@ -87,15 +93,28 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 
 	for (; pi < numPairs; pi += pairsStride) {
 		// ---- stage both raw rows in LDS as float32
+		if constexpr (ILV) {
 #pragma unroll
-		for (int i = 0; i < 2 * NL; i++) {
-			float* dst = row + (i / NL) * ROW1 + ROW_OFF + 4 * lane + 256 * (i % NL);
-			*reinterpret_cast<float4*>(dst) = chunk_to_float<IN_U16>(u32x4{pre[i].x, pre[i].y, 0u, 0u}, 0, shift);
+			for (int c = 0; c < NL; c++) {
+				const float4 r0 = chunk_to_float<IN_U16>(u32x4{pre[c].x, pre[c].y, 0u, 0u}, 0, shift);
+				const float4 r1 = chunk_to_float<IN_U16>(u32x4{pre[NL + c].x, pre[NL + c].y, 0u, 0u}, 0, shift);
+				float* dst = reinterpret_cast<float*>(rowp + ROW_OFF + 4 * lane + 256 * c);
+				*reinterpret_cast<float4*>(dst) = float4{r0.x, r1.x, r0.y, r1.y};
+				*reinterpret_cast<float4*>(dst + 4) = float4{r0.z, r1.z, r0.w, r1.w};
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 2 * NL; i++) {
+				float* dst = row + (i / NL) * ROW1 + ROW_OFF + 4 * lane + 256 * (i % NL);
+				*reinterpret_cast<float4*>(dst) = chunk_to_float<IN_U16>(u32x4{pre[i].x, pre[i].y, 0u, 0u}, 0, shift);
+			}
 		}
 		if (pi + pairsStride < numPairs) prefetch(pi + pairsStride);
 		wave_sync_lds();
-		if constexpr (RS == RS_CUBIC) {
-			if (lane < 2) {  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
+		if constexpr (RS == RS_CUBIC) {  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
+			if constexpr (ILV) {
+				if (lane == 0) rowp[ROW_OFF - 1] = rowp[ROW_OFF + 1];
+			} else if (lane < 2) {
 				float* r = row + lane * ROW1;
 				r[ROW_OFF - 1] = r[ROW_OFF + 1];
 			}
@@ -109,25 +128,26 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 		for (int q = 0; q < P; q++) {
 			const int j = lane + 64 * q;
 			const float w = winL[j];
-			float y0, y1;
+			f2 y;  // (row 0, row 1) at the same resampling position
 			if constexpr (RS == RS_NONE) {
-				y0 = row[ROW_OFF + j];
-				y1 = row[ROW1 + ROW_OFF + j];
+				if constexpr (ILV) y = rowp[ROW_OFF + j];
+				else y = f2{row[ROW_OFF + j], row[ROW1 + ROW_OFF + j]};
 			} else {
 				const float rho = rhoL[j];
 				const int n1 = (int)rho;
 				const float frac = __builtin_amdgcn_fractf(rho);  // rho >= 0: == rho - (float)n1 exactly (cu:293)
-				const float* t0 = row + ROW_OFF - 1 + n1;
-				const float* t1 = t0 + ROW1;
-				if constexpr (RS == RS_CUBIC) {
-					y0 = cubic_hermite(t0[0], t0[1], t0[2], t0[3], frac);
-					y1 = cubic_hermite(t1[0], t1[1], t1[2], t1[3], frac);
+				if constexpr (ILV) {  // every operation is one packed instruction for both rows
+					const f2* t = rowp + ROW_OFF - 1 + n1;
+					if constexpr (RS == RS_CUBIC) y = cubic_hermite<f2>(t[0], t[1], t[2], t[3], frac);
+					else y = t[1] + (t[2] - t[1]) * frac;
 				} else {
-					y0 = t0[1] + (t0[2] - t0[1]) * frac;
-					y1 = t1[1] + (t1[2] - t1[1]) * frac;
+					const float* t0 = row + ROW_OFF - 1 + n1;
+					const float* t1 = t0 + ROW1;
+					if constexpr (RS == RS_CUBIC) y = f2{cubic_hermite<float>(t0[0], t0[1], t0[2], t0[3], frac), cubic_hermite<float>(t1[0], t1[1], t1[2], t1[3], frac)};
+					else y = f2{t0[1] + (t0[2] - t0[1]) * frac, t1[1] + (t1[2] - t1[1]) * frac};
 				}
 			}
-			v[q] = f2{w * y0, w * y1};
+			v[q] = y * w;
 		}
 		wave_sync_lds();  // the rows are dead from here on
 
