@@ -60,6 +60,8 @@ hipError_t launch_real2n(int log2n, int rs, bool logScale, const FusedArgs& a, h
 // N = 1664 = 32 x 4 x 13 (the reference recording's length): mixed-radix transform in registers (mixed1664.h)
 constexpr unsigned kMixedLength = 1664;
 hipError_t launch_mixed1664(int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream);
+// the same length with a real transform input (no dispersion compensation): two A-scans per transform (mixed1664_real2.h)
+hipError_t launch_mixed1664_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 
 // power-of-two lengths run the direct FFT
 inline bool fused_supported(unsigned n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }

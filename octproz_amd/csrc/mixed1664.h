@@ -13,11 +13,14 @@
 //   B  multiplies by W_1664^{n2 k1} (table in LDS) and writes T[k1][n2] to the wave's LDS slice (pitch 54: the writes are
 //      unit-stride, the reads below hit 32 different banks per half wave),
 //   C  lane 2 k1 + h reads the 26 values y[a][b], a in {h, h+2}: two 13-point transforms in registers (real-symmetric form,
-//      102 packed operations each), the radix-2 step over (a, a+2) in the lane, and the last radix-2 step between the two
-//      lanes of a pair as ONE DPP multiply-add per component (v_fmac_f32 quad_perm:[1,0,3,2]): lane h = 0 ends with
-//      X[c = 0, 1][d], lane h = 1 with -X[c = 2, 3][d] (the sign is undone where it matters: the mean line of those bins is
-//      loaded negated, |.|^2 does not see it, the spectrum output multiplies it back).
-//   Only bins k < N/2 are kept: k2(c + 2, d) = k2(c, d) + 26, so for every (c, d) exactly one lane of a pair stores.
+//      102 packed operations each), the radix-2 step over (a, a+2) in the lane (s = y_h + y_{h+2}, dd = y_h - y_{h+2}), and
+//      the last radix-2 step between the two lanes of a pair through DPP (quad_perm:[1,0,3,2]):
+//          X[c=0] = s0 + s1,  X[c=2] = s0 - s1,  X[c=1] = dd0 + i dd1,  X[c=3] = dd0 - i dd1.
+//      Image output: only bins k < N/2 are kept and k2(c + 2, d) = k2(c, d) + 26, so of {c, c + 2} exactly one is kept.  Lane
+//      h = 0 computes c in {0, 2} (it needs s1), lane h = 1 computes c in {1, 3} (it needs dd0): every lane ends with ONE kept
+//      and one upper bin per d, the epilogue runs on 13 bins per lane and every store is useful (mr::pair_step).
+//      Spectrum output (all N bins; debug and mean-line determination): lane 0 takes c in {0, 1}, lane 1 c in {2, 3} with a
+//      sign that is multiplied back.
 // Algorithmic HBM traffic as for the other lengths: 2 N bytes in (uint16), 2 N bytes out.
 #pragma once
 #include "kernels.h"
@@ -97,6 +100,38 @@ OCT_DEV float pair_fma(float acc, float v, float s) {
 	return __builtin_fmaf(p, s, acc);
 }
 
+// value of the other lane of the pair
+OCT_DEV float pair_get(float v) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false));
+}
+
+// Image-mode split of the last radix-2 step.  Lane half h computes the bins c = h and c = h + 2 of every d:
+//     k2(c, d) = (13 c + 40 d) mod 52;   the kept one (k2 < 26) is c = h when kept_first(h, d), else c = h + 2,
+//     and its k2 is k2_kept(h, d); the other one is k2_kept + 26.   k2_kept(1, d) - k2_kept(0, d) = +13 or -13.
+constexpr bool kept_first(int h, int d) { return (40 * d + 13 * h) % 52 < 26; }
+constexpr int k2_kept(int h, int d) { return (40 * d + 13 * h) % 26; }
+// With u = own term (s for h = 0, i dd for h = 1) and p = the partner's term (s1 resp. dd0):
+//     lane 0: X[0] = u + p, X[2] = u - p;     lane 1: X[1] = p + u, X[3] = p - u.
+// G = u + tau p and U = u - tau p with tau = +1 where the lane's first bin is the kept one:
+//     kept bin  = G (lane 0), tau1 G (lane 1);     upper bin = U (lane 0), -tau1 U (lane 1),   tau1 = tau of lane 1.
+// pair_step returns G and U; kept_sign / upper_sign are the factors (1 or sg, sg = -1 on lane 1) that make them true values.
+OCT_DEV void pair_step(int d /* a constant after unrolling */, f2 y0, f2 y1, int h, float sg, f2& G, f2& U) {
+	const bool T0 = kept_first(0, d), T1 = kept_first(1, d);
+	const f2 s = y0 + y1, dd = y0 - y1;
+	const f2 e = h ? s : dd;                       // what the partner needs: lane 0 shows dd0, lane 1 shows s1
+	const f2 u = h ? f2{-dd.y, dd.x} : s;
+	f2 p = f2{pair_get(e.x), pair_get(e.y)};
+	if (T0 != T1) p = p * sg;                      // tau = sg (T0) or -sg (T1)
+	if (T0) { G = u + p; U = u - p; }
+	else { G = u - p; U = u + p; }
+}
+OCT_DEV float kept_sign(int d, float sg) { return kept_first(1, d) ? 1.0f : sg; }
+OCT_DEV float upper_sign(int d, float sg) { return kept_first(1, d) ? sg : 1.0f; }
+// k2_kept of the two lanes differs by 13: the smaller one goes into the instruction's immediate offset, the lane that holds the
+// larger one adds 13 units through one of two lane registers (base + (h ? unit : 0) when lane 1 is the larger, else (h ? 0 : unit))
+constexpr bool lane1_larger(int d) { return k2_kept(0, d) < 13; }
+constexpr int k2_kept_min(int d) { return lane1_larger(d) ? k2_kept(0, d) : k2_kept(1, d); }
+
 }  // namespace mr
 
 // INTYPE: IN_U16 (raw) or IN_F32 (prepared by oct_prepare_kernel: other containers / formats, rolling average).
@@ -133,17 +168,13 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 	const f2* Tk = T + k1 * MR_PITCH;
 	const f2* baseNoWrap = Tk + 13 * h;
 	const f2* baseWrap = Tk + 13 * h - 52 * h;  // h = 0 never wraps: both bases coincide
-	// kept bins: for (ci, d) bin k = k1 + 32 (k2 mod 26), k2 = (13 ci + 40 d) mod 52, stored by lane h = (k2 >= 26)
-	f2 meanR[SPECTRUM ? 1 : 26];
+	// image mode: the lane keeps bin k1 + 32 k2_kept(h, d) for every d (mr::pair_step); its mean-line value carries the sign
+	// that pair_step leaves on the bin
+	f2 meanR[SPECTRUM ? 1 : 13];
 	if constexpr (!SPECTRUM) {
 #pragma unroll
-		for (int ci = 0; ci < 2; ci++)
-#pragma unroll
-			for (int d = 0; d < 13; d++) {
-				const int k2 = (13 * ci + 40 * d) % 52;
-				const bool mine = (k2 >= 26) == (h == 1);
-				meanR[ci * 13 + d] = (a.subtractMean && mine) ? a.meanLine[k1 + 32 * (k2 % 26)] * sg : f2{0.0f, 0.0f};
-			}
+		for (int d = 0; d < 13; d++)
+			meanR[d] = a.subtractMean ? a.meanLine[k1 + 32 * (h ? mr::k2_kept(1, d) : mr::k2_kept(0, d))] * mr::kept_sign(d, sg) : f2{0.0f, 0.0f};
 	}
 
 	const unsigned wavesTotal = gridDim.x * (unsigned)MR_WAVES;
@@ -223,28 +254,32 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 		}
 		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
 		const __amdgpu_buffer_rsrc_t specR = make_rsrc(a.spectrum + (size_t)line * N, N * 8u);
-		// lane offsets of the stores: this lane's k1 when its half is the one that keeps the bin, far out of range otherwise
-		// (a buffer store beyond the descriptor's size is dropped)
-		const int offEven = h == 0 ? k1 * 4 : 0x40000000, offOdd = h == 1 ? k1 * 4 : 0x40000000;
-#pragma unroll
-		for (int d = 0; d < 13; d++) {
-			const f2 s = Y0[d] + Y1[d], dd = Y0[d] - Y1[d];
-			const f2 w = h ? f2{-dd.y, dd.x} : dd;  // lane 1 contributes i (y1 - y3)
+		if constexpr (SPECTRUM) {
 			// lane 0: X[c=0] = s0 + s1, X[c=1] = d0 + i d1;   lane 1: -X[c=2] = s1 - s0, -X[c=3] = i d1 - d0
-			const f2 o[2] = {f2{mr::pair_fma(s.x, s.x, sg), mr::pair_fma(s.y, s.y, sg)}, f2{mr::pair_fma(w.x, w.x, sg), mr::pair_fma(w.y, w.y, sg)}};
 #pragma unroll
-			for (int ci = 0; ci < 2; ci++) {
-				const int k2 = (13 * ci + 40 * d) % 52;  // of lane 0; lane 1 holds k2 + 26 (mod 52)
-				if constexpr (SPECTRUM) {
+			for (int d = 0; d < 13; d++) {
+				const f2 s = Y0[d] + Y1[d], dd = Y0[d] - Y1[d];
+				const f2 w = h ? f2{-dd.y, dd.x} : dd;  // lane 1 contributes i (y1 - y3)
+				const f2 o[2] = {f2{mr::pair_fma(s.x, s.x, sg), mr::pair_fma(s.y, s.y, sg)}, f2{mr::pair_fma(w.x, w.x, sg), mr::pair_fma(w.y, w.y, sg)}};
+#pragma unroll
+				for (int ci = 0; ci < 2; ci++) {
+					const int k2 = (13 * ci + 40 * d) % 52;  // of lane 0; lane 1 holds k2 + 26 (mod 52)
 					const f2 z = o[ci] * sg;
 					const int kk = k1 + 32 * (h ? (k2 + 26) % 52 : k2);
 					__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, z), specR, kk * 8, 0, 0);
-				} else {
-					const f2 z = o[ci] - meanR[ci * 13 + d];
-					const float p = z.x * z.x + z.y * z.y;
-					const float f = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
-					buf_store32(a.sA * f + a.sB, outR, k2 >= 26 ? offOdd : offEven, 32 * (k2 % 26) * 4);
 				}
+			}
+		} else {
+			// one kept bin per lane and d: k = k1 + 32 k2_kept(h, d); store offset = lane register + immediate (see lane1_larger)
+			const int offA = k1 * 4 + (h ? 13 * 128 : 0), offB = k1 * 4 + (h ? 0 : 13 * 128);
+#pragma unroll
+			for (int d = 0; d < 13; d++) {
+				f2 G, U;
+				mr::pair_step(d, Y0[d], Y1[d], h, sg, G, U);
+				const f2 z = G - meanR[d];
+				const float p = z.x * z.x + z.y * z.y;
+				const float f = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
+				buf_store32(a.sA * f + a.sB, outR, mr::lane1_larger(d) ? offA : offB, 128 * mr::k2_kept_min(d));
 			}
 		}
 		__builtin_amdgcn_s_setprio(0);

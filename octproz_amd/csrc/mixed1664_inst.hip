@@ -1,6 +1,7 @@
 // mixed1664_inst.hip -- instantiates the mixed-radix kernel for N = 1664 (mixed1664.h)
 #include "launch.h"
 #include "mixed1664.h"
+#include "mixed1664_real2.h"
 
 namespace oct {
 
@@ -16,6 +17,20 @@ hipError_t launch_mixed_one(const FusedArgs& a, hipStream_t stream) {
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
 	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MR_WAVES * 64), MR_LDS_BYTES, stream, a);
+	return hipGetLastError();
+}
+template <int RS, int MODE>
+hipError_t launch_mixed_real2_one(const FusedArgs& a, hipStream_t stream) {
+	auto kernel = oct_mixed1664_real2_kernel<RS, MODE>;
+	KernelLaunchInfo info;
+	hipError_t e = kernel_launch_info(kernel, MR_WAVES * 64, MR2_LDS_BYTES, &info);
+	if (e != hipSuccess) return e;
+	const unsigned pairs = (a.numLines + 1u) / 2u;
+	const unsigned need = (pairs + MR_WAVES - 1) / MR_WAVES;
+	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);
+	if (blocks > need) blocks = need;
+	if (blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MR_WAVES * 64), MR2_LDS_BYTES, stream, a);
 	return hipGetLastError();
 }
 template <int INTYPE, int RS>
@@ -40,6 +55,16 @@ hipError_t launch_mixed1664(int intype, int rs, bool spectrum, bool logScale, co
 	if (intype == IN_U16) return launch_mixed_rs<IN_U16>(rs, spectrum, logScale, a, stream);
 	if (intype == IN_F32) return launch_mixed_rs<IN_F32>(rs, spectrum, logScale, a, stream);
 	return hipErrorInvalidValue;
+}
+
+// real transform input (no dispersion compensation): uint16 samples, no / linear / cubic resampling, image output
+hipError_t launch_mixed1664_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	switch (rs) {
+	case RS_NONE: return logScale ? launch_mixed_real2_one<RS_NONE, MODE_LOG>(a, stream) : launch_mixed_real2_one<RS_NONE, 0>(a, stream);
+	case RS_LINEAR: return logScale ? launch_mixed_real2_one<RS_LINEAR, MODE_LOG>(a, stream) : launch_mixed_real2_one<RS_LINEAR, 0>(a, stream);
+	case RS_CUBIC: return logScale ? launch_mixed_real2_one<RS_CUBIC, MODE_LOG>(a, stream) : launch_mixed_real2_one<RS_CUBIC, 0>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 }  // namespace oct

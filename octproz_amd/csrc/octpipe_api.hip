@@ -429,7 +429,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	} else if (useMixed) {
 		a.lut = h->d_lutPlain;
 		a.twiddle = h->d_twMixed;
-		HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
+		if (intype == oct::IN_U16 && !spectrum && !p.dispersionCompensation && !h->noReal2)  // real FFT input: two A-scans per transform
+			HIP_TRY(oct::launch_mixed1664_real2(rs, p.signalLogScaling != 0, a, h->stream));
+		else
+			HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->bluestein) {
 		oct::BluesteinArgs b{};
 		b.samples = h->d_prepared;

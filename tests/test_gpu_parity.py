@@ -229,13 +229,15 @@ def test_real_input_kernel_matches_oracle(case, A, B):
     pipe.close(); o.close()
 
 
-@pytest.mark.parametrize("N", [256, 512, 2048])
+@pytest.mark.parametrize("N", [256, 512, 2048, 1664])
 @pytest.mark.parametrize("case", list(REAL_INPUT_CASES))
 @pytest.mark.parametrize("A,B", [(24, 3), (7, 3), (1, 1)])
 def test_real_input_kernel_on_the_other_lengths(N, case, A, B):
-    """real2n_kernel.h: the same two-A-scans-per-transform scheme on the 4.4.4.4, 8.8.8 and (planar) 16.16.8 plans; and it
-    must agree with the general kernel of that length (OCTPIPE_NO_REAL2 route is covered by the chain tests) within tolerance"""
+    """real2n_kernel.h: the same two-A-scans-per-transform scheme on the 4.4.4.4, 8.8.8 and (planar) 16.16.8 plans, and
+    mixed1664_real2.h on the 32 x 4 x 13 plan of the reference recording's length"""
     p = v180_benchmark_params(N, A, B)
+    if N == 1664:
+        p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
     REAL_INPUT_CASES[case](p)
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=N + A * 10 + B)
@@ -393,6 +395,30 @@ def test_mixed_radix_1664_agrees_with_the_bluestein_route(monkeypatch):
     pipe.process_device(d.data_ptr()); pipe.synchronize()
     assert np.array_equal(pipe.processed_host().view(np.uint32), got.view(np.uint32))  # prepared float32 route == uint16 route
     pipe.close(); blue.close(); o.close()
+
+
+@pytest.mark.parametrize("N", [512, 1024, 2048, 1664])
+def test_real_input_route_agrees_with_the_complex_route(N, monkeypatch):
+    """dispersion compensation off: the two-A-scans-per-transform kernels and the general kernel of the length
+    (OCTPIPE_NO_REAL2=1) give the same image within the float tolerance, from really different code, and both hold the oracle"""
+    A, B = 25, 3  # odd line count: the last pair is half empty
+    p = v180_benchmark_params(N, A, B)
+    p.dispersionCompensation = 0
+    p.bscanFlip = 0
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + 3)
+    o, pipe, d, want, got = run_both(p, raw)
+    monkeypatch.setenv("OCTPIPE_NO_REAL2", "1")
+    general = Pipeline(p, device=0)
+    monkeypatch.delenv("OCTPIPE_NO_REAL2")
+    general.set_mean_line(o.mean_line(), pin=True)
+    general.process_device(d.data_ptr()); general.synchronize()
+    ref = general.processed_host()
+    common.compare_images(ref, want, p, "general kernel N=%d" % N)
+    common.compare_images(got, want, p, "real-input kernel N=%d" % N)
+    common.compare_images(got, ref, p, "real-input vs general N=%d" % N)
+    assert not np.array_equal(got, ref)
+    pipe.close(); general.close(); o.close()
 
 
 @pytest.mark.parametrize("N", [1664, 1000])
@@ -780,6 +806,11 @@ def test_full_size_n1664_mixed_radix_512x128():
     """the reference recording's A-scan length at a production-sized buffer: every A-scan against the float64 model,
     sharded == unsharded, idempotent, oracle samples"""
     _full_size(1664, 512, 128, sample_lines=64)
+
+
+def test_full_size_n1664_real_input_512x128():
+    """the recording's length on its default-style settings (no dispersion compensation): mixed-radix real-input kernel"""
+    _full_size(1664, 512, 128, sample_lines=64, dispersionCompensation=0)
 
 
 def test_full_size_config3_2048x1024x512():
