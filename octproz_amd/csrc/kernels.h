@@ -82,21 +82,29 @@ struct FusedArgs {
 #ifndef OCT_REGTW3
 #define OCT_REGTW3 1
 #endif
+#ifndef OCT_MEANREG11
+#define OCT_MEANREG11 1
+#endif
+#ifndef OCT_CW11
+#define OCT_CW11 8
+#endif
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<10> { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 12; static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = OCT_REGTAB ? 8 : 15; };
-template <> struct Cfg<11> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 6; static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
+template <> struct Cfg<11> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = OCT_CW11 ? 5 : 6; static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = OCT_CW11; };
 template <> struct Cfg<12> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 3; static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
 // per kernel variant: the cubic gather with precomputed weights trades waves for a larger table
 template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr bool CW = RS == RS_CUBIC && Cfg<LOG2N>::LDS_LUT && Cfg<LOG2N>::WAVES_CW > 0;
+	// N = 2048 with the weights table runs 8 waves of up to 256 VGPRs: room for the lane's 16 mean-line bins (OCT_MEANREG11)
+	static constexpr bool MEAN_REGS = Cfg<LOG2N>::MEAN_REGS || (CW && LOG2N == 11 && OCT_MEANREG11 != 0);
 	static constexpr bool REGTAB = CW && LOG2N == 10 && OCT_REGTAB != 0;
 	static constexpr bool REGLIN = !CW && LOG2N == 10 && OCT_REGLIN != 0 && (RS == RS_LINEAR || RS == RS_NONE) && !ROLL;
 	static constexpr int WAVES_PLAIN = REGLIN ? (RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
 	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
 	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0 && Cfg<LOG2N>::WAVES_ROLL < WAVES_PLAIN) ? Cfg<LOG2N>::WAVES_ROLL : WAVES_PLAIN;
-	static constexpr int MINW = (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
+	static constexpr int MINW = (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
@@ -467,10 +475,10 @@ OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
 		for (int i = tid; i < twiddle_count<LOG2N>(); i += threads) tw[i] = g[i];
 	}
 }
-template <int LOG2N> constexpr int mean_lds_bytes() { return Cfg<LOG2N>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
+template <int LOG2N, int RS> constexpr int mean_lds_bytes() { return KCfg<LOG2N, RS>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
 template <int LOG2N, int RS, bool ROLL = false> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB || KCfg<LOG2N, RS, ROLL>::REGLIN) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
 template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
-	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
+	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
 }
 
 // MODE bits of the kernel template
@@ -485,7 +493,7 @@ template <int LOG2N, int INTYPE, int RS, int MODE>
 __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KCfg<LOG2N, RS, (MODE & 1) != 0>::MINW)) void oct_fused_kernel(const FusedArgs a) {
 	constexpr int N = 1 << LOG2N, P = N / 64;
 	constexpr int WAVES = KCfg<LOG2N, RS, (MODE & MODE_ROLL) != 0>::WAVES, THREADS = WAVES * 64;
-	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = Cfg<LOG2N>::MEAN_REGS, REGTAB = KCfg<LOG2N, RS>::REGTAB;
+	constexpr bool LDS_LUT = Cfg<LOG2N>::LDS_LUT, CW = KCfg<LOG2N, RS>::CW, MEAN_REGS = KCfg<LOG2N, RS>::MEAN_REGS, REGTAB = KCfg<LOG2N, RS>::REGTAB;
 	constexpr bool REGLIN = KCfg<LOG2N, RS, (MODE & 1) != 0>::REGLIN && RS != RS_LANCZOS;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
@@ -497,12 +505,12 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* tw = reinterpret_cast<f2*>(smem);
 	f2* meanL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>());
-	float* rhoL = reinterpret_cast<float*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>());
+	float* rhoL = reinterpret_cast<float*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>());
 	f32x4* cwL = reinterpret_cast<f32x4*>(rhoL);  // CW
-	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + N * (CW ? 16 : 4));
+	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + N * (CW ? 16 : 4));
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
-	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * wave_lds_bytes<N, ROLL>();
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * wave_lds_bytes<N, ROLL>();
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
