@@ -146,4 +146,36 @@ struct Dft<16, ST, PRUNE> {
 	}
 };
 
+// R = 2 * 16: even / odd samples by the radix-16 kernel (stride 2 ST), then X[k] = E[k] + w^k O[k], X[k + 16] = E[k] - w^k O[k],
+// w = exp(+2 pi i / 32).  Unpruned only (a first or middle pass).
+template <int ST>
+struct Dft<32, ST, false> {
+	static OCT_DEV void run(f2* v) {
+		// cos / sin (2 pi k / 32), k = 0..15
+		constexpr float c[16] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+		                         0.55557023301960222f, 0.38268343236508977f, 0.19509032201612827f, 0.0f, -0.19509032201612827f,
+		                         -0.38268343236508977f, -0.55557023301960222f, -0.70710678118654752f, -0.83146961230254524f,
+		                         -0.92387953251128674f, -0.98078528040323044f};
+		constexpr float s[16] = {0.0f, 0.19509032201612827f, 0.38268343236508977f, 0.55557023301960222f, 0.70710678118654752f,
+		                         0.83146961230254524f, 0.92387953251128674f, 0.98078528040323044f, 1.0f, 0.98078528040323044f,
+		                         0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960222f,
+		                         0.38268343236508977f, 0.19509032201612827f};
+		Dft<16, 2 * ST, false>::run(v);
+		Dft<16, 2 * ST, false>::run(v + ST);
+		f2 o[32];
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const f2 e = v[2 * k * ST], d = v[(2 * k + 1) * ST];
+			f2 t;
+			if (k == 0) t = d;
+			else if (k == 8) t = f2{-d.y, d.x};
+			else t = f2{d.x * c[k] - d.y * s[k], d.x * s[k] + d.y * c[k]};
+			o[k] = e + t;
+			o[k + 16] = e - t;
+		}
+#pragma unroll
+		for (int k = 0; k < 32; k++) v[k * ST] = o[k];
+	}
+};
+
 }  // namespace octfft

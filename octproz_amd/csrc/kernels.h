@@ -326,7 +326,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 template <int N, int R, int NS>
 OCT_DEV void exchange_planar(f2 (&v)[N / 64], float* plane, int lane) {
 	constexpr int P = N / 64, NB = P / R, K = NS == 1 ? 1 : 2;
-	static_assert(R == 16 && (NS == 1 || NS == 16), "pads derived for the radix-16 passes with NS = 1, 16");
+	static_assert((R == 16 && (NS == 1 || NS == 16)) || (R == 32 && NS == 1), "pads derived for the radix-16 passes with NS = 1, 16 and the radix-32 pass with NS = 1");
 	const float* rb = plane + lane + K * (lane >> 5);
 	float nx[P], ny[P];
 #pragma unroll
@@ -354,7 +354,16 @@ template <int LOG2N> struct Plan;
 template <> struct Plan<8>  { static constexpr int R0 = 4,  R1 = 4,  R2 = 4,  R3 = 4; static constexpr bool PERM = false; };
 template <> struct Plan<9>  { static constexpr int R0 = 8,  R1 = 8,  R2 = 8,  R3 = 1; static constexpr bool PERM = false; };
 template <> struct Plan<10> { static constexpr int R0 = 16, R1 = 16, R2 = 4,  R3 = 1; static constexpr bool PERM = true; };
+#ifndef OCT_PLAN11_PERM
+#define OCT_PLAN11_PERM 1
+#endif
+#if OCT_PLAN11_PERM
+// 32 x 16 x 4: one planar exchange through LDS; the exchange in front of the radix-4 pass is ONE v_permlane32_swap per register
+// pair (perm_exchange32x2: lane bit 5 <-> lowest bit of the radix-16 output index)
+template <> struct Plan<11> { static constexpr int R0 = 32, R1 = 16, R2 = 4,  R3 = 1; static constexpr bool PERM = false; };
+#else
 template <> struct Plan<11> { static constexpr int R0 = 16, R1 = 16, R2 = 8,  R3 = 1; static constexpr bool PERM = false; };
+#endif
 template <> struct Plan<12> { static constexpr int R0 = 16, R1 = 16, R2 = 16, R3 = 1; static constexpr bool PERM = false; };
 
 // entries of the per-pass twiddle tables: sum over passes with NS > 1 of (R-1)*NS
@@ -406,6 +415,26 @@ OCT_DEV void perm_exchange16x4(f2 (&v)[16]) {
 template <int P> OCT_DEV void perm_exchange(f2 (&v)[P]) {
 	if constexpr (P == 16) perm_exchange16x4(v);
 }
+// N = 2048, plan 32 x 16 x 4.  After the radix-16 pass (NS = 32, two butterflies b = lane + 64 m per lane) lane l holds element
+// 512 t' + (l & 31) + 32 u in v[m + 2 u], t' = (l >> 5) + 2 m.  The radix-4 pass wants element L + 64 m' + 512 t in v[m' + 8 t]:
+// (L & 31) = (l & 31), u = (L >> 5) + 2 m'.  So lane bit 5 trades places with bit 0 of u: for every (m, m') the registers
+// A = v[m + 4 m'] (u even) and B = v[m + 4 m' + 2] (u odd) swap A's upper half-wave with B's lower one; afterwards A is t = 2 m
+// and B is t = 2 m + 1 in every lane.
+OCT_DEV void perm_exchange32x2(f2 (&v)[32]) {
+	f2 w[32];
+#pragma unroll
+	for (int m = 0; m < 2; m++)
+#pragma unroll
+		for (int mp = 0; mp < 8; mp++) {
+			float ax = v[m + 4 * mp].x, ay = v[m + 4 * mp].y, bx = v[m + 4 * mp + 2].x, by = v[m + 4 * mp + 2].y;
+			perm_swap32(ax, bx);
+			perm_swap32(ay, by);
+			w[mp + 8 * (2 * m)] = f2{ax, ay};
+			w[mp + 8 * (2 * m + 1)] = f2{bx, by};
+		}
+#pragma unroll
+	for (int i = 0; i < 32; i++) v[i] = w[i];
+}
 
 // natural-order inverse FFT of v (element lane+64q).  With RL = radix of the last pass and NB = P/RL
 // the result bin lane + 64*m + u*N/RL is held in v[m + u*NB] (fft_bin).  PRUNE: only u < RL/2 valid.
@@ -421,13 +450,24 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	static_assert(R0 * R1 * R2 * R3 == N, "plan");
 	constexpr int T1 = 0, T2 = T1 + (R1 - 1) * R0, T3 = T2 + (R2 - 1) * R0 * R1;
 	constexpr int P = N / 64;
-	if constexpr (Cfg<LOG2N>::PLANAR) {
-		static_assert(!Cfg<LOG2N>::PLANAR || (R3 == 1 && R0 == 16 && R1 == 16), "planar exchange: radix 16, 16, R2");
+	if constexpr (Cfg<LOG2N>::PLANAR && R0 == 32) {
+		static_assert(R0 != 32 || (R1 == 16 && R2 == 4 && R3 == 1 && P == 32), "32 x 16 x 4");
 		float* plane = reinterpret_cast<float*>(xbuf);
 		fft_pass<N, R0, 1, false, false, false>(v, xbuf, tw, lane);
 		exchange_planar<N, R0, 1>(v, plane, lane);
 		fft_pass<N, R1, R0, false, false, false>(v, xbuf, tw + T1, lane);
+		if constexpr (P == 32) perm_exchange32x2(v);
+		fft_pass<N, R2, R0 * R1, false, false, PRUNE>(v, xbuf, tw + T2, lane);
+		return;
+	} else if constexpr (Cfg<LOG2N>::PLANAR) {
+		static_assert(!Cfg<LOG2N>::PLANAR || R0 == 32 || (R3 == 1 && R0 == 16 && R1 == 16), "planar exchange: radix 16, 16, R2");
+		float* plane = reinterpret_cast<float*>(xbuf);
+		fft_pass<N, R0, 1, false, false, false>(v, xbuf, tw, lane);
+		exchange_planar<N, R0, 1>(v, plane, lane);
+		fft_pass<N, R1, R0, false, false, false>(v, xbuf, tw + T1, lane);
+#ifndef OCT_SKEL_SKIP_X2
 		exchange_planar<N, R1, R0>(v, plane, lane);
+#endif
 		fft_pass<N, R2, R0 * R1, false, false, PRUNE>(v, xbuf, tw + T2, lane);
 		return;
 	}
