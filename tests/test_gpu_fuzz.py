@@ -1,0 +1,93 @@
+"""Randomised setting combinations against the CPU oracle (needs an MI355X:  python -m pytest tests -m gpu).
+
+The pipeline chooses between many kernels from the settings (general / register-table / real-input / mixed-radix / Bluestein /
+library route; fused or prepared unpack; prefix-sum or ordered rolling average; post pass or not).  The cases of
+test_gpu_parity.py walk these routes one setting at a time; here seeded random draws combine them, so that an interaction
+between two switches (say rolling average + linear resampling + flip on the real-input route of N = 2048) cannot hide behind
+the per-feature cases.  Seeds are fixed: a failure names its draw and reproduces."""
+import copy
+
+import numpy as np
+import pytest
+
+import common
+from octproz_amd import INTERPOLATION, Pipeline, WindowType, synthetic_raw, v180_benchmark_params
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS = [256, 512, 1024, 1024, 2048, 2048, 1664, 1664, 1000, 4096]  # the benchmark lengths drawn more often
+
+
+def draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice(LENGTHS))
+    A = int(rng.integers(3, 41))
+    B = int(rng.integers(1, 5))
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, float(rng.uniform(0.7, 0.95)) * N, float(rng.uniform(-0.2, 0.0)) * N, float(rng.uniform(0.0, 0.1)) * N
+    p.resampling = int(rng.random() < 0.8)
+    p.resamplingInterpolation = [INTERPOLATION.LINEAR, INTERPOLATION.CUBIC, INTERPOLATION.CUBIC, INTERPOLATION.LANCZOS][int(rng.integers(0, 4))]
+    p.windowing = int(rng.random() < 0.8)
+    p.window = [WindowType.Hanning, WindowType.Gauss, WindowType.Sine, WindowType.FlatTop, WindowType.Rectangular][int(rng.integers(0, 5))]
+    p.windowFillFactor = float(rng.uniform(0.5, 1.0))
+    p.windowCenter = float(rng.uniform(0.4, 0.6))
+    p.dispersionCompensation = int(rng.random() < 0.5)
+    p.d2, p.d3 = float(rng.uniform(-30, 30)), float(rng.uniform(-10, 10))
+    p.backgroundRemoval = int(rng.random() < 0.3)
+    p.rollingAverageWindowSize = int(rng.choice([1, 3, 8, 64, 100, 300]))
+    # The mean line comes from floor(H / 9) lines per segment, H = bscansForNoiseDetermination x A.  With fewer than 18 lines a
+    # segment is ONE line and the subtraction cancels it exactly (-inf after the logarithm, and rounding residues next to it
+    # that no tolerance can hold: DESIGN.md section 4); the draw keeps H >= 27 or switches the removal off.
+    p.bscansForNoiseDetermination = int(rng.integers(1, B + 1))
+    p.fixedPatternNoiseRemoval = int(rng.random() < 0.7 and p.bscansForNoiseDetermination * A >= 27)
+    p.signalLogScaling = int(rng.random() < 0.7)
+    if not p.signalLogScaling:
+        p.signalGrayscaleMax, p.signalGrayscaleMin = 900.0, 0.0
+    p.signalMultiplicator = float(rng.choice([1.0, 2.5]))
+    p.signalAddend = float(rng.choice([0.0, -0.25]))
+    p.bscanFlip = int(rng.random() < 0.3)
+    # (the sinusoidal scan correction blends two A-scans in the image domain, where the power-domain tolerance of compare_images
+    # has no meaning; it is checked bit for bit on identical input in test_gpu_side_kernels.py and end to end in "flip_sinus")
+    p.sinusoidalScanCorrection = 0
+    container = ["u16", "u16", "u16", "u16", "u16shift", "u8", "u32"][int(rng.integers(0, 7))]
+    shift = container == "u16shift"
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=seed)  # 12-bit values in uint16
+    if shift:  # 16-bit container, samples in the upper 12 bits (cu:129-147)
+        p.bitshift, p.bitDepth = 1, 16
+        raw = (raw.astype(np.uint32) * 16).astype(np.uint16)
+    elif container == "u8":  # bitDepth <= 8: one byte per sample (cu:109-118)
+        p.bitDepth = 8
+        raw = (raw >> 4).astype(np.uint8)
+    elif container == "u32":  # bitDepth > 16: four bytes per sample
+        p.bitDepth = 24
+        raw = raw.astype(np.uint32) * 256
+    what = "seed %d: N=%d %dx%d rs=%d/%d win=%d/%d disp=%d roll=%d/%d fpn=%d log=%d flip=%d sinus=%d shift=%d" % (
+        seed, N, A, B, p.resampling, int(p.resamplingInterpolation), p.windowing, int(p.window), p.dispersionCompensation, p.backgroundRemoval,
+        p.rollingAverageWindowSize, p.fixedPatternNoiseRemoval, p.signalLogScaling, p.bscanFlip, p.sinusoidalScanCorrection, int(shift)) + " " + container
+    return p, raw, what
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_setting_combination_matches_oracle(seed):
+    import torch
+    p, raw, what = draw(seed)
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    pipe = Pipeline(p, device=0)
+    if p.fixedPatternNoiseRemoval:
+        pipe.set_mean_line(o.mean_line(), pin=True)
+    d = torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).to("cuda:0")
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    got = pipe.processed_host()
+    # the tolerances of compare_images are stated for a unit multiplicator: take multiplicator and addend out on both sides
+    q = copy.copy(p)
+    q.signalMultiplicator, q.signalAddend = 1.0, 0.0
+    unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
+    common.compare_images(unscale(got), unscale(want), q, what)
+    # the second buffer through the same handle (tables resident, slot logic) gives the same image
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    assert np.array_equal(pipe.processed_host().view(np.uint32), got.view(np.uint32)), what + ": second pass differs"
+    pipe.close(); o.close()
