@@ -91,3 +91,62 @@ def test_random_setting_combination_matches_oracle(seed):
     pipe.synchronize()
     assert np.array_equal(pipe.processed_host().view(np.uint32), got.view(np.uint32)), what + ": second pass differs"
     pipe.close(); o.close()
+
+
+# ------------------------------------------------------------------ settings changed between buffers of one handle
+def _mutations(rng, N):
+    """a few setting changes as the GUI would make them between two buffers (octalgorithmparameters.cpp setters + *Updated flags)"""
+    muts = [
+        lambda p: setattr(p, "resamplingInterpolation", [INTERPOLATION.LINEAR, INTERPOLATION.CUBIC, INTERPOLATION.LANCZOS][int(rng.integers(0, 3))]),
+        lambda p: setattr(p, "resampling", 1 - p.resampling),
+        lambda p: setattr(p, "dispersionCompensation", 1 - p.dispersionCompensation),
+        lambda p: setattr(p, "windowing", 1 - p.windowing),
+        lambda p: setattr(p, "window", [WindowType.Hanning, WindowType.Gauss, WindowType.Sine, WindowType.FlatTop][int(rng.integers(0, 4))]),
+        lambda p: setattr(p, "c1", float(rng.uniform(0.7, 0.95)) * N),
+        lambda p: setattr(p, "d2", float(rng.uniform(-30, 30))),
+        lambda p: setattr(p, "backgroundRemoval", 1 - p.backgroundRemoval),
+        lambda p: setattr(p, "rollingAverageWindowSize", int(rng.choice([2, 16, 64, 300]))),
+        lambda p: setattr(p, "signalLogScaling", 1 - p.signalLogScaling),
+        lambda p: setattr(p, "bscanFlip", 1 - p.bscanFlip),
+        lambda p: setattr(p, "fixedPatternNoiseRemoval", 1 - p.fixedPatternNoiseRemoval),
+    ]
+    k = int(rng.integers(1, 4))
+    return [muts[i] for i in rng.choice(len(muts), size=k, replace=False)]
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_settings_changed_between_buffers(seed):
+    """One handle, six buffers, one to three settings changed before each: the kernel route, the tables in LDS / registers and
+    the curve uploads have to follow (dirty flags of cu:1395-1412).  Every buffer is checked against a fresh oracle."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    N = int(rng.choice([512, 1024, 1024, 2048, 1664, 1000]))
+    A, B = int(rng.integers(27, 40)), int(rng.integers(1, 3))
+    p = v180_benchmark_params(N, A, B)
+    p.buffersPerVolume = int(rng.integers(1, 4))
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    p.update_all_curves()
+    pipe = Pipeline(p, device=0)
+    for step in range(6):
+        if step:
+            for mut in _mutations(rng, N):
+                mut(p)
+            if not p.signalLogScaling:
+                p.signalGrayscaleMax, p.signalGrayscaleMin = 900.0, 0.0
+            else:
+                p.signalGrayscaleMax, p.signalGrayscaleMin = v180_benchmark_params(N, A, B).signalGrayscaleMax, v180_benchmark_params(N, A, B).signalGrayscaleMin
+            p.update_all_curves()
+        raw = synthetic_raw(N, A, B, seed=100 * seed + step)
+        o = common.make_oracle(p)
+        want = o.process(raw)
+        if p.fixedPatternNoiseRemoval:
+            pipe.set_mean_line(o.mean_line(), pin=True)
+        d = torch.from_numpy(np.ascontiguousarray(raw).view(np.int16)).to("cuda:0")
+        pipe.process_device(d.data_ptr())
+        pipe.synchronize()
+        what = "seed %d step %d: N=%d rs=%d/%d win=%d/%d disp=%d roll=%d/%d fpn=%d log=%d flip=%d bpv=%d" % (
+            seed, step, N, p.resampling, int(p.resamplingInterpolation), p.windowing, int(p.window), p.dispersionCompensation, p.backgroundRemoval,
+            p.rollingAverageWindowSize, p.fixedPatternNoiseRemoval, p.signalLogScaling, p.bscanFlip, p.buffersPerVolume)
+        common.compare_images(pipe.processed_host(), want, p, what)
+        o.close()
+    pipe.close()
