@@ -85,6 +85,9 @@ struct FusedArgs {
 #ifndef OCT_MEANREG11
 #define OCT_MEANREG11 1
 #endif
+#ifndef OCT_LANCZOS_LDS
+#define OCT_LANCZOS_LDS 1
+#endif
 #ifndef OCT_CW11
 #define OCT_CW11 8
 #endif
@@ -101,10 +104,12 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr bool MEAN_REGS = Cfg<LOG2N>::MEAN_REGS || (CW && LOG2N == 11 && OCT_MEANREG11 != 0);
 	static constexpr bool REGTAB = CW && LOG2N == 10 && OCT_REGTAB != 0;
 	static constexpr bool REGLIN = !CW && LOG2N == 10 && OCT_REGLIN != 0 && (RS == RS_LINEAR || RS == RS_NONE) && !ROLL;
-	static constexpr int WAVES_PLAIN = REGLIN ? (RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : Cfg<LOG2N>::WAVES;
+	// Lanczos: the [N][16] tap-weight table (64 B per sample) in LDS where it fits (N <= 1024; at N = 1024 with 8 waves)
+	static constexpr bool LZ_LDS = RS == RS_LANCZOS && LOG2N <= 10 && Cfg<LOG2N>::LDS_LUT && OCT_LANCZOS_LDS != 0;
+	static constexpr int WAVES_PLAIN = REGLIN ? (RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : (LZ_LDS && LOG2N == 10) ? 8 : Cfg<LOG2N>::WAVES;
 	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
 	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0 && Cfg<LOG2N>::WAVES_ROLL < WAVES_PLAIN) ? Cfg<LOG2N>::WAVES_ROLL : WAVES_PLAIN;
-	static constexpr int MINW = (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
+	static constexpr int MINW = (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN || (LZ_LDS && LOG2N == 10)) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
@@ -516,7 +521,7 @@ OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
 	}
 }
 template <int LOG2N, int RS> constexpr int mean_lds_bytes() { return KCfg<LOG2N, RS>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
-template <int LOG2N, int RS, bool ROLL = false> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB || KCfg<LOG2N, RS, ROLL>::REGLIN) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12); }
+template <int LOG2N, int RS, bool ROLL = false> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB || KCfg<LOG2N, RS, ROLL>::REGLIN) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12) + (KCfg<LOG2N, RS>::LZ_LDS ? (1 << LOG2N) * 64 : 0); }
 template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
 	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
 }
@@ -548,6 +553,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	float* rhoL = reinterpret_cast<float*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>());
 	f32x4* cwL = reinterpret_cast<f32x4*>(rhoL);  // CW
 	f2* wphL = reinterpret_cast<f2*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + N * (CW ? 16 : 4));
+	constexpr bool LZ_LDS = KCfg<LOG2N, RS>::LZ_LDS;
+	// Lanczos tap weights, unit [q][c][lane] = weights 4c .. 4c+3 of sample lane + 64 q (consecutive lanes, consecutive 16-byte units)
+	f32x4* lzL = reinterpret_cast<f32x4*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + N * 12);
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
 	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * wave_lds_bytes<N, ROLL>();
@@ -556,6 +564,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 
 	// tables -> LDS, once per (persistent) workgroup
 	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
+	if constexpr (LZ_LDS) {
+		const f32x4* g = reinterpret_cast<const f32x4*>(a.lanczosW);
+		for (int u = tid; u < N * 4; u += THREADS) lzL[u] = g[((u & 63) + 64 * (u >> 8)) * 4 + ((u >> 6) & 3)];
+	}
 	if constexpr (!MEAN_REGS)
 		for (int i = tid; i < N / 2; i += THREADS) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
 	if constexpr (LDS_LUT && !REGTAB && !REGLIN) {
@@ -831,7 +843,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				const float* t = &row[ROW_OFF + n0];
 				f32x4 w[4];
 #pragma unroll
-				for (int c = 0; c < 4; c++) w[c] = buf_load128(lanczosR, lane * 64, q * 4096 + c * 16);
+				for (int c = 0; c < 4; c++) {
+					if constexpr (LZ_LDS) w[c] = lzL[(q * 4 + c) * 64 + lane];
+					else w[c] = buf_load128(lanczosR, lane * 64, q * 4096 + c * 16);
+				}
 				float sum = 0.0f;
 #pragma unroll
 				for (int i = -7; i <= 8; i++) sum += t[i] * w[(i + 7) >> 2][(i + 7) & 3];
