@@ -56,7 +56,10 @@ hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, 
 hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,
                                              int requestedBlocks, hipStream_t stream, int* blocksUsed) {
 	if (intype == IN_U16) {
-		if (rs == RS_LANCZOS) return hipErrorInvalidValue;
+		if (rs == RS_LANCZOS) {  // raw rows + 8 samples of the neighbour rows on both sides; not with the in-kernel rolling average
+			if (roll) return hipErrorInvalidValue;
+			return launch_out<IN_U16, RS_LANCZOS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		}
 		if (roll) {
 			switch (rs) {
 			case RS_NONE: return launch_out<IN_U16, RS_NONE, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);

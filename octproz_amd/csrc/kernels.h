@@ -544,7 +544,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (64 * SPL);
-	static_assert(!(RS == RS_LANCZOS && INTYPE != IN_F32), "Lanczos needs the prepared float buffer");
+	static_assert(!(RS == RS_LANCZOS && INTYPE != IN_F32 && INTYPE != IN_U16), "Lanczos: prepared float buffer or raw uint16 rows");
+	static_assert(!(RS == RS_LANCZOS && (MODE & MODE_ROLL) != 0), "Lanczos taps cross line borders: the rolling average of the neighbour rows comes prepared");
 	static_assert(!(ROLL && INTYPE != IN_U16), "in-kernel rolling average: uint16 rows only (everything else comes prepared)");
 	static_assert(N / (64 * SPL) >= 1, "a row holds at least one chunk per lane");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -743,12 +744,29 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
 			}
 		} else {
-			// Lanczos taps cross line borders (cu:313-321): stage [off-8, off+N+8) of the prepared
-			// float buffer, off = clamp(line*N, 8, S-9) (the reference's first-line quirk), 0 outside.
+			// Lanczos taps cross line borders (cu:313-321): stage [off-8, off+N+8) of the buffer (prepared float32, or raw uint16
+			// converted here), off = clamp(line*N, 8, S-9) (the reference's first-line quirk), 0 outside.
 			const long long S = (long long)a.linesInBuffer * N;
 			long long off = (long long)line * N;
 			if (off < 8) off = 8;
 			if (off > S - 9) off = S - 9;
+			if constexpr (INTYPE == IN_U16) {
+				// 16-byte loads (8 samples) through a descriptor that ends with the buffer: reads past it return 0; the window starts
+				// at sample 0 or at a multiple of N minus 8, i.e. 16-byte aligned
+				const uint16_t* g = reinterpret_cast<const uint16_t*>(a.raw) + (off - 8);
+				const long long left = (S - (off - 8)) * 2;
+				const __amdgpu_buffer_rsrc_t haloR = make_rsrc(g, (uint32_t)(left < (long long)(N + 16) * 2 ? left : (long long)(N + 16) * 2));
+				constexpr int UNITS = (N + 16) / 8;
+#pragma unroll
+				for (int i = 0; i < (UNITS + 63) / 64; i++) {
+					const int u = lane + 64 * i;
+					if (u < UNITS) {
+						const u32x4 c = __builtin_bit_cast(u32x4, buf_load128(haloR, u * 16, 0));
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 8 * u]) = chunk_to_float<IN_U16>(c, 0, shift);
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 8 * u + 4]) = chunk_to_float<IN_U16>(c, 1, shift);
+					}
+				}
+			} else {
 			// 16-byte loads through a descriptor that ends with the buffer: reads past it return 0
 			const float* g = reinterpret_cast<const float*>(a.raw) + (off - 8);
 			const long long left = (S - (off - 8)) * 4;
@@ -761,6 +779,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					const f32x4 f = buf_load128(haloR, u * 16, 0);
 					*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 4 * u]) = float4{f.x, f.y, f.z, f.w};
 				}
+			}
 			}
 		}
 		wave_sync_lds();

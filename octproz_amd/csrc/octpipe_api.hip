@@ -337,8 +337,10 @@ size_t rawBytes(const octpipe* h) {
 	}
 }
 
+// Lanczos taps reach 8 samples into the neighbour rows: with the rolling average on, those have to be the corrected samples
 bool needsPrepared(const octpipe* h) {
-	return h->libfft || h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO || (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS);
+	return h->libfft || h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO ||
+	       (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS && (h->params.backgroundRemoval != 0 || h->mixed));
 }
 
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw

@@ -78,6 +78,30 @@ def test_fused_unpack_equals_standalone_unpack_bitwise():
     pipe.close(); o.close()
 
 
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("A,B,bitshift", [(24, 3, 0), (5, 1, 1), (1, 1, 0)])
+def test_lanczos_on_raw_rows_equals_the_prepared_route_bitwise(N, A, B, bitshift):
+    """Lanczos taps reach 8 samples into the neighbour rows (cu:313-321, with the first-line quirk of cu:309): the fused kernel
+    stages [off - 8, off + N + 8) straight from the uint16 buffer.  Same image, bit for bit, as through the float32 buffer of
+    the prepare kernel, and both hold the oracle; first / last line and a single-line buffer included."""
+    p = v180_benchmark_params(N, A, B)
+    p.resamplingInterpolation = INTERPOLATION.LANCZOS
+    if A * B < 27:
+        p.fixedPatternNoiseRemoval = 0
+    raw = synthetic_raw(N, A, B, seed=N + A)
+    if bitshift:
+        p.bitshift, p.bitDepth = 1, 16
+        raw = (raw.astype(np.uint32) * 16).astype(np.uint16)
+    p.update_all_curves()
+    o, pipe, d, want, got = run_both(p, raw)
+    common.compare_images(got, want, p, "lanczos raw rows N=%d %dx%d" % (N, A, B))
+    pipe.debug_force_prepared(True)
+    pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    assert np.array_equal(pipe.processed_host().view(np.uint32), got.view(np.uint32))
+    pipe.close(); o.close()
+
+
 @pytest.mark.parametrize("N,W,bits", [(1024, 200, 12), (1024, 256, 12), (2048, 250, 12), (512, 255, 10), (1024, 129, 16), (1024, 300, 12), (4096, 256, 12)])
 def test_rolling_average_wide_windows(N, W, bits):
     """W <= 256 takes the prefix-sum route whenever 2 W x (largest sample) < 2^24 (12-bit data: always), the ordered float loop
