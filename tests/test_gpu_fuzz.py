@@ -4,8 +4,14 @@ The pipeline chooses between many kernels from the settings (general / register-
 library route; fused or prepared unpack; prefix-sum or ordered rolling average; post pass or not).  The cases of
 test_gpu_parity.py walk these routes one setting at a time; here seeded random draws combine them, so that an interaction
 between two switches (say rolling average + linear resampling + flip on the real-input route of N = 2048) cannot hide behind
-the per-feature cases.  Seeds are fixed: a failure names its draw and reproduces."""
+the per-feature cases.  Seeds are fixed: a failure names its draw and reproduces.
+
+A longer hunt (OCT_FUZZ_SEEDS=1200 OCT_FUZZ_SEQUENCES=150, 1 350 cases, round 2): no wrong image; three draws (seeds 129, 171,
+901: fixed-pattern-noise removal on, window off or Gaussian, i.e. a large DC term next to bins at 1e-6 of the line maximum)
+passed the 1e-4 linear-power bound and missed the normalised-dB bound of tests/common.py by a factor < 1.5 (5.5e-4 .. 7.2e-4
+against 5e-4): float32 rounding of the transform at the weakest bins the dB check looks at, on every route alike."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -68,7 +74,7 @@ def draw(seed):
     return p, raw, what
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SEEDS", "96"))))  # OCT_FUZZ_SEEDS=1000 for a longer hunt
 def test_random_setting_combination_matches_oracle(seed):
     import torch
     p, raw, what = draw(seed)
@@ -114,7 +120,7 @@ def _mutations(rng, N):
     return [muts[i] for i in rng.choice(len(muts), size=k, replace=False)]
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SEQUENCES", "16"))))
 def test_settings_changed_between_buffers(seed):
     """One handle, six buffers, one to three settings changed before each: the kernel route, the tables in LDS / registers and
     the curve uploads have to follow (dirty flags of cu:1395-1412).  Every buffer is checked against a fresh oracle."""
