@@ -178,4 +178,42 @@ struct Dft<32, ST, false> {
 	}
 };
 
+// R = 4 * 16: t = 4 t1 + t0; the four subsequences t0 by the radix-16 kernel (stride 4 ST, in place: output u1 of subsequence t0
+// lands at index 4 u1 + t0), twiddle w^(t0 u1), w = exp(+2 pi i / 64), then 16 radix-4 butterflies over t0: X[u1 + 16 u0].
+template <int ST>
+struct Dft<64, ST, false> {
+	static OCT_DEV f2 rot(f2 d, int k) {  // d * w^k, k = t0 u1 <= 45 (a constant after unrolling)
+		// cos (2 pi k / 64), k = 0..63;  sin (2 pi k / 64) = cos (2 pi (k - 16) / 64)
+		constexpr float c[64] = {1.0f, 0.99518472667219693f, 0.98078528040323043f, 0.95694033573220882f, 0.92387953251128674f, 0.88192126434835505f,
+		                         0.83146961230254524f, 0.77301045336273699f, 0.70710678118654757f, 0.63439328416364549f, 0.55557023301960229f, 0.47139673682599781f,
+		                         0.38268343236508984f, 0.29028467725446233f, 0.19509032201612833f, 0.09801714032956077f, 0.0f, -0.098017140329560645f,
+		                         -0.19509032201612819f, -0.29028467725446216f, -0.38268343236508973f, -0.4713967368259977f, -0.55557023301960196f, -0.63439328416364538f,
+		                         -0.70710678118654746f, -0.77301045336273699f, -0.83146961230254535f, -0.88192126434835494f, -0.92387953251128674f, -0.95694033573220882f,
+		                         -0.98078528040323043f, -0.99518472667219682f, -1.0f, -0.99518472667219693f, -0.98078528040323043f, -0.95694033573220894f,
+		                         -0.92387953251128685f, -0.88192126434835505f, -0.83146961230254546f, -0.7730104533627371f, -0.70710678118654768f, -0.63439328416364593f,
+		                         -0.55557023301960218f, -0.47139673682599786f, -0.38268343236509034f, -0.29028467725446244f, -0.19509032201612866f, -0.098017140329560451f,
+		                         0.0f, 0.09801714032956009f, 0.1950903220161283f, 0.29028467725446205f, 0.38268343236509f, 0.47139673682599759f,
+		                         0.55557023301960184f, 0.6343932841636456f, 0.70710678118654735f, 0.77301045336273666f, 0.83146961230254524f, 0.88192126434835483f,
+		                         0.92387953251128652f, 0.95694033573220882f, 0.98078528040323032f, 0.99518472667219693f};
+		if (k == 0) return d;
+		if (k == 16) return f2{-d.y, d.x};
+		if (k == 32) return f2{-d.x, -d.y};
+		const float cs = c[k], sn = c[(k + 48) % 64];
+		return f2{d.x * cs - d.y * sn, d.x * sn + d.y * cs};
+	}
+	static OCT_DEV void run(f2* v) {
+#pragma unroll
+		for (int t0 = 0; t0 < 4; t0++) Dft<16, 4 * ST, false>::run(v + t0 * ST);
+		f2 o[64];
+#pragma unroll
+		for (int u1 = 0; u1 < 16; u1++) {
+			f2 a0 = v[(4 * u1 + 0) * ST], a1 = rot(v[(4 * u1 + 1) * ST], u1), a2 = rot(v[(4 * u1 + 2) * ST], 2 * u1), a3 = rot(v[(4 * u1 + 3) * ST], 3 * u1);
+			dft4<false>(a0, a1, a2, a3);
+			o[u1] = a0; o[u1 + 16] = a1; o[u1 + 32] = a2; o[u1 + 48] = a3;
+		}
+#pragma unroll
+		for (int k = 0; k < 64; k++) v[k * ST] = o[k];
+	}
+};
+
 }  // namespace octfft

@@ -331,7 +331,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 template <int N, int R, int NS>
 OCT_DEV void exchange_planar(f2 (&v)[N / 64], float* plane, int lane) {
 	constexpr int P = N / 64, NB = P / R, K = NS == 1 ? 1 : 2;
-	static_assert((R == 16 && (NS == 1 || NS == 16)) || (R == 32 && NS == 1), "pads derived for the radix-16 passes with NS = 1, 16 and the radix-32 pass with NS = 1");
+	static_assert((R == 16 && (NS == 1 || NS == 16)) || ((R == 32 || R == 64) && NS == 1), "pads derived for the radix-16 passes with NS = 1, 16 and the radix-32 / 64 first pass");
 	const float* rb = plane + lane + K * (lane >> 5);
 	float nx[P], ny[P];
 #pragma unroll
@@ -369,7 +369,16 @@ template <> struct Plan<11> { static constexpr int R0 = 32, R1 = 16, R2 = 4,  R3
 #else
 template <> struct Plan<11> { static constexpr int R0 = 16, R1 = 16, R2 = 8,  R3 = 1; static constexpr bool PERM = false; };
 #endif
+#ifndef OCT_PLAN12_NOX
+#define OCT_PLAN12_NOX 1
+#endif
+#if OCT_PLAN12_NOX
+// 64 x 16 x 4: after the radix-16 pass (NS = 64) every input of the radix-4 pass already sits in the lane that needs it --
+// one planar exchange through LDS in the whole transform, the second "exchange" is a renaming of registers
+template <> struct Plan<12> { static constexpr int R0 = 64, R1 = 16, R2 = 4,  R3 = 1; static constexpr bool PERM = false; };
+#else
 template <> struct Plan<12> { static constexpr int R0 = 16, R1 = 16, R2 = 16, R3 = 1; static constexpr bool PERM = false; };
+#endif
 
 // entries of the per-pass twiddle tables: sum over passes with NS > 1 of (R-1)*NS
 template <int LOG2N> constexpr int twiddle_count() {
@@ -455,13 +464,25 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	static_assert(R0 * R1 * R2 * R3 == N, "plan");
 	constexpr int T1 = 0, T2 = T1 + (R1 - 1) * R0, T3 = T2 + (R2 - 1) * R0 * R1;
 	constexpr int P = N / 64;
-	if constexpr (Cfg<LOG2N>::PLANAR && R0 == 32) {
-		static_assert(R0 != 32 || (R1 == 16 && R2 == 4 && R3 == 1 && P == 32), "32 x 16 x 4");
+	if constexpr (Cfg<LOG2N>::PLANAR && (R0 == 32 || R0 == 64)) {
+		static_assert((R0 != 32 && R0 != 64) || (R1 == 16 && R2 == 4 && R3 == 1 && P == R0), "P x 16 x 4 with the whole first pass in the lane");
 		float* plane = reinterpret_cast<float*>(xbuf);
 		fft_pass<N, R0, 1, false, false, false>(v, xbuf, tw, lane);
 		exchange_planar<N, R0, 1>(v, plane, lane);
 		fft_pass<N, R1, R0, false, false, false>(v, xbuf, tw + T1, lane);
-		if constexpr (P == 32) perm_exchange32x2(v);
+		if constexpr (P == 32) {
+			perm_exchange32x2(v);
+		} else if constexpr (P == 64) {
+			// N = 4096: the radix-16 pass (NS = 64, butterflies b = lane + 64 m) leaves element 1024 m + lane + 64 u in v[m + 4 u]; the
+			// radix-4 pass wants element lane + 64 m' + 1024 t in v[m' + 16 t]: t = m, m' = u, same lane
+			f2 w[P];
+#pragma unroll
+			for (int m = 0; m < 4; m++)
+#pragma unroll
+				for (int u = 0; u < 16; u++) w[(u + 16 * m) % P] = v[(m + 4 * u) % P];
+#pragma unroll
+			for (int i = 0; i < P; i++) v[i] = w[i];
+		}
 		fft_pass<N, R2, R0 * R1, false, false, PRUNE>(v, xbuf, tw + T2, lane);
 		return;
 	} else if constexpr (Cfg<LOG2N>::PLANAR) {
