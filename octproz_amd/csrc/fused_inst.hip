@@ -25,7 +25,7 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 	constexpr bool kRoll = (MODE & MODE_ROLL) != 0;
 	constexpr int waves = KCfg<kLog2N, RS, kRoll>::WAVES;
 	constexpr int threads = waves * 64;
-	constexpr size_t lds = block_lds_bytes<kLog2N, RS, kRoll>();
+	constexpr size_t lds = block_lds_bytes<kLog2N, RS, kRoll>() + bg_lds_bytes<MODE, kN>();
 	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
 	KernelLaunchInfo info;
 	hipError_t e = kernel_launch_info(kernel, threads, lds, &info);
@@ -44,6 +44,13 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 template <int INTYPE, int RS, int ROLLBIT>
 hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, hipStream_t st, int* bu) {
 	if (spectrum) return launch_one<INTYPE, RS, ROLLBIT | MODE_SPECTRUM>(a, rb, st, bu);
+	// post-process background removal inside the image store (a.bgTerm set): instantiated for raw uint16 rows without the
+	// in-kernel rolling average; the caller keeps the post pass for everything else
+	if constexpr (INTYPE == IN_U16 && ROLLBIT == 0) {
+		if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, rb, st, bu) : launch_one<INTYPE, RS, MODE_BG>(a, rb, st, bu);
+	} else if (a.bgTerm) {
+		return hipErrorInvalidValue;
+	}
 	if (logScale) return launch_one<INTYPE, RS, ROLLBIT | MODE_LOG>(a, rb, st, bu);
 	return launch_one<INTYPE, RS, ROLLBIT>(a, rb, st, bu);
 }
@@ -132,7 +139,8 @@ template <int RS, int MODE>
 hipError_t launch_real2n_one(const FusedArgs& a, hipStream_t stream) {
 	auto kernel = oct_real2n_kernel<kLog2N, RS, MODE>;
 	constexpr int waves = Real2Cfg<kLog2N>::WAVES;
-	constexpr size_t lds = real2n_lds_bytes<kLog2N>();
+	constexpr size_t lds = real2n_lds_bytes<kLog2N>() + bg_lds_bytes<MODE, kN>();
+	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
 	KernelLaunchInfo info;
 	hipError_t e = kernel_launch_info(kernel, waves * 64, lds, &info);
 	if (e != hipSuccess) return e;
@@ -144,14 +152,19 @@ hipError_t launch_real2n_one(const FusedArgs& a, hipStream_t stream) {
 	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(waves * 64), lds, stream, a);
 	return hipGetLastError();
 }
+template <int RS>
+hipError_t launch_real2n_mode(bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (a.bgTerm) return logScale ? launch_real2n_one<RS, MODE_LOG | MODE_BG>(a, stream) : launch_real2n_one<RS, MODE_BG>(a, stream);
+	return logScale ? launch_real2n_one<RS, MODE_LOG>(a, stream) : launch_real2n_one<RS, 0>(a, stream);
+}
 }  // namespace
 #endif
 hipError_t OCT_CAT(launch_real2n_, OCT_LOG2N)(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
 #if OCT_HAVE_REAL2N
 	switch (rs) {
-	case RS_NONE: return logScale ? launch_real2n_one<RS_NONE, MODE_LOG>(a, stream) : launch_real2n_one<RS_NONE, 0>(a, stream);
-	case RS_LINEAR: return logScale ? launch_real2n_one<RS_LINEAR, MODE_LOG>(a, stream) : launch_real2n_one<RS_LINEAR, 0>(a, stream);
-	case RS_CUBIC: return logScale ? launch_real2n_one<RS_CUBIC, MODE_LOG>(a, stream) : launch_real2n_one<RS_CUBIC, 0>(a, stream);
+	case RS_NONE: return launch_real2n_mode<RS_NONE>(logScale, a, stream);
+	case RS_LINEAR: return launch_real2n_mode<RS_LINEAR>(logScale, a, stream);
+	case RS_CUBIC: return launch_real2n_mode<RS_CUBIC>(logScale, a, stream);
 	default: return hipErrorInvalidValue;
 	}
 #else

@@ -46,6 +46,7 @@ struct FusedArgs {
 	int subtractMean;
 	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
 	const float* lanczosW;   // RS_LANCZOS: [N][16] tap weights L(rho_j - (n0_j + i)), i = -7..8 (cu:297-326), the same for every A-scan
+	const float* bgTerm;     // [N/2] weight * background + offset, or nullptr: post-process background removal inside the image store
 };
 
 // Per-length launch shape.  WAVES = A-scans in flight per workgroup; all waves of a workgroup share
@@ -154,6 +155,25 @@ OCT_DEV u32x2 buf_load64(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 }
 OCT_DEV void buf_store32(float v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, vbase + (c & 4095), c & ~4095, 0);
+}
+// Image store with the post-process background removal folded in (cu:757-767: saturate(v - (weight bg[bin] + offset)), the only
+// clamp of the float path).  Valid whenever no sinusoidal correction sits between the grey-scale mapping and the removal: the
+// B-scan flip only moves whole A-scans.  term[bin] = weight bg[bin] + offset is prepared by oct_bg_term_kernel with the
+// post pass' own rounding; every workgroup keeps a copy in LDS (2 N bytes behind its other tables, bg_lds_bytes) and the store
+// looks it up with its own byte offsets.  (Read from L2 right in front of the stores it cost more than the post pass it
+// replaces: 8 dependent loads per A-scan at two waves per SIMD.)  A template flag (MODE_BG), not a run-time one: a uniform
+// branch in the epilogue cost the kernels without removal 4 %.
+template <int MODE, int N> constexpr int bg_lds_bytes() { return (MODE & 8 /* MODE_BG */) ? N * 2 : 0; }
+OCT_DEV void fill_bg_term(float* termL, const float* g, int n, int tid, int threads) {
+	for (int i = tid; i < n; i += threads) termL[i] = g[i];
+}
+template <bool BG> OCT_DEV void store_image(float v, __amdgpu_buffer_rsrc_t outR, const float* termL, int vbase, int c) {
+	if constexpr (BG) {
+		const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(termL) + vbase + c);
+		v = v - t;
+		v = !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v);
+	}
+	buf_store32(v, outR, vbase, c);
 }
 
 // ------------------------------------------------------------------ raw chunk = SPL consecutive samples per lane
@@ -548,7 +568,7 @@ template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
 }
 
 // MODE bits of the kernel template
-enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4 };
+enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4, MODE_BG = 8 };
 
 // INTYPE: IN_U16 (raw, the hot configuration) or IN_F32 (samples prepared by oct_prepare_kernel:
 // uint8 / uint32 input and everything in front of the Lanczos variant).
@@ -585,6 +605,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
 	// tables -> LDS, once per (persistent) workgroup
+	const float* termL = reinterpret_cast<const float*>(smem + block_lds_bytes<LOG2N, RS, ROLL>());
+	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + block_lds_bytes<LOG2N, RS, ROLL>()), a.bgTerm, N / 2, tid, THREADS);
 	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
 	if constexpr (LZ_LDS) {
 		const f32x4* g = reinterpret_cast<const f32x4*>(a.lanczosW);
@@ -922,6 +944,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
 			}
 			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
+			constexpr bool BG = (MODE & MODE_BG) != 0;
 			const f2* ml = meanL + lane;
 #pragma unroll
 			for (int u = 0; u < RL / 2; u++) {
@@ -936,7 +959,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					o[m] = a.sA * s + a.sB;
 				}
 #pragma unroll
-				for (int m = 0; m < NBL; m++) buf_store32(o[m], outR, lane * 4, (64 * m + u * (N / RL)) * 4);
+				for (int m = 0; m < NBL; m++) store_image<BG>(o[m], outR, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
 			}
 		}
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(0);

@@ -158,6 +158,8 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 		wphL[i] = f2{t.y * t.z, t.y * t.w};  // window folded into the phasor
 	}
 	for (int i = tid; i < N1 * N2; i += THREADS) twB[i] = a.twiddle[i];  // [k1][n2]
+	const float* termL = reinterpret_cast<const float*>(smem + MR_LDS_BYTES);
+	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + MR_LDS_BYTES), a.bgTerm, N / 2, tid, THREADS);
 	__syncthreads();
 
 	const int n2 = lane < N2 ? lane : N2 - 1;  // lanes 52..63 duplicate lane 51 (same values to the same addresses)
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 		}
 		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
 		const __amdgpu_buffer_rsrc_t specR = make_rsrc(a.spectrum + (size_t)line * N, N * 8u);
+		constexpr bool BG = (MODE & MODE_BG) != 0;
 		if constexpr (SPECTRUM) {
 			// lane 0: X[c=0] = s0 + s1, X[c=1] = d0 + i d1;   lane 1: -X[c=2] = s1 - s0, -X[c=3] = i d1 - d0
 #pragma unroll
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 				const f2 z = G - meanR[d];
 				const float p = z.x * z.x + z.y * z.y;
 				const float f = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
-				buf_store32(a.sA * f + a.sB, outR, mr::lane1_larger(d) ? offA : offB, 128 * mr::k2_kept_min(d));
+				store_image<BG>(a.sA * f + a.sB, outR, termL, mr::lane1_larger(d) ? offA : offB, 128 * mr::k2_kept_min(d));
 			}
 		}
 		__builtin_amdgcn_s_setprio(0);

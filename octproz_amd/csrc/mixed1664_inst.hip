@@ -10,32 +10,46 @@ template <int INTYPE, int RS, int MODE>
 hipError_t launch_mixed_one(const FusedArgs& a, hipStream_t stream) {
 	auto kernel = oct_mixed1664_kernel<INTYPE, RS, MODE>;
 	KernelLaunchInfo info;
-	hipError_t e = kernel_launch_info(kernel, MR_WAVES * 64, MR_LDS_BYTES, &info);
+	constexpr int lds = MR_LDS_BYTES + bg_lds_bytes<MODE, MR_N>();
+	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
+	hipError_t e = kernel_launch_info(kernel, MR_WAVES * 64, lds, &info);
 	if (e != hipSuccess) return e;
 	const unsigned need = (a.numLines + MR_WAVES - 1) / MR_WAVES;
 	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MR_WAVES * 64), MR_LDS_BYTES, stream, a);
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MR_WAVES * 64), lds, stream, a);
 	return hipGetLastError();
 }
 template <int RS, int MODE>
 hipError_t launch_mixed_real2_one(const FusedArgs& a, hipStream_t stream) {
 	auto kernel = oct_mixed1664_real2_kernel<RS, MODE>;
 	KernelLaunchInfo info;
-	hipError_t e = kernel_launch_info(kernel, MR_WAVES * 64, MR2_LDS_BYTES, &info);
+	constexpr int lds = MR2_LDS_BYTES + bg_lds_bytes<MODE, MR_N>();
+	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
+	hipError_t e = kernel_launch_info(kernel, MR_WAVES * 64, lds, &info);
 	if (e != hipSuccess) return e;
 	const unsigned pairs = (a.numLines + 1u) / 2u;
 	const unsigned need = (pairs + MR_WAVES - 1) / MR_WAVES;
 	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MR_WAVES * 64), MR2_LDS_BYTES, stream, a);
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MR_WAVES * 64), lds, stream, a);
 	return hipGetLastError();
+}
+template <int RS>
+hipError_t launch_mixed_real2_mode(bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (a.bgTerm) return logScale ? launch_mixed_real2_one<RS, MODE_LOG | MODE_BG>(a, stream) : launch_mixed_real2_one<RS, MODE_BG>(a, stream);
+	return logScale ? launch_mixed_real2_one<RS, MODE_LOG>(a, stream) : launch_mixed_real2_one<RS, 0>(a, stream);
 }
 template <int INTYPE, int RS>
 hipError_t launch_mixed_out(bool spectrum, bool logScale, const FusedArgs& a, hipStream_t st) {
 	if (spectrum) return launch_mixed_one<INTYPE, RS, MODE_SPECTRUM>(a, st);
+	if constexpr (INTYPE == IN_U16) {  // a.bgTerm: post-process background removal inside the image store
+		if (a.bgTerm) return logScale ? launch_mixed_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, st) : launch_mixed_one<INTYPE, RS, MODE_BG>(a, st);
+	} else if (a.bgTerm) {
+		return hipErrorInvalidValue;
+	}
 	if (logScale) return launch_mixed_one<INTYPE, RS, MODE_LOG>(a, st);
 	return launch_mixed_one<INTYPE, RS, 0>(a, st);
 }
@@ -60,9 +74,9 @@ hipError_t launch_mixed1664(int intype, int rs, bool spectrum, bool logScale, co
 // real transform input (no dispersion compensation): uint16 samples, no / linear / cubic resampling, image output
 hipError_t launch_mixed1664_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	switch (rs) {
-	case RS_NONE: return logScale ? launch_mixed_real2_one<RS_NONE, MODE_LOG>(a, stream) : launch_mixed_real2_one<RS_NONE, 0>(a, stream);
-	case RS_LINEAR: return logScale ? launch_mixed_real2_one<RS_LINEAR, MODE_LOG>(a, stream) : launch_mixed_real2_one<RS_LINEAR, 0>(a, stream);
-	case RS_CUBIC: return logScale ? launch_mixed_real2_one<RS_CUBIC, MODE_LOG>(a, stream) : launch_mixed_real2_one<RS_CUBIC, 0>(a, stream);
+	case RS_NONE: return launch_mixed_real2_mode<RS_NONE>(logScale, a, stream);
+	case RS_LINEAR: return launch_mixed_real2_mode<RS_LINEAR>(logScale, a, stream);
+	case RS_CUBIC: return launch_mixed_real2_mode<RS_CUBIC>(logScale, a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

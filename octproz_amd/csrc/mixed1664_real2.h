@@ -48,6 +48,8 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_real2_kernel(c
 		winL[i] = t.y * t.z;  // phasor = (1, 0): the window alone
 	}
 	for (int i = tid; i < N1 * N2; i += THREADS) twB[i] = a.twiddle[i];  // [k1][n2]
+	const float* termL = reinterpret_cast<const float*>(smem + MR2_LDS_BYTES);
+	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + MR2_LDS_BYTES), a.bgTerm, N / 2, tid, THREADS);
 	__syncthreads();
 
 	const int n2 = lane < N2 ? lane : N2 - 1;  // lanes 52..63 duplicate lane 51 (same values to the same addresses)
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_real2_kernel(c
 		}
 		const __amdgpu_buffer_rsrc_t out0 = make_rsrc(a.out + (size_t)orow[0] * (N / 2), N * 2u);
 		const __amdgpu_buffer_rsrc_t out1 = make_rsrc(a.out + (size_t)orow[1] * (N / 2), line0 + 1u < a.numLines ? N * 2u : 0u);
+		constexpr bool BG = (MODE & MODE_BG) != 0;
 #pragma unroll
 		for (int d = 0; d < 13; d++) {
 			const f2 zz = zk[d], mm = mean2[d];
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_real2_kernel(c
 			const float f1 = LOGSCALE ? __builtin_amdgcn_logf(p1) : __builtin_amdgcn_sqrtf(p1);
 			const float f2v = LOGSCALE ? __builtin_amdgcn_logf(p2) : __builtin_amdgcn_sqrtf(p2);
 			const int off = mr::lane1_larger(d) ? offA : offB;
-			buf_store32(sA * f1 + sB, out0, off, 128 * mr::k2_kept_min(d));
-			buf_store32(sA * f2v + sB, out1, off, 128 * mr::k2_kept_min(d));
+			store_image<BG>(sA * f1 + sB, out0, termL, off, 128 * mr::k2_kept_min(d));
+			store_image<BG>(sA * f2v + sB, out1, termL, off, 128 * mr::k2_kept_min(d));
 		}
 		__builtin_amdgcn_s_setprio(0);
 		wave_sync_lds();

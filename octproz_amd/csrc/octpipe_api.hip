@@ -72,6 +72,10 @@ struct octpipe {
 	f2* d_twiddle = nullptr;
 	f2* d_meanLine = nullptr;
 	float* d_postBg = nullptr;
+	float* d_bgTerm = nullptr;       // weight * d_postBg + offset for the removal inside the fused kernels' store
+	unsigned bgVersion = 1, bgTermVersion = 0;  // d_postBg content / what d_bgTerm was computed from
+	float bgTermWeight = 0.0f, bgTermOffset = 0.0f;
+	bool noFusedBg = getenv("OCTPIPE_NO_FUSED_BG") != nullptr;  // A/B switch: always the post pass
 	float* d_sinusCurve = nullptr;
 	f2* d_spectrum = nullptr;  // FPN / debug scratch, lazily
 	size_t spectrumLines = 0;
@@ -356,7 +360,10 @@ uint64_t displaySignature(const OctPipeParams& p) {
 	return s | 1ull;
 }
 
-int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt) {
+// wantBg: fold the post-process background removal into the image store if this buffer's route has such a kernel (raw uint16 rows
+// without the in-kernel rolling average through the fused / real-input / mixed-radix kernels); *bgApplied tells the caller
+int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt, bool wantBg = false,
+                bool* bgApplied = nullptr) {
 	const OctPipeParams& p = h->params;
 	oct::FusedArgs a{};
 	int intype = oct::IN_U16;
@@ -390,6 +397,19 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		a.raw = h->d_prepared;
 		intype = oct::IN_F32;
 		roll = false;
+	}
+	if (bgApplied) *bgApplied = false;
+	if (wantBg && !spectrum && intype == oct::IN_U16 && !roll && !h->libfft && (useMixed ? mixedDirect : !h->bluestein)) {
+		int rc = ensure((void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
+		if (rc) return rc;
+		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {
+			hipLaunchKernelGGL(oct::oct_bg_term_kernel, dim3((h->N / 2 + 255) / 256), dim3(256), 0, h->stream, h->d_bgTerm, h->d_postBg,
+			                   p.postProcessBackgroundWeight, p.postProcessBackgroundOffset, h->N / 2);
+			HIP_TRY(hipGetLastError());
+			h->bgTermVersion = h->bgVersion; h->bgTermWeight = p.postProcessBackgroundWeight; h->bgTermOffset = p.postProcessBackgroundOffset;
+		}
+		a.bgTerm = h->d_bgTerm;
+		if (bgApplied) *bgApplied = true;
 	}
 	a.out = out;
 	a.spectrum = spectrumOut;
@@ -620,12 +640,19 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 		if ((rc = ensure((void**)&h->d_sinusTmp, sizeof(float) * (S / 2)))) return rc;
 		d_fusedOut = h->d_sinusTmp;
 	}
-	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true))) return rc;
+	const bool sinus = p.sinusoidalScanCorrection != 0;
+	bool bgRemoval = p.postProcessBackgroundRemoval != 0;
+	// the removal commutes with everything but the sinusoidal correction (a blend of two A-scans in front of the clamp) and has
+	// to follow a recording requested for this very buffer: otherwise it rides on the fused kernel's store
+	bool bgFused = false;
+	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true,
+	                      bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !h->noFusedBg, &bgFused))) return rc;
+	if (bgFused) bgRemoval = false;
 
-	const bool sinus = p.sinusoidalScanCorrection != 0, bgRemoval = p.postProcessBackgroundRemoval != 0;
 	if (bgRemoval && p.postProcessBackgroundRecordingRequested) {  // cu:1557-1568: record from the corrected first B-scan, then remove
 		if (sinus && (rc = launchPostPass(h, true, false, d_fusedOut, d_curr))) return rc;
 		hipLaunchKernelGGL(oct::oct_get_postproc_background_kernel, dim3((N / 2 + 255) / 256), dim3(256), 0, h->stream, h->d_postBg, d_curr, N / 2, A);
+		h->bgVersion++;
 		HIP_TRY(hipGetLastError());
 		// the host shadow is filled in-stream before the callback fires (cu:652-656): the callback itself makes no HIP call
 		HIP_TRY(hipMemcpyAsync(h->h_postBg.data(), h->d_postBg, sizeof(float) * (N / 2), hipMemcpyDeviceToHost, h->stream));
@@ -829,7 +856,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_lanczosW};
+	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_lanczosW};
 	for (void* b : bufs) if (b) hipFree(b);
 	if (h->copyStream) hipStreamDestroy(h->copyStream);
 	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);
@@ -889,6 +916,7 @@ int octpipe_update_postprocess_background(octpipe_t* h, const float* background,
 		int rc = setDevice(h); if (rc) return rc;
 		std::memcpy(h->h_postBg.data(), background, sizeof(float) * (size_t)size);
 		HIP_TRY(hipMemcpyAsync(h->d_postBg, h->h_postBg.data(), sizeof(float) * (size_t)size, hipMemcpyHostToDevice, h->stream));
+		h->bgVersion++;
 		HIP_TRY(hipStreamSynchronize(h->stream));
 	}
 	return OCTPIPE_OK;
@@ -942,6 +970,7 @@ int octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size) {
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	HIP_TRY(hipMemcpy(h->d_meanLine, p, sizeof(float) * 2 * N, hipMemcpyHostToDevice)); p += sizeof(float) * 2 * N;
 	HIP_TRY(hipMemcpy(h->d_postBg, p, sizeof(float) * (N / 2), hipMemcpyHostToDevice));
+	h->bgVersion++;
 	std::memcpy(h->h_postBg.data(), p, sizeof(float) * (N / 2));
 	h->fpnDetermined = hd.fixedPatternNoiseDetermined != 0;
 	h->lutDirty = true;

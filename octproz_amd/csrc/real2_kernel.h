@@ -66,6 +66,8 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
+	const float* termL = reinterpret_cast<const float*>(smem + real2_lds_bytes<RS>());
+	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + real2_lds_bytes<RS>()), a.bgTerm, N / 2, tid, THREADS);
 	fill_twiddles<10>(tw, a.twiddle, tid, THREADS);
 	if constexpr (!REGTAB)
 	for (int i = tid; i < N; i += THREADS) {
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 		}
 		const __amdgpu_buffer_rsrc_t out0 = make_rsrc(a.out + (size_t)orow[0] * (N / 2), N * 2u);
 		const __amdgpu_buffer_rsrc_t out1 = make_rsrc(a.out + (size_t)orow[1] * (N / 2), line0 + 1u < a.numLines ? N * 2u : 0u);
+		constexpr bool BG = (MODE & MODE_BG) != 0;
 #pragma unroll
 		for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -270,8 +273,8 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 				const float p1 = s1.x * s1.x + s1.y * s1.y, p2 = s2.x * s2.x + s2.y * s2.y;
 				const float f1 = LOGSCALE ? __builtin_amdgcn_logf(p1) : __builtin_amdgcn_sqrtf(p1);
 				const float f2v = LOGSCALE ? __builtin_amdgcn_logf(p2) : __builtin_amdgcn_sqrtf(p2);
-				buf_store32(sA * f1 + sB, out0, lane * 4, (64 * m + 256 * u) * 4);
-				buf_store32(sA * f2v + sB, out1, lane * 4, (64 * m + 256 * u) * 4);
+				store_image<BG>(sA * f1 + sB, out0, termL, lane * 4, (64 * m + 256 * u) * 4);
+				store_image<BG>(sA * f2v + sB, out1, termL, lane * 4, (64 * m + 256 * u) * 4);
 			}
 
 		__builtin_amdgcn_s_setprio(0);

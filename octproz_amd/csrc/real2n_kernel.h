@@ -58,6 +58,8 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 	f2* rowp = reinterpret_cast<f2*>(wbase);  // ILV: element n = (row0[n], row1[n])
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
+	const float* termL = reinterpret_cast<const float*>(smem + real2n_lds_bytes<LOG2N>());
+	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + real2n_lds_bytes<LOG2N>()), a.bgTerm, N / 2, tid, THREADS);
 	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
 	for (int i = tid; i < N; i += THREADS) {
 		const float4 t = a.lut[i];
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 		}
 		const __amdgpu_buffer_rsrc_t out0 = make_rsrc(a.out + (size_t)orow[0] * (N / 2), N * 2u);
 		const __amdgpu_buffer_rsrc_t out1 = make_rsrc(a.out + (size_t)orow[1] * (N / 2), line0 + 1u < a.numLines ? N * 2u : 0u);
+		constexpr bool BG = (MODE & MODE_BG) != 0;
 #pragma unroll
 		for (int u = 0; u < RL / 2; u++)
 #pragma unroll
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 				const float f1 = LOGSCALE ? __builtin_amdgcn_logf(p1) : __builtin_amdgcn_sqrtf(p1);
 				const float f2v = LOGSCALE ? __builtin_amdgcn_logf(p2) : __builtin_amdgcn_sqrtf(p2);
 				const int off = (64 * m + u * (N / RL)) * 4;
-				buf_store32(sA * f1 + sB, out0, lane * 4, off);
-				buf_store32(sA * f2v + sB, out1, lane * 4, off);
+				store_image<BG>(sA * f1 + sB, out0, termL, lane * 4, off);
+				store_image<BG>(sA * f2v + sB, out1, termL, lane * 4, off);
 			}
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(0);
 		wave_sync_lds();

@@ -158,6 +158,14 @@ __global__ void oct_get_postproc_background_kernel(float* bg, const float* in, i
 	}
 }
 
+// term[r] = weight bg[r] + offset with the rounding of the post pass (two operations, no contraction): the fused kernels subtract
+// it inside their image store (kernels.h store_image) when the removal can be folded in
+__global__ void oct_bg_term_kernel(float* term, const float* bg, float weight, float offset, int spa) {
+#pragma clang fp contract(off)
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < spa) term[r] = weight * bg[r] + offset;
+}
+
 // ------------------------------------------------------------------ quantiser (cu:943-967)
 // (T)(saturate(v) * M), M = 2^bits - 1, truncation; the product in double up to 16 bit like the reference's `* (255.0)`.
 // One lane converts 16 / sizeof(T) values and stores 16 bytes.

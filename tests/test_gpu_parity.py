@@ -594,6 +594,48 @@ def test_postprocess_background_record_and_remove():
     pipe.close(); o.close(); oo.close()
 
 
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096, 1664])
+@pytest.mark.parametrize("variant", ["v180", "no_dispersion", "linear_flip", "lanczos", "lin_scale"])
+def test_background_removal_inside_the_fused_store_equals_the_post_pass(N, variant, monkeypatch):
+    """cu:757-767 saturate(v - (weight bg + offset)): without the sinusoidal correction the removal rides on the image store of
+    the fused / real-input / mixed-radix kernels (MODE_BG) instead of a second pass over the volume.  Bit for bit the image of
+    the post pass (OCTPIPE_NO_FUSED_BG=1), which test_gpu_side_kernels.py pins against the oracle; and close to the oracle
+    end to end."""
+    A, B = 27, 2
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    {"v180": mutate(), "no_dispersion": mutate(dispersionCompensation=0),
+     "linear_flip": mutate(resamplingInterpolation=INTERPOLATION.LINEAR, bscanFlip=1, dispersionCompensation=0),
+     "lanczos": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS),
+     "lin_scale": mutate(signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0)}[variant](p)
+    p.signalGrayscaleMax, p.signalGrayscaleMin = (110.0, 20.0) if p.signalLogScaling else (900.0, 0.0)
+    p.postProcessBackgroundRemoval = 1
+    p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 0.9, 0.01
+    p.loadPostProcessingBackground(np.linspace(0.0, 0.4, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + len(variant))
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    d = to_device(raw)
+    imgs = []
+    for post_pass in (False, True):
+        if post_pass:
+            monkeypatch.setenv("OCTPIPE_NO_FUSED_BG", "1")
+        p.postProcessBackgroundUpdated = True
+        pipe = Pipeline(p, device=0)
+        monkeypatch.delenv("OCTPIPE_NO_FUSED_BG", raising=False)
+        pipe.set_mean_line(o.mean_line(), pin=True)
+        for _ in range(2):  # second buffer: the cached term, same image
+            pipe.process_device(d.data_ptr()); pipe.synchronize()
+        imgs.append(pipe.processed_host())
+        pipe.close()
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    assert imgs[0].min() >= 0.0 and imgs[0].max() <= 1.0
+    assert (imgs[0] > 0).any() and (imgs[0] == 0).any()  # the clamp is active, the image is not empty
+    assert np.abs(imgs[0] - want).max() < 2e-3
+    o.close()
+
+
 @pytest.mark.parametrize("bits", [8, 12, 16])
 def test_streaming_quantised_and_float_with_callbacks(bits):
     """host-loop entry point octpipe_process + streamProcessedData / streamProcessedFloatData
