@@ -55,6 +55,11 @@ def draw(seed):
     # (the sinusoidal scan correction blends two A-scans in the image domain, where the power-domain tolerance of compare_images
     # has no meaning; it is checked bit for bit on identical input in test_gpu_side_kernels.py and end to end in "flip_sinus")
     p.sinusoidalScanCorrection = 0
+    # post-process background removal (cu:757-767): inside the fused kernels' store or as a post pass, depending on the route
+    p.postProcessBackgroundRemoval = int(rng.random() < 0.25)
+    if p.postProcessBackgroundRemoval:
+        p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = float(rng.uniform(0.5, 1.0)), float(rng.uniform(0.0, 0.05))
+        p.loadPostProcessingBackground(rng.uniform(0.0, 0.4, N // 2).astype(np.float32))
     container = ["u16", "u16", "u16", "u16", "u16shift", "u8", "u32"][int(rng.integers(0, 7))]
     shift = container == "u16shift"
     p.update_all_curves()
@@ -70,7 +75,7 @@ def draw(seed):
         raw = raw.astype(np.uint32) * 256
     what = "seed %d: N=%d %dx%d rs=%d/%d win=%d/%d disp=%d roll=%d/%d fpn=%d log=%d flip=%d sinus=%d shift=%d" % (
         seed, N, A, B, p.resampling, int(p.resamplingInterpolation), p.windowing, int(p.window), p.dispersionCompensation, p.backgroundRemoval,
-        p.rollingAverageWindowSize, p.fixedPatternNoiseRemoval, p.signalLogScaling, p.bscanFlip, p.sinusoidalScanCorrection, int(shift)) + " " + container
+        p.rollingAverageWindowSize, p.fixedPatternNoiseRemoval, p.signalLogScaling, p.bscanFlip, p.sinusoidalScanCorrection, int(shift)) + " " + container + (" bg" if p.postProcessBackgroundRemoval else "")
     return p, raw, what
 
 
@@ -87,6 +92,13 @@ def test_random_setting_combination_matches_oracle(seed):
     pipe.process_device(d.data_ptr())
     pipe.synchronize()
     got = pipe.processed_host()
+    if p.postProcessBackgroundRemoval:
+        # behind the clamp the image no longer maps back to a power: image-domain bound (the removal itself is checked bit for
+        # bit in test_gpu_side_kernels.py and against the post pass in test_gpu_parity.py)
+        assert got.min() >= 0.0 and got.max() <= 1.0, what
+        assert np.abs(got.astype(np.float64) - want).max() < 2e-3 * max(1.0, p.signalMultiplicator), what + ": image differs behind the background removal"
+        pipe.close(); o.close()
+        return
     # the tolerances of compare_images are stated for a unit multiplicator: take multiplicator and addend out on both sides
     q = copy.copy(p)
     q.signalMultiplicator, q.signalAddend = 1.0, 0.0
