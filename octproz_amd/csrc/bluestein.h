@@ -119,7 +119,7 @@ __global__ __launch_bounds__(bluestein_waves<LOG2M>() * 64) void oct_bluestein_k
 				const int bin = fft_bin<LOG2M>(lane, m, u);
 				const f2 t = octfft::cmul(v[m + u * NBL], a.filter[bin]);
 				if constexpr (Cfg<LOG2M>::PLANAR) v[m + u * NBL] = f2{t.x, -t.y};
-				else xbuf[pad16c(0) + bin + (bin >> 4)] = f2{t.x, -t.y};
+				else xbuf[pad16c(0) + bin + OCT_PADK * (bin >> 4)] = f2{t.x, -t.y};
 			}
 		if constexpr (Cfg<LOG2M>::PLANAR) {
 			// bin order -> natural order through the float plane, one component at a time (both sides
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(bluestein_waves<LOG2M>() * 64) void oct_bluestein_k
 			for (int q = 0; q < P; q++) v[q] = f2{nx[q], ny[q]};
 		} else {
 			wave_sync_lds();
-			const f2* rb = xbuf + (lane + (lane >> 4));
+			const f2* rb = xbuf + (lane + OCT_PADK * (lane >> 4));
 #pragma unroll
-			for (int q = 0; q < P; q++) v[q] = rb[68 * q];
+			for (int q = 0; q < P; q++) v[q] = rb[(64 + 4 * OCT_PADK) * q];
 			wave_sync_lds();
 		}
 		// ---- r = IFFT_M(p);  X[k] = (c[k]/M) * conj(r[k])

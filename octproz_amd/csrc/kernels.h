@@ -113,6 +113,9 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr int MINW = (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN || (LZ_LDS && LOG2N == 10)) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
+#ifndef OCT_PADK
+#define OCT_PADK 1  // pad elements per 16 of the complex exchange layout (2 keeps a lane's 16 outputs 16-byte aligned)
+#endif
 constexpr int ROW_OFF = 12;  // float offset of sample 0 inside the LDS row (room for mirror tap / Lanczos halo)
 constexpr int ROLL_PAD = 256;  // largest window half-size served by the prefix-sum route; pads of the prefix array on both sides
 
@@ -120,7 +123,7 @@ constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
 // LDS slice of one wave: the staged row (+ the prefix-sum array of the rolling average) and, later in
 // the iteration, the FFT exchange buffer: N complex padded by 1/16, or one float plane of that shape
 template <int N, bool ROLL = false> constexpr int wave_lds_bytes() {
-	constexpr int fft = (N + N / 16) * (Cfg<ilog2c(N)>::PLANAR ? 4 : 8);
+	constexpr int fft = (N + (Cfg<ilog2c(N)>::PLANAR ? 1 : OCT_PADK) * N / 16) * (Cfg<ilog2c(N)>::PLANAR ? 4 : 8);
 	constexpr int row = (N + 2 * ROW_OFF) * 4 + (ROLL ? (N + 2 * ROLL_PAD) * 4 : 0);
 	constexpr int m = fft > row ? fft : row;
 	return (m + 15) & ~15;
@@ -281,7 +284,7 @@ OCT_DEV float lanczos8(float x) {
 // per wave instruction.  (A contiguous last-pass mapping with 16-byte stores was used before the
 // permlane / planar exchanges; the 4-byte stores measured within 2 % of it.)
 // All LDS addresses are "per-lane base + compile-time offset" (immediate fields, no VALU).
-constexpr int pad16c(int j) { return j + (j >> 4); }
+constexpr int pad16c(int j) { return j + OCT_PADK * (j >> 4); }
 
 // READ: fetch the pass input from the LDS slice (else it is already in v in the strided mapping);
 // WRITE: store the pass output to the slice (else it stays in v: v[m + u*NB] = element j0 + u*NS).
@@ -295,9 +298,9 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 	constexpr int P = N / 64, NB = P / R;
 	static_assert(NB >= 1, "radix larger than points per lane");
 	if constexpr (READ) {
-		const f2* rb = xbuf + (lane + (lane >> 4));
+		const f2* rb = xbuf + (lane + OCT_PADK * (lane >> 4));
 #pragma unroll
-		for (int q = 0; q < P; q++) v[q] = rb[68 * q];
+		for (int q = 0; q < P; q++) v[q] = rb[(64 + 4 * OCT_PADK) * q];
 		wave_sync_lds();
 	}
 	if constexpr (PACK == 2) {
@@ -335,7 +338,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 		for (int m = 0; m < NB; m++) {
 			const int b = lane + 64 * m;
 			const int j0 = (b / NS) * (NS * R) + (b & (NS - 1));
-			f2* wb = xbuf + (j0 + (j0 >> 4));
+			f2* wb = xbuf + (j0 + OCT_PADK * (j0 >> 4));
 #pragma unroll
 			for (int u = 0; u < R; u++) wb[pad16c(u * NS)] = v[m + u * NB];
 		}

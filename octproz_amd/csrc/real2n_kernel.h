@@ -29,7 +29,7 @@ template <> struct Real2Cfg<11> { static constexpr int WAVES = 7,  MINW = 2; sta
 template <int LOG2N> constexpr int real2n_slice_bytes() {
 	constexpr int N = 1 << LOG2N;
 	constexpr int rows = 2 * (N + 2 * ROW_OFF) * 4;
-	constexpr int fft = (N + N / 16) * (Cfg<LOG2N>::PLANAR ? 4 : 8);
+	constexpr int fft = (N + (Cfg<LOG2N>::PLANAR ? 1 : OCT_PADK) * N / 16) * (Cfg<LOG2N>::PLANAR ? 4 : 8);
 	constexpr int mirror = (N / 2 + 1) * 8;
 	constexpr int m = rows > fft ? (rows > mirror ? rows : mirror) : (fft > mirror ? fft : mirror);
 	return (m + 15) & ~15;
