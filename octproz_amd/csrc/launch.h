@@ -52,6 +52,8 @@ OCT_DECL_LAUNCH(12)
 // N = 1024 / uint16 / image output without dispersion compensation (rs = RS_NONE, RS_LINEAR or RS_CUBIC): real FFT
 // input, two A-scans per complex transform (real2_kernel.h)
 hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
+// N = 1024 / uint16 / cubic / image output with a complex transform input: two A-scans per wave iteration (pair_kernel.h)
+hipError_t launch_pair(bool logScale, const FusedArgs& a, hipStream_t stream);
 
 // the other lengths with a real-input kernel (real2n_kernel.h)
 inline bool real2n_supported(int log2n) { return log2n == 8 || log2n == 9 || log2n == 11; }

@@ -123,6 +123,7 @@ struct octpipe {
 	void* user = nullptr;
 
 	bool timing = false;
+	bool usePair = getenv("OCTPIPE_PAIR") != nullptr;  // experiment switch: pair_kernel.h for the headline configuration
 	bool noReal2 = getenv("OCTPIPE_NO_REAL2") != nullptr;  // A/B switch: keep real-input configurations on oct_fused_kernel
 	bool fullDisplay = getenv("OCTPIPE_FULL_DISPLAY") != nullptr;  // A/B switch: whole en-face frame for every buffer
 	std::vector<TimedLaunch> timed;
@@ -479,6 +480,8 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
 		if (h->log2n == 10) HIP_TRY(oct::launch_real2(rs, p.signalLogScaling != 0, a, h->stream));
 		else HIP_TRY(oct::launch_real2n(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
+	} else if (h->log2n == 10 && intype == oct::IN_U16 && rs == oct::RS_CUBIC && !roll && !spectrum && !a.bgTerm && h->usePair) {
+		HIP_TRY(oct::launch_pair(p.signalLogScaling != 0, a, h->stream));
 	} else {
 		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, nullptr));
 	}

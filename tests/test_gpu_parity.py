@@ -445,6 +445,33 @@ def test_real_input_route_agrees_with_the_complex_route(N, monkeypatch):
     pipe.close(); general.close(); o.close()
 
 
+@pytest.mark.parametrize("A,B,mode", [(24, 3, "log"), (7, 3, "lin_flip"), (1, 1, "log")])
+def test_pair_kernel_experiment_matches_oracle_and_the_general_kernel(A, B, mode, monkeypatch):
+    """OCTPIPE_PAIR=1: the headline configuration on pair_kernel.h (two A-scans per wave iteration, structure-of-arrays
+    registers).  Not the default route (it measured within 1-2 % of the general kernel), kept and tested as
+    the record of that experiment: oracle tolerance, agreement with the general kernel, odd line counts."""
+    N = 1024
+    p = v180_benchmark_params(N, A, B)
+    if mode == "lin_flip":
+        p.signalLogScaling, p.signalGrayscaleMax, p.signalGrayscaleMin, p.bscanFlip = 0, 900.0, 0.0, 1
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=A + B)
+    o, general, d, want, ref = run_both(p, raw)
+    monkeypatch.setenv("OCTPIPE_PAIR", "1")
+    pair = Pipeline(p, device=0)
+    monkeypatch.delenv("OCTPIPE_PAIR")
+    if p.fixedPatternNoiseRemoval:
+        pair.set_mean_line(o.mean_line(), pin=True)
+    pair.process_device(d.data_ptr()); pair.synchronize()
+    got = pair.processed_host()
+    common.compare_images(got, want, p, "pair kernel %dx%d %s" % (A, B, mode))
+    common.compare_images(got, ref, p, "pair kernel vs general kernel")
+    assert not np.array_equal(got, ref)  # a different kernel really ran
+    pair.close(); general.close(); o.close()
+
+
 @pytest.mark.parametrize("N", [1664, 1000])
 def test_non_power_of_two_fpn_determination_and_flip(N):
     A, B = 24, 4
