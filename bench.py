@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--host-loop-seconds", type=float, default=3.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (exercises the RCCL setup, barrier and all-reduce on a 1-GPU box)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="test hook of the launcher: this rank exits with code 3 right after the rendezvous of a --dry-run")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch + rendezvous + calibration broadcast only, no GPU work (CPU test of the N-rank launch path with --backend gloo)")
     return ap.parse_args(argv)
@@ -64,7 +65,10 @@ def free_port():
 
 
 def launch_ranks(n, argv, timeout=3000.0):
-    """Start n rank processes of this script and relay rank 0's JSON line.  Runs before any GPU call of this process."""
+    """Start n rank processes of this script and relay rank 0's JSON line.  Runs before any GPU call of this process.
+    All children are polled: the first rank that exits non-zero ends the run at once (the others would sit in the rendezvous
+    or a barrier until the collective timeout), and only the processes started here are ever killed."""
+    import threading
     port = free_port()
     procs = []
     for r in range(n):
@@ -74,25 +78,42 @@ def launch_ranks(n, argv, timeout=3000.0):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)  # rank 0's pipe never fills up
+    reader.start()
     deadline = time.time() + timeout
-    out0 = ""
-    try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for p in procs[1:]:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-    except subprocess.TimeoutExpired:
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed = (-1, 124)
+            break
+        time.sleep(0.05)
+    if failed is not None:
         for p in procs:  # exactly the processes started here
             if p.poll() is None:
                 p.kill()
-        sys.stderr.write("bench.py launcher: ranks timed out\n")
-        return 124
-    rc = max(abs(p.returncode or 0) for p in procs)
+        for p in procs:
+            try:
+                p.wait(timeout=10.0)
+            except subprocess.TimeoutExpired:
+                pass
+        sys.stderr.write("bench.py launcher: %s\n" % ("ranks timed out" if failed[0] < 0 else "rank %d exited with code %d; the other ranks were stopped" % failed))
+    reader.join(timeout=10.0)
+    out0 = "".join(c for c in chunks if c)
+    rc = abs(failed[1]) if failed is not None else 0
     lines = [l for l in out0.splitlines() if l.strip()]
     js = [l for l in lines if l.lstrip().startswith("{")]
     for l in lines:
         if not js or l is not js[-1]:
             sys.stderr.write(l + "\n")
-    if js:
+    if js and rc == 0:
         print(js[-1], flush=True)
     elif rc == 0:
         rc = 1
@@ -146,6 +167,8 @@ def dry_run(args, world, rank):
     from octproz_amd import dist as odist
     from octproz_amd import v180_benchmark_params
     dist.init_process_group(backend=args.backend)
+    if rank == args.dry_run_fail_rank:
+        os._exit(3)  # a rank that dies while the others wait in a collective (launcher test)
     N = args.samples
     blob = None
     if rank == 0:
@@ -276,10 +299,14 @@ def main():
 
     dt, kernel_ms, launches = timed_run(pipe, vols, args.steps, args.warmup, args.warmup_seconds,
                                         barrier=dist.barrier if distributed else None)
+    kernel_ms_ranks = [kernel_ms]
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        km = [torch.zeros(1, dtype=torch.float64, device=comm_dev) for _ in range(ranks)]
+        dist.all_gather(km, torch.tensor([kernel_ms], dtype=torch.float64, device=comm_dev))
+        kernel_ms_ranks = [float(x.item()) for x in km]
 
     out = None
     if rank == 0:
@@ -289,7 +316,7 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM bytes per launch: NOT measured in this run -- copied from the PMC passes of the last profiling run
         # (profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE with the guide's gfx950 correction)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, rec = None, None, {}
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             if rec.get("workload") == "%dx%dx%d" % (N, A, B):
@@ -308,12 +335,16 @@ def main():
                        "warmup_seconds": args.warmup_seconds, "parallelism": "bscan-slab x%d" % ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_pair_kernel<4>" if os.environ.get("OCTPIPE_PAIR") else "oct_fused_kernel<10, 1, 2, 4>",
+                         "kernel": {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_fused_kernel<10, 1, 2, 4>",
                                     2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_fused_kernel<12, 1, 2, 4>",
                                     1664: "oct_mixed1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)"),
                          "kernel_ms": kernel_ms,
+                         "kernel_ms_per_rank": {"min": min(kernel_ms_ranks), "max": max(kernel_ms_ranks), "ranks": kernel_ms_ranks},
                          "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if traffic is not None and rec.get("kernel") and rec.get("kernel") != out["roofline"]["kernel"]:
+            # a traffic figure of another kernel says nothing about this one: drop it rather than report it
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = None, "profiles/hbm_traffic.json is for %s, not this kernel" % rec.get("kernel")
     pipe.close()
 
     if rank == 0 and ranks == 1 and not args.no_extras:
@@ -337,6 +368,11 @@ def main():
                 out["host_loop"] = {"error": str(e)}
     if rank == 0 and not args.no_cpu_baseline and ranks == 1:
         out["cpu_baseline"] = cpu_baseline(p, 11)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_note"] = "timed on rank 0 of the N = 1 run only" if ranks > 1 else "skipped (--no-cpu-baseline)"
+        if ranks > 1:
+            out["extras_note"] = "real_input / host_loop records belong to the N = 1 run"
 
     if distributed:
         dist.barrier()

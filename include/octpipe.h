@@ -111,7 +111,8 @@ typedef void (*octpipe_data_callback)(void* buffer, unsigned bitDepth, unsigned 
                                       unsigned linesPerFrame, unsigned framesPerBuffer,
                                       unsigned buffersPerVolume, unsigned currentBufferNr, void* user);
 typedef void (*octpipe_event_callback)(void* user); /* backgroundRecorded, gpu2hostnotifier.cpp:57 */
-/* Callbacks run inside hipLaunchHostFunc on the pipeline's stream: they MUST NOT call any octpipe_* function that
+/* Callbacks run inside hipLaunchHostFunc on the pipeline's result stream (the background callback on the compute stream):
+ * while a data callback runs, the next device-to-host copy waits, the kernels of the following buffers do not.  They MUST NOT call any octpipe_* function that
  * touches the device (everything except octpipe_last_error, octpipe_get_acquisition_params and
  * octpipe_get_postprocess_background_host) -- HIP calls are not allowed there and a stream wait would deadlock. */
 
@@ -203,10 +204,15 @@ int octpipe_process_device(octpipe_t* h, const void* d_raw);
 int octpipe_synchronize(octpipe_t* h);
 
 /* Device pointer to the processed volume (d_processedBuffer, cu:1118: float32
- * [buffersPerVolume][B][A][N/2]) and the index of the slot the last call wrote (cu:1535). */
+ * [buffersPerVolume][B][A][N/2]) and the index of the slot the last call wrote (cu:1535).
+ * With buffersPerVolume == 1 and float streaming active the pipeline alternates between TWO such buffers, so that the
+ * device-to-host copy of buffer k (result stream) overlaps the kernels of buffer k+1 without a race on the volume (the
+ * reference lets them race, cu:1396); the pointer returned here is the buffer written last. */
 int octpipe_get_processed_device(octpipe_t* h, void** d_processed, size_t* bytes, unsigned* bufferNumberInVolume);
 int octpipe_copy_processed_to_host(octpipe_t* h, float* dst, size_t count, size_t offset);
-/* the HIP stream all work of this handle is enqueued on (as void*), and a way to replace it */
+/* the HIP stream the kernels of this handle are enqueued on (as void*), and a way to replace it.  Two more streams belong to
+ * the handle: the copy stream (H2D of the raw buffer) and the result stream (quantiser, both D2H copies and the data
+ * callbacks, ordered against the compute stream by events: cu:1357-1386 on the rotating streams of cu:1396). */
 int octpipe_get_stream(octpipe_t* h, void** stream);
 int octpipe_set_stream(octpipe_t* h, void* stream);
 
@@ -223,6 +229,23 @@ int octpipe_debug_unpack(octpipe_t* h, const void* d_raw, size_t count, float* h
 /* route uint16 input through the float32 "prepared" path as well (normally only uint8/uint32 input
  * and the Lanczos variant take it); lets a test prove fused-unpack == standalone unpack bit-for-bit */
 int octpipe_debug_force_prepared(octpipe_t* h, int enable);
+/* Route selection for tests and A/B measurements: where two independent implementations of a stage exist, these flags keep
+ * a configuration on the slower / more general one so that the tests can hold one against the other.  Flags of an existing
+ * handle take effect with the next buffer; the FFT-backend flags are read when a handle is created: call with h = NULL to
+ * set them for the handles this THREAD creates afterwards (0 restores the default choice).  No environment variable is read
+ * anywhere in the library. */
+enum {
+	OCTPIPE_ROUTE_NO_REAL_INPUT = 1,   /* dispersion compensation off: keep the general kernel instead of the two-A-scans-per-transform kernels */
+	OCTPIPE_ROUTE_NO_FUSED_BG   = 2,   /* post-process background removal always as the post pass (cu:1567), never inside the image store */
+	OCTPIPE_ROUTE_FULL_DISPLAY  = 4,   /* display frames re-extracted from the whole volume for every buffer (cu:1571-1578 literally) */
+	OCTPIPE_ROUTE_NO_LIBFFT     = 16,  /* creation: Bluestein on the in-register FFT instead of hipFFT for lengths without a fused kernel (<= 2047) */
+	OCTPIPE_ROUTE_FORCE_LIBFFT  = 32,  /* creation: every length through unpack -> gather -> hipFFT -> epilogue (the reference's pass structure) */
+	OCTPIPE_ROUTE_NO_MIXED      = 64   /* creation: samplesPerLine = 1664 without the mixed-radix kernel */
+};
+int octpipe_debug_set_route(octpipe_t* h_or_null, unsigned flags);
+/* persistent-grid size (workgroups) of the last launch of the general fused kernel: each kernel variant has its own
+ * occupancy-derived grid, whatever was launched before it in the process */
+int octpipe_debug_last_grid(const octpipe_t* h, int* blocks);
 
 /* ------------------------------------------------------------------ result delivery
  * cuda_registerStreamingBuffers / cuda_unregisterStreamingBuffers (kernels.h:69-70, cu:659-675)

@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")  # override: A/B builds only
 
 OCTPIPE_OK = 0
+# OCTPIPE_ROUTE_* (include/octpipe.h, octpipe_debug_set_route): keep a configuration on the slower / more general of two routes
+ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED = 1, 2, 4, 16, 32, 64
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE"}
 
 
@@ -92,7 +94,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_process", "octpipe_process_async", "octpipe_wait_input", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
     "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_debug_spectrum",
-    "octpipe_debug_unpack", "octpipe_debug_force_prepared",
+    "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_last_grid",
     "octpipe_register_streaming_buffers", "octpipe_unregister_streaming_buffers",
     "octpipe_register_float_streaming_buffers", "octpipe_unregister_float_streaming_buffers",
     "octpipe_set_callbacks",
@@ -111,7 +113,7 @@ OCTHOST_SYMBOLS = [
     "octhost_buffer_count", "octhost_buffer_bytes", "octhost_buffer_slot", "octhost_buffer_ready",
     "octhost_buffer_set_ready", "octhost_buffer_curr_index", "octhost_buffer_set_curr_index",
     "octhost_virtual_system_create", "octhost_memory_system_create", "octhost_system_destroy",
-    "octhost_system_start", "octhost_system_stop", "octhost_system_running", "octhost_system_buffer",
+    "octhost_system_start", "octhost_system_stop", "octhost_system_running", "octhost_system_set_copy_threads", "octhost_system_buffer",
     "octhost_system_acquisition_params", "octhost_last_error",
     "octhost_processing_run", "octhost_processing_run_pipeline", "octhost_processing_run_group",
     "octhost_load_settings_ini", "octhost_save_settings_ini", "octhost_load_curve_csv", "octhost_save_curve_csv",
@@ -200,6 +202,9 @@ def lib():
         L.octpipe_debug_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.octpipe_debug_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.octpipe_debug_force_prepared.argtypes = [C.c_void_p, C.c_int]
+        L.octpipe_debug_set_route.argtypes = [C.c_void_p, C.c_uint]
+        L.octpipe_debug_last_grid.argtypes = [C.c_void_p, C.c_void_p]
+        L.octhost_system_set_copy_threads.argtypes = [C.c_void_p, C.c_uint]
         L.octpipe_register_streaming_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.octpipe_register_float_streaming_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.octpipe_set_callbacks.argtypes = [C.c_void_p, DATA_CALLBACK, DATA_CALLBACK, EVENT_CALLBACK, C.c_void_p]

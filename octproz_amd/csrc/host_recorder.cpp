@@ -1,9 +1,15 @@
-// host_recorder.cpp -- the Recorder of the reference (src/recorder.cpp:52-152) without Qt: accumulate K buffers in memory,
-// then write them back to back into  <savePath>/<timestamp>[_<fileName>]_<name>.raw  (headerless, the same layout the
-// virtual OCT system reads: virtualoctsystem.cpp:163-353).  OCTproZ runs two of these, named "raw" (fed from the
-// acquisition ring, processing.cpp:187-189) and "processed" (fed from the streaming callbacks, gpu2hostnotifier.cpp:45-53).
+// host_recorder.cpp -- writer of headerless .raw recordings, the file format the virtual OCT system replays
+// (virtualoctsystem.cpp:163-353).  Behavioural contract taken from the reference's Recorder (src/recorder.cpp:52-152):
+//   * file name  <savePath>/<timestamp>[_<fileName>]_<name>.raw  (OCTproZ runs two recorders, "raw" fed from the acquisition
+//     ring, processing.cpp:187-189, and "processed" fed from the streaming callbacks, gpu2hostnotifier.cpp:45-53);
+//   * K buffers back to back, optionally starting with the first buffer of a volume (currentBufferNr == 0);
+//   * the file appears under its name when the K-th buffer has arrived or the recording is aborted (an aborted recording
+//     keeps the buffers captured so far); buffers offered after that are ignored.
+// Structure here: one explicit state and write-through.  The reference holds all K buffers in one malloc and writes them at
+// the end; a 60 s streaming run at 256 MiB per buffer does not fit that, so every buffer goes straight to
+// "<final name>.part" (the page cache absorbs it at memcpy speed) and the file is renamed when the recording ends.
+#include <cerrno>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <string>
@@ -12,38 +18,43 @@
 
 #include "../../include/octhost.h"
 
+namespace {
+enum class RecState { Idle, Armed, Capturing, Complete, Failed };
+}
+
 struct octhost_recorder {
-	std::string name, savePath, path, error;
-	char* recBuffer = nullptr;
-	size_t bufferSizeInBytes = 0;
-	unsigned buffersToRecord = 0, recordedBuffers = 0;
-	bool startWithFirstBuffer = false;
-	bool initialized = false, recordingEnabled = false, recordingFinished = true, isRecording = false;
+	std::string name, finalPath, partPath, error;
+	RecState state = RecState::Idle;
+	FILE* file = nullptr;
+	size_t bytesPerBuffer = 0;
+	unsigned wanted = 0, captured = 0;
+	bool waitForBufferZero = false;
 	uint64_t bytesWritten = 0;
 };
 
 namespace {
 
-int recFail(octhost_recorder* r, const char* msg) { r->error = msg; return OCTPIPE_ERR_INVALID_ARGUMENT; }
-
-void uninit(octhost_recorder* r) {  // recorder.cpp:90-98
-	free(r->recBuffer);
-	r->recBuffer = nullptr;
-	r->initialized = false;
-	r->recordingFinished = true;
-	r->recordedBuffers = 0;
+int recFail(octhost_recorder* r, const std::string& msg, int code = OCTPIPE_ERR_INVALID_ARGUMENT) {
+	r->error = msg;
+	return code;
 }
 
-int saveToDisk(octhost_recorder* r) {  // recorder.cpp:136-152: whatever was captured so far, in one write
-	if (!r->initialized) return recFail(r, "Save recording to disk not possible. Record buffer not initialized.");
-	FILE* f = fopen(r->path.c_str(), "wb");
-	if (!f) return recFail(r, "Recording failed! Could not write file to disk.");
-	const size_t n = (size_t)r->recordedBuffers * r->bufferSizeInBytes;
-	const size_t w = n ? fwrite(r->recBuffer, 1, n, f) : 0;
-	fclose(f);
-	r->bytesWritten = w;
-	if (w != n) return recFail(r, "Recording failed! Short write.");
-	return OCTPIPE_OK;
+void dropPartFile(octhost_recorder* r) {
+	if (r->file) { fclose(r->file); r->file = nullptr; }
+	if (!r->partPath.empty()) remove(r->partPath.c_str());
+}
+
+// close the part file and publish it under the final name; the state afterwards is Complete or Failed
+int finish(octhost_recorder* r) {
+	int rc = OCTPIPE_OK;
+	if (r->file) {
+		if (fclose(r->file) != 0) rc = recFail(r, "recording lost: closing " + r->partPath + " failed (" + strerror(errno) + ")");
+		r->file = nullptr;
+	}
+	if (!rc && rename(r->partPath.c_str(), r->finalPath.c_str()) != 0)
+		rc = recFail(r, "recording lost: cannot move " + r->partPath + " to " + r->finalPath + " (" + strerror(errno) + ")");
+	r->state = rc ? RecState::Failed : RecState::Complete;
+	return rc;
 }
 
 }  // namespace
@@ -58,76 +69,77 @@ octhost_recorder_t* octhost_recorder_create(const char* name) {
 
 void octhost_recorder_destroy(octhost_recorder_t* r) {
 	if (!r) return;
-	free(r->recBuffer);
+	if (r->state == RecState::Armed || r->state == RecState::Capturing) dropPartFile(r);  // destroyed mid-recording without abort: nothing is kept
 	delete r;
 }
 
-int octhost_recorder_init(octhost_recorder_t* r, const OctHostRecordingParams* p) {  // slot_init, recorder.cpp:64-88
+int octhost_recorder_init(octhost_recorder_t* r, const OctHostRecordingParams* p) {
 	if (!r || !p) return OCTPIPE_ERR_INVALID_ARGUMENT;
-	struct stat st;
-	if (!p->savePath || !p->savePath[0] || stat(p->savePath, &st) != 0 || !S_ISDIR(st.st_mode)) {
-		uninit(r);
-		return recFail(r, "Recording not initialized: save path is empty or invalid.");
-	}
-	if (p->bufferSizeInBytes == 0 || p->buffersToRecord == 0) return recFail(r, "Recording not initialized: nothing to record.");
-	free(r->recBuffer);
-	r->recBuffer = static_cast<char*>(malloc((size_t)p->buffersToRecord * p->bufferSizeInBytes));
-	if (!r->recBuffer) { r->error = "out of memory"; return OCTPIPE_ERR_OUT_OF_MEMORY; }
-	r->bufferSizeInBytes = p->bufferSizeInBytes;
-	r->buffersToRecord = p->buffersToRecord;
-	r->startWithFirstBuffer = p->startWithFirstBuffer != 0;
-	std::string user = (p->fileName && p->fileName[0]) ? std::string("_") + p->fileName : std::string();
-	r->savePath = p->savePath;
-	r->path = r->savePath + "/" + (p->timestamp ? p->timestamp : "") + user + "_" + r->name + ".raw";
-	r->recordedBuffers = 0;
+	if (r->state == RecState::Armed || r->state == RecState::Capturing) dropPartFile(r);
+	r->state = RecState::Idle;
+	r->captured = 0;
 	r->bytesWritten = 0;
-	r->initialized = true;
-	r->recordingFinished = false;
-	r->recordingEnabled = true;
-	r->isRecording = false;
+	struct stat st;
+	if (!p->savePath || !p->savePath[0] || stat(p->savePath, &st) != 0 || !S_ISDIR(st.st_mode))
+		return recFail(r, "recorder not armed: the save path is empty or not a directory");
+	if (p->bufferSizeInBytes == 0 || p->buffersToRecord == 0) return recFail(r, "recorder not armed: zero buffers or zero bytes per buffer requested");
+	r->bytesPerBuffer = p->bufferSizeInBytes;
+	r->wanted = p->buffersToRecord;
+	r->waitForBufferZero = p->startWithFirstBuffer != 0;
+	r->finalPath = std::string(p->savePath) + "/" + (p->timestamp ? p->timestamp : "");
+	if (p->fileName && p->fileName[0]) r->finalPath += std::string("_") + p->fileName;
+	r->finalPath += "_" + r->name + ".raw";
+	r->partPath = r->finalPath + ".part";
+	r->file = fopen(r->partPath.c_str(), "wb");
+	if (!r->file) {
+		r->state = RecState::Failed;
+		return recFail(r, "recorder not armed: cannot create " + r->partPath + " (" + strerror(errno) + ")");
+	}
+	r->error.clear();
+	r->state = RecState::Armed;
 	return OCTPIPE_OK;
 }
 
-int octhost_recorder_record(octhost_recorder_t* r, const void* buffer, unsigned currentBufferNr) {  // slot_record, recorder.cpp:100-134
+int octhost_recorder_record(octhost_recorder_t* r, const void* buffer, unsigned currentBufferNr) {
 	if (!r || !buffer) return OCTPIPE_ERR_INVALID_ARGUMENT;
-	if (!r->recordingEnabled) return OCTPIPE_OK;
-	if (!r->initialized) return recFail(r, "Recording not possible. Record buffer not initialized.");
-	// a recording that has to start with the first buffer of a volume waits for buffer number 0
-	if (r->startWithFirstBuffer && !r->isRecording && currentBufferNr != 0) return OCTPIPE_OK;
-	r->isRecording = true;
-	std::memcpy(r->recBuffer + (size_t)r->recordedBuffers * r->bufferSizeInBytes, buffer, r->bufferSizeInBytes);
-	r->recordedBuffers++;
-	if (r->recordedBuffers >= r->buffersToRecord) {
-		r->recordingEnabled = false;
-		r->isRecording = false;
-		const int rc = saveToDisk(r);
-		uninit(r);
-		return rc;
+	switch (r->state) {
+	case RecState::Idle: case RecState::Complete: case RecState::Failed:
+		return OCTPIPE_OK;  // not recording: the buffer is not ours to take
+	case RecState::Armed:
+		if (r->waitForBufferZero && currentBufferNr != 0) return OCTPIPE_OK;  // the recording begins with a volume
+		r->state = RecState::Capturing;
+		break;
+	case RecState::Capturing:
+		break;
 	}
-	return OCTPIPE_OK;
+	if (fwrite(buffer, 1, r->bytesPerBuffer, r->file) != r->bytesPerBuffer) {
+		const std::string why = strerror(errno);
+		dropPartFile(r);
+		r->state = RecState::Failed;
+		return recFail(r, "recording lost: short write to " + r->partPath + " (" + why + ")", OCTPIPE_ERR_DEVICE);
+	}
+	r->captured++;
+	r->bytesWritten += r->bytesPerBuffer;
+	return r->captured >= r->wanted ? finish(r) : OCTPIPE_OK;
 }
 
-int octhost_recorder_abort(octhost_recorder_t* r) {  // slot_abortRecording, recorder.cpp:52-62: keep what was captured
+int octhost_recorder_abort(octhost_recorder_t* r) {
 	if (!r) return OCTPIPE_ERR_INVALID_ARGUMENT;
-	if (r->recordingEnabled && !r->recordingFinished) {
-		r->recordingEnabled = false;
-		const int rc = saveToDisk(r);
-		uninit(r);
-		return rc;
-	}
-	return OCTPIPE_OK;
+	if (r->state != RecState::Armed && r->state != RecState::Capturing) return OCTPIPE_OK;
+	return finish(r);  // what was captured so far (possibly nothing) becomes the file
 }
 
 int octhost_recorder_state(const octhost_recorder_t* r, int* recordingEnabled, int* finished, unsigned* recordedBuffers, uint64_t* bytesWritten) {
 	if (!r) return OCTPIPE_ERR_INVALID_ARGUMENT;
-	if (recordingEnabled) *recordingEnabled = r->recordingEnabled ? 1 : 0;
-	if (finished) *finished = r->recordingFinished ? 1 : 0;
-	if (recordedBuffers) *recordedBuffers = r->recordedBuffers;
+	const bool active = r->state == RecState::Armed || r->state == RecState::Capturing;
+	if (recordingEnabled) *recordingEnabled = active ? 1 : 0;
+	if (finished) *finished = active ? 0 : 1;
+	if (recordedBuffers) *recordedBuffers = r->captured;
 	if (bytesWritten) *bytesWritten = r->bytesWritten;
 	return OCTPIPE_OK;
 }
 
-const char* octhost_recorder_path(const octhost_recorder_t* r) { return r ? r->path.c_str() : ""; }
+const char* octhost_recorder_path(const octhost_recorder_t* r) { return r ? r->finalPath.c_str() : ""; }
 const char* octhost_recorder_error(const octhost_recorder_t* r) { return r ? r->error.c_str() : ""; }
 
 // SettingsFileManager's timestamp (settingsfilemanager.cpp:36): yyyyMMdd_hhmmsszzz, local time

@@ -8,6 +8,8 @@
 // acquire/release ordering so the slot contents are visible when the flag is.
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,8 +33,70 @@ struct octhost_buffer {
 	size_t bytesPerBuffer = 0;
 };
 
+// The per-buffer host copy of the "copy file to RAM" mode (virtualoctsystem.cpp:335: one memcpy of the whole buffer on the
+// acquisition thread, ~10 GB/s, which caps that mode at a third of what PCIe Gen5 x16 carries: performance_v100.md:99 names it
+// as the limit).  Here the acquisition thread splits the copy over a few persistent helper threads; the ring protocol (flags,
+// currIndex) is untouched: the slot is published when every part has landed.
+class CopyPool {
+public:
+	explicit CopyPool(unsigned helpers) {
+		for (unsigned i = 0; i < helpers; ++i) workers_.emplace_back([this, i] { run(i + 1); });
+	}
+	~CopyPool() {
+		{ std::lock_guard<std::mutex> l(m_); quit_ = true; ++gen_; }
+		wake_.notify_all();
+		for (auto& t : workers_) t.join();
+	}
+	void copy(void* dst, const void* src, size_t bytes) {
+		const unsigned parts = (unsigned)workers_.size() + 1;
+		if (parts == 1 || bytes < (size_t)(4u << 20)) { std::memcpy(dst, src, bytes); return; }
+		{
+			std::lock_guard<std::mutex> l(m_);
+			dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes;
+			pending_ = parts - 1;
+			++gen_;
+		}
+		wake_.notify_all();
+		part(0, parts);
+		std::unique_lock<std::mutex> l(m_);
+		done_.wait(l, [this] { return pending_ == 0; });
+	}
+
+private:
+	void part(unsigned i, unsigned parts) {
+		const size_t chunk = ((bytes_ / parts) + 4095) & ~(size_t)4095;  // page-sized pieces
+		const size_t lo = (size_t)i * chunk, hi = i + 1 == parts ? bytes_ : (lo + chunk < bytes_ ? lo + chunk : bytes_);
+		if (lo < hi) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+	}
+	void run(unsigned i) {
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> l(m_);
+				wake_.wait(l, [&] { return gen_ != seen; });
+				seen = gen_;
+				if (quit_) return;
+			}
+			part(i, (unsigned)workers_.size() + 1);
+			std::lock_guard<std::mutex> l(m_);
+			if (--pending_ == 0) done_.notify_one();
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::mutex m_;
+	std::condition_variable wake_, done_;
+	uint64_t gen_ = 0;
+	unsigned pending_ = 0;
+	bool quit_ = false;
+	char* dst_ = nullptr;
+	const char* src_ = nullptr;
+	size_t bytes_ = 0;
+};
+
 struct octhost_system {
 	OctHostVirtualParams p{};
+	unsigned copyThreads = 0;  // 0 = choose: min(8, hardware threads / 4), at least 1
+
 	std::string path;
 	const unsigned char* mem = nullptr;
 	size_t memBytes = 0;
@@ -106,6 +170,12 @@ void runFromRam(octhost_system* s, FILE* f) {
 	s->buffer->currIndex = 0;
 	int nextIndex = 1;
 	int streamIdx = (int)n - 1;
+	unsigned threads = s->copyThreads;
+	if (threads == 0) {
+		const unsigned hw = std::thread::hardware_concurrency();
+		threads = hw / 4 > 8 ? 8 : (hw / 4 < 1 ? 1 : hw / 4);
+	}
+	CopyPool pool(threads - 1);
 	s->started = true;
 	bool sync = true;
 	while (s->running.load()) {
@@ -113,7 +183,7 @@ void runFromRam(octhost_system* s, FILE* f) {
 		s->buffer->currIndex.store(nextIndex, std::memory_order_release);
 		if (!s->buffer->ready[nextIndex].load(std::memory_order_acquire)) {
 			streamIdx = (streamIdx + 1) % (int)n;
-			std::memcpy(s->buffer->bufferArray[nextIndex], s->streamBuffer->bufferArray[streamIdx], bytes);
+			pool.copy(s->buffer->bufferArray[nextIndex], s->streamBuffer->bufferArray[streamIdx], bytes);
 			s->buffer->ready[nextIndex].store(1, std::memory_order_release);
 			nextIndex = (s->buffer->currIndex.load() + 1) % 2;
 		}
@@ -274,6 +344,14 @@ int octhost_system_stop(octhost_system_t* s) {
 	if (!s) return hostFail("null system");
 	s->running = false;
 	if (s->thread.joinable()) s->thread.join();
+	return OCTPIPE_OK;
+}
+
+int octhost_system_set_copy_threads(octhost_system_t* s, unsigned threads) {
+	if (!s) return hostFail("null system");
+	if (s->thread.joinable()) return hostFail("set the copy threads before startAcquisition");
+	if (threads > 64) return hostFail("at most 64 copy threads");
+	s->copyThreads = threads;
 	return OCTPIPE_OK;
 }
 

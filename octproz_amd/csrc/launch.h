@@ -2,28 +2,37 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "bluestein.h"
 #include "kernels.h"
 
 namespace oct {
 
-// Per-kernel, per-DEVICE launch facts (CU count, resident workgroups per CU) and the one-time opt-in to > 64 KiB of dynamic
+// Per-KERNEL, per-DEVICE launch facts (CU count, resident workgroups per CU) and the one-time opt-in to > 64 KiB of dynamic
 // LDS.  One process may drive several GPUs through several handles (octpipe_group_*), possibly from several threads: the
-// cache is indexed by the current device and guarded by a mutex (hipFuncSetAttribute is per device).
+// cache is keyed by (kernel address, current device) and guarded by a mutex (hipFuncSetAttribute is per kernel and device).
+// The key is the ADDRESS, not the function-pointer type: every kernel taking FusedArgs has the same type, and a cache per
+// type would hand the first kernel's occupancy to all the others.
 struct KernelLaunchInfo { int numCU = 0, blocksPerCU = 0; bool ready = false; };
+struct KernelLaunchCache {
+	std::mutex mtx;
+	std::map<std::pair<const void*, int>, KernelLaunchInfo> entries;
+};
+inline KernelLaunchCache& kernel_launch_cache() {
+	static KernelLaunchCache c;  // one object per process (inline function: the linker merges the translation units' copies)
+	return c;
+}
 template <typename K>
 hipError_t kernel_launch_info(K kernel, int threads, size_t ldsBytes, KernelLaunchInfo* out) {
-	constexpr int kMaxDevices = 64;
-	static std::mutex mtx;
-	static KernelLaunchInfo cache[kMaxDevices];
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
-	if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
-	std::lock_guard<std::mutex> lock(mtx);
-	KernelLaunchInfo& c = cache[dev];
+	KernelLaunchCache& kc = kernel_launch_cache();
+	std::lock_guard<std::mutex> lock(kc.mtx);
+	KernelLaunchInfo& c = kc.entries[std::make_pair(reinterpret_cast<const void*>(kernel), dev)];
 	if (!c.ready) {
 		if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)) != hipSuccess) return e;
 		if ((e = hipDeviceGetAttribute(&c.numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
@@ -52,8 +61,6 @@ OCT_DECL_LAUNCH(12)
 // N = 1024 / uint16 / image output without dispersion compensation (rs = RS_NONE, RS_LINEAR or RS_CUBIC): real FFT
 // input, two A-scans per complex transform (real2_kernel.h)
 hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
-// N = 1024 / uint16 / cubic / image output with a complex transform input: two A-scans per wave iteration (pair_kernel.h)
-hipError_t launch_pair(bool logScale, const FusedArgs& a, hipStream_t stream);
 
 // the other lengths with a real-input kernel (real2n_kernel.h)
 inline bool real2n_supported(int log2n) { return log2n == 8 || log2n == 9 || log2n == 11; }

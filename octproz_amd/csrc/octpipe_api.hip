@@ -23,6 +23,7 @@
 namespace {
 
 thread_local std::string g_lastError;
+thread_local unsigned g_createRoute = 0;  // octpipe_debug_set_route(NULL, flags): FFT-backend flags for the handles this thread creates
 
 int fail(int code, const std::string& msg) {
 	g_lastError = msg;
@@ -54,8 +55,17 @@ struct octpipe {
 	int N = 0, A = 0, B = 0, log2n = 0, bytesPerSample = 0, sampleFormat = OCTPIPE_FORMAT_AUTO;
 	size_t S = 0;  // samplesPerBuffer
 
-	hipStream_t stream = nullptr;      // compute stream (all kernels)
+	hipStream_t stream = nullptr;      // compute stream (all kernels of the chain)
 	hipStream_t copyStream = nullptr;  // H2D of the raw buffer
+	hipStream_t outStream = nullptr;   // result delivery: quantiser, both D2H copies, data callbacks (cu:1357-1386)
+	hipEvent_t chainDone = nullptr;    // compute stream: the processed slot of the current buffer is complete
+	std::vector<hipEvent_t> destRead;  // result stream: everything that reads processed destination d has finished
+	std::vector<char> destReadPending;
+	float* d_processedAlt = nullptr;   // second processed buffer (buffersPerVolume == 1 with float streaming, see octpipe.h)
+	float* d_processedCur = nullptr;   // the one of the two the last buffer went to
+	int altCur = 0;
+	unsigned route = 0;                // OCTPIPE_ROUTE_* (octpipe_debug_set_route)
+	int lastGrid = 0;
 	bool ownStream = true;
 	hipEvent_t h2dDone[2] = {nullptr, nullptr};   // raw slot filled
 	hipEvent_t slotFree[2] = {nullptr, nullptr};  // fused kernel finished reading the raw slot
@@ -75,7 +85,6 @@ struct octpipe {
 	float* d_bgTerm = nullptr;       // weight * d_postBg + offset for the removal inside the fused kernels' store
 	unsigned bgVersion = 1, bgTermVersion = 0;  // d_postBg content / what d_bgTerm was computed from
 	float bgTermWeight = 0.0f, bgTermOffset = 0.0f;
-	bool noFusedBg = getenv("OCTPIPE_NO_FUSED_BG") != nullptr;  // A/B switch: always the post pass
 	float* d_sinusCurve = nullptr;
 	f2* d_spectrum = nullptr;  // FPN / debug scratch, lazily
 	size_t spectrumLines = 0;
@@ -123,9 +132,6 @@ struct octpipe {
 	void* user = nullptr;
 
 	bool timing = false;
-	bool usePair = getenv("OCTPIPE_PAIR") != nullptr;  // experiment switch: pair_kernel.h for the headline configuration
-	bool noReal2 = getenv("OCTPIPE_NO_REAL2") != nullptr;  // A/B switch: keep real-input configurations on oct_fused_kernel
-	bool fullDisplay = getenv("OCTPIPE_FULL_DISPLAY") != nullptr;  // A/B switch: whole en-face frame for every buffer
 	std::vector<TimedLaunch> timed;
 	double timedMs = 0.0;
 	unsigned timedLaunches = 0;
@@ -303,9 +309,10 @@ int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, boo
 		slot = h->fftPlanBatch[0] == 0 ? 0 : 1;
 		if (h->fftPlanBatch[slot]) { HIP_TRY(hipStreamSynchronize(h->stream)); h->fftDestroy(h->fftPlan[slot]); h->fftPlanBatch[slot] = 0; }
 		if (h->fftPlan1d(&h->fftPlan[slot], h->N, 0x29 /* HIPFFT_C2C */, (int)lines) != 0) return fail(OCTPIPE_ERR_DEVICE, "hipfftPlan1d failed");
-		if (h->fftSetStream(h->fftPlan[slot], h->stream) != 0) return fail(OCTPIPE_ERR_DEVICE, "hipfftSetStream failed");
 		h->fftPlanBatch[slot] = lines;
 	}
+	// bound before EVERY execution: octpipe_set_stream may have replaced the compute stream since the plan was made
+	if (h->fftSetStream(h->fftPlan[slot], h->stream) != 0) return fail(OCTPIPE_ERR_DEVICE, "hipfftSetStream failed");
 	if (h->fftExecC2C(h->fftPlan[slot], work, work, 1 /* HIPFFT_BACKWARD: e^{+2 pi i nk/N}, unnormalised */) != 0) return fail(OCTPIPE_ERR_DEVICE, "hipfftExecC2C failed");
 	if (!spectrum) {
 		hipLaunchKernelGGL(oct::oct_lib_epilogue_kernel, dim3(gridFor(lines * (N / 2))), dim3(256), 0, h->stream, work, a.out, a.meanLine, h->N, lines,
@@ -452,7 +459,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	} else if (useMixed) {
 		a.lut = h->d_lutPlain;
 		a.twiddle = h->d_twMixed;
-		if (intype == oct::IN_U16 && !spectrum && !p.dispersionCompensation && !h->noReal2)  // real FFT input: two A-scans per transform
+		if (intype == oct::IN_U16 && !spectrum && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT))  // real FFT input: two A-scans per transform
 			HIP_TRY(oct::launch_mixed1664_real2(rs, p.signalLogScaling != 0, a, h->stream));
 		else
 			HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
@@ -476,14 +483,12 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		b.sB = a.sB;
 		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
 	} else if ((h->log2n == 10 || oct::real2n_supported(h->log2n)) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
-	           !p.dispersionCompensation && !h->noReal2) {
+	           !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
 		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
 		if (h->log2n == 10) HIP_TRY(oct::launch_real2(rs, p.signalLogScaling != 0, a, h->stream));
 		else HIP_TRY(oct::launch_real2n(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
-	} else if (h->log2n == 10 && intype == oct::IN_U16 && rs == oct::RS_CUBIC && !roll && !spectrum && !a.bgTerm && h->usePair) {
-		HIP_TRY(oct::launch_pair(p.signalLogScaling != 0, a, h->stream));
 	} else {
-		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, nullptr));
+		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, &h->lastGrid));
 	}
 	if (timeIt && h->timing) {
 		HIP_TRY(hipEventRecord(t.stop, h->stream));
@@ -556,7 +561,7 @@ void launchDisplayB(int mb, int me, const oct::DisplayArgs& d, unsigned eb, hipS
 int updateDisplay(octpipe* h, bool bscan, unsigned frameNrB, unsigned framesB, int fnB, bool enface, unsigned frameNrE, unsigned framesE, int fnE,
                   bool currentBufferOnly = false) {
 	oct::DisplayArgs d{};
-	d.dispBscan = h->d_dispBscan; d.dispEnFace = h->d_dispEnFace; d.vol = h->d_processed;
+	d.dispBscan = h->d_dispBscan; d.dispEnFace = h->d_dispEnFace; d.vol = h->d_processedCur;
 	d.bscansPerVolume = (unsigned)h->B * h->acq.buffersPerVolume;
 	d.nBscan = (unsigned)(h->N * h->A / 2);
 	d.frameNrBscan = frameNrB < d.bscansPerVolume ? frameNrB : 0;   // cu:1269
@@ -633,7 +638,26 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	}
 
 	if (h->acq.buffersPerVolume > 1) h->bufferNumberInVolume = (h->bufferNumberInVolume + 1) % h->acq.buffersPerVolume;  // cu:1530-1532
-	float* d_curr = h->d_processed + (S / 2) * h->bufferNumberInVolume;                                                   // cu:1535
+	// Destination of this buffer.  The float D2H of buffer k reads its processed slot for milliseconds on the result stream; with
+	// one buffer per volume buffer k+1 would have to wait for it before it may overwrite the same slot, so two processed buffers
+	// alternate in that case (the reference lets its streams race on the single slot, cu:1396).
+	const bool floatStreaming = p.streamFloatToHost && h->floatStreamingRegistered;
+	unsigned dest = h->bufferNumberInVolume;
+	h->d_processedCur = h->d_processed;
+	if (h->acq.buffersPerVolume == 1 && floatStreaming) {
+		int rcAlt = ensure((void**)&h->d_processedAlt, sizeof(float) * (S / 2));
+		if (rcAlt) return rcAlt;
+		h->altCur ^= 1;
+		dest = (unsigned)h->altCur;
+		if (h->altCur) h->d_processedCur = h->d_processedAlt;
+	} else {
+		h->altCur = 0;
+	}
+	float* d_curr = h->d_processedCur + (S / 2) * h->bufferNumberInVolume;                                                // cu:1535
+	if (h->destReadPending[dest]) {  // the result stream may still be reading what this destination held
+		HIP_TRY(hipStreamWaitEvent(h->stream, h->destRead[dest], 0));
+		h->destReadPending[dest] = 0;
+	}
 
 	// with the sinusoidal correction on, the fused kernel writes a scratch slot and the post pass gathers from it into the
 	// volume (cu:1551-1554 copies the buffer device-to-device and runs a second pass instead)
@@ -649,7 +673,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	// to follow a recording requested for this very buffer: otherwise it rides on the fused kernel's store
 	bool bgFused = false;
 	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true,
-	                      bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !h->noFusedBg, &bgFused))) return rc;
+	                      bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG), &bgFused))) return rc;
 	if (bgFused) bgRemoval = false;
 
 	if (bgRemoval && p.postProcessBackgroundRecordingRequested) {  // cu:1557-1568: record from the corrected first B-scan, then remove
@@ -668,7 +692,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 
 	if (p.bscanViewEnabled || p.enFaceViewEnabled) {  // cu:1571-1578, both frames in one launch
 		const uint64_t sig = displaySignature(p);
-		const bool incremental = sig == h->displaySig && !h->fullDisplay;
+		const bool incremental = sig == h->displaySig && !(h->route & OCTPIPE_ROUTE_FULL_DISPLAY);
 		if ((rc = updateDisplay(h, p.bscanViewEnabled != 0, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan,
 		                        p.enFaceViewEnabled != 0, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView, incremental))) return rc;
 		h->displaySig = sig;
@@ -682,28 +706,43 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 		HIP_TRY(hipGetLastError());
 	}
 
-	if (p.streamFloatToHost && h->floatStreamingRegistered) {  // streamProcessedFloatData, cu:1374-1386
-		h->floatStreamingBufferNumber = (h->floatStreamingBufferNumber + 1) % 2;
-		void* dst = h->floatStreamingBufferNumber == 0 ? h->h_floatStream[0] : h->h_floatStream[1];
-		HIP_TRY(hipMemcpyAsync(dst, d_curr, (S / 2) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-		HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, dst, h->bufferNumberInVolume, 1}));
+	// Result delivery (streamProcessedFloatData cu:1374-1386, streamProcessedData cu:1357-1372) on the result stream: ordered
+	// behind this buffer's chain by chainDone, and in front of the next writer of the destination by destRead.  The D2H copies
+	// of buffer k overlap the H2D and the kernels of buffer k+1, as on the reference's rotating streams (cu:1396).
+	bool quantise = false;
+	if (p.streamToHost && h->h_stream[0] && h->h_stream[1]) {
+		quantise = h->streamedBuffers % (p.streamingBuffersToSkip + 1) == 0;
+		if (quantise) h->streamedBuffers = 0;
+		h->streamedBuffers++;
 	}
-	if (p.streamToHost && h->h_stream[0] && h->h_stream[1]) {  // streamProcessedData, cu:1357-1372
-		if (h->streamedBuffers % (p.streamingBuffersToSkip + 1) == 0) {
-			h->streamedBuffers = 0;
+	if (floatStreaming || quantise) {
+		HIP_TRY(hipEventRecord(h->chainDone, h->stream));
+		HIP_TRY(hipStreamWaitEvent(h->outStream, h->chainDone, 0));
+		void* qdst = nullptr;
+		if (quantise) {  // the (fast) kernel first: the volume slot is released after the float copy below
 			h->streamingBufferNumber = (h->streamingBufferNumber + 1) % 2;
-			void* dst = h->streamingBufferNumber == 0 ? h->h_stream[0] : h->h_stream[1];
+			qdst = h->streamingBufferNumber == 0 ? h->h_stream[0] : h->h_stream[1];
 			rc = ensure(&h->d_output, (S / 2) * (size_t)h->bytesPerSample);
 			if (rc) return rc;
 			const int qgrid = gridFor((S / 2) * (size_t)h->bytesPerSample / 16);
-			if (h->bytesPerSample == 1) hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint8_t>, dim3(qgrid), dim3(256), 0, h->stream, (uint8_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
-			else if (h->bytesPerSample == 2) hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint16_t>, dim3(qgrid), dim3(256), 0, h->stream, (uint16_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
-			else hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint32_t>, dim3(qgrid), dim3(256), 0, h->stream, (uint32_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
+			if (h->bytesPerSample == 1) hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint8_t>, dim3(qgrid), dim3(256), 0, h->outStream, (uint8_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
+			else if (h->bytesPerSample == 2) hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint16_t>, dim3(qgrid), dim3(256), 0, h->outStream, (uint16_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
+			else hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint32_t>, dim3(qgrid), dim3(256), 0, h->outStream, (uint32_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipMemcpyAsync(dst, h->d_output, (S / 2) * (size_t)h->bytesPerSample, hipMemcpyDeviceToHost, h->stream));
-			HIP_TRY(hipLaunchHostFunc(h->stream, hostCallback, new CallbackCtx{h, dst, h->bufferNumberInVolume, 0}));
 		}
-		h->streamedBuffers++;
+		void* fdst = nullptr;
+		if (floatStreaming) {
+			h->floatStreamingBufferNumber = (h->floatStreamingBufferNumber + 1) % 2;
+			fdst = h->floatStreamingBufferNumber == 0 ? h->h_floatStream[0] : h->h_floatStream[1];
+			HIP_TRY(hipMemcpyAsync(fdst, d_curr, (S / 2) * sizeof(float), hipMemcpyDeviceToHost, h->outStream));
+		}
+		HIP_TRY(hipEventRecord(h->destRead[dest], h->outStream));  // d_curr is no longer read from here on
+		h->destReadPending[dest] = 1;
+		if (floatStreaming) HIP_TRY(hipLaunchHostFunc(h->outStream, hostCallback, new CallbackCtx{h, fdst, h->bufferNumberInVolume, 1}));
+		if (quantise) {
+			HIP_TRY(hipMemcpyAsync(qdst, h->d_output, (S / 2) * (size_t)h->bytesPerSample, hipMemcpyDeviceToHost, h->outStream));
+			HIP_TRY(hipLaunchHostFunc(h->outStream, hostCallback, new CallbackCtx{h, qdst, h->bufferNumberInVolume, 0}));
+		}
 	}
 	return OCTPIPE_OK;
 }
@@ -761,14 +800,16 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "packed 12-bit buffers need an even number of samples");
 	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
-	// OCTPIPE_FORCE_LIBFFT=1: every length through the library route (measurement: the reference's multi-pass structure on this GPU)
+	// OCTPIPE_ROUTE_FORCE_LIBFFT: every length through the library route (measurement: the reference's multi-pass structure on this GPU)
 	// Lengths that are neither a power of two nor 1664: Bluestein on the in-register FFT (bluestein.h, up to 2047) or the library
 	// route; measured on MI355X the library route is 1.4-3x faster (N = 600: 160 vs 91 M A-scans/s, N = 2000: 48 vs 16 M), so it
-	// is the default where hipFFT can be loaded and Bluestein the fallback (OCTPIPE_NO_LIBFFT=1 forces it).
+	// is the default where hipFFT can be loaded and Bluestein the fallback (OCTPIPE_ROUTE_NO_LIBFFT forces it).
+	const unsigned createRoute = g_createRoute;
+	const bool forceLib = (createRoute & OCTPIPE_ROUTE_FORCE_LIBFFT) != 0, noLib = (createRoute & OCTPIPE_ROUTE_NO_LIBFFT) != 0;
 	const bool noFused = !oct::fused_supported(acq->samplesPerLine) && acq->samplesPerLine != oct::kMixedLength;
 	const bool bluesteinOk = oct::bluestein_log2m(acq->samplesPerLine) >= 0;
-	bool needLibFft = (noFused && (!bluesteinOk || getenv("OCTPIPE_NO_LIBFFT") == nullptr)) || getenv("OCTPIPE_FORCE_LIBFFT") != nullptr;
-	if (needLibFft && bluesteinOk && getenv("OCTPIPE_FORCE_LIBFFT") == nullptr && !fftLibraryAvailable()) needLibFft = false;
+	bool needLibFft = (noFused && (!bluesteinOk || !noLib)) || forceLib;
+	if (needLibFft && bluesteinOk && !forceLib && !fftLibraryAvailable()) needLibFft = false;
 	if (needLibFft && (acq->samplesPerLine < 8 || acq->samplesPerLine > 65536))
 		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must lie in 8..65536");
 	int count = 0;
@@ -779,6 +820,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 
 	octpipe* h = new octpipe();
 	h->device = device;
+	h->route = createRoute;
 	h->acq = *acq;
 	h->params = *params;
 	h->N = (int)acq->samplesPerLine;
@@ -795,7 +837,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	} else if (!oct::fused_supported(acq->samplesPerLine)) {
 		h->bluestein = true;
 		h->log2n = oct::bluestein_log2m(acq->samplesPerLine);
-		h->mixed = acq->samplesPerLine == oct::kMixedLength && getenv("OCTPIPE_NO_MIXED") == nullptr;  // (A/B switch: Bluestein for 1664 too)
+		h->mixed = acq->samplesPerLine == oct::kMixedLength && !(createRoute & OCTPIPE_ROUTE_NO_MIXED);  // (A/B route: Bluestein for 1664 too)
 	}
 	h->resample.assign(h->N, 0.0f);
 	h->dispersion.assign(h->N, 0.0f);
@@ -808,12 +850,18 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&h->outStream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&h->chainDone, hipEventDisableTiming));
+	h->destRead.assign(acq->buffersPerVolume < 2 ? 2 : acq->buffersPerVolume, nullptr);
+	h->destReadPending.assign(h->destRead.size(), 0);
+	for (auto& e : h->destRead) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	for (int i = 0; i < 2; ++i) {
 		HIP_TRY(hipEventCreateWithFlags(&h->h2dDone[i], hipEventBlockingSync | hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&h->slotFree[i], hipEventDisableTiming));
 	}
 	const size_t S = h->S;
 	if ((rc = ensure((void**)&h->d_processed, sizeof(float) * (S / 2) * acq->buffersPerVolume))) return rc;
+	h->d_processedCur = h->d_processed;
 	if ((rc = ensure((void**)&h->d_lut, sizeof(float4) * h->N))) return rc;
 	if ((rc = ensure((void**)&h->d_meanLine, sizeof(f2) * h->N))) return rc;
 	if ((rc = ensure((void**)&h->d_postBg, sizeof(float) * (h->N / 2)))) return rc;
@@ -847,7 +895,10 @@ int octpipe_destroy(octpipe_t* h) {
 	hipSetDevice(h->device);
 	if (h->stream) hipStreamSynchronize(h->stream);
 	if (h->copyStream) hipStreamSynchronize(h->copyStream);
+	if (h->outStream) hipStreamSynchronize(h->outStream);
 	for (auto& t : h->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+	if (h->chainDone) hipEventDestroy(h->chainDone);
+	for (auto e : h->destRead) if (e) hipEventDestroy(e);
 	for (int i = 0; i < 2; ++i) {
 		if (h->h_bufferRegistered[i]) hipHostUnregister(h->h_buffer[i]);
 		if (h->d_raw[i]) hipFree(h->d_raw[i]);
@@ -858,10 +909,11 @@ int octpipe_destroy(octpipe_t* h) {
 	if (h->d_cplx) hipFree(h->d_cplx);
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
-	void* bufs[] = {h->d_prepared, h->d_processed, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
+	void* bufs[] = {h->d_prepared, h->d_processed, h->d_processedAlt, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
 	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_lanczosW};
 	for (void* b : bufs) if (b) hipFree(b);
 	if (h->copyStream) hipStreamDestroy(h->copyStream);
+	if (h->outStream) hipStreamDestroy(h->outStream);
 	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);
 	delete h;
 	return OCTPIPE_OK;
@@ -1028,12 +1080,13 @@ int octpipe_synchronize(octpipe_t* h) {
 	int rc = setDevice(h); if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->copyStream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipStreamSynchronize(h->outStream));  // after the compute stream: its work waits on events recorded there
 	return OCTPIPE_OK;
 }
 
 int octpipe_get_processed_device(octpipe_t* h, void** d_processed, size_t* bytes, unsigned* bufferNumberInVolume) {
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
-	if (d_processed) *d_processed = h->d_processed;
+	if (d_processed) *d_processed = h->d_processedCur;
 	if (bytes) *bytes = sizeof(float) * (h->S / 2) * h->acq.buffersPerVolume;
 	if (bufferNumberInVolume) *bufferNumberInVolume = h->bufferNumberInVolume;
 	return OCTPIPE_OK;
@@ -1043,7 +1096,7 @@ int octpipe_copy_processed_to_host(octpipe_t* h, float* dst, size_t count, size_
 	if (!h || !dst) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	if (offset + count > (h->S / 2) * h->acq.buffersPerVolume) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "range outside the processed volume");
 	int rc = setDevice(h); if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(dst, h->d_processed + offset, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipMemcpyAsync(dst, h->d_processedCur + offset, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return OCTPIPE_OK;
 }
@@ -1141,6 +1194,17 @@ int octpipe_debug_force_prepared(octpipe_t* h, int enable) {
 	return OCTPIPE_OK;
 }
 
+int octpipe_debug_set_route(octpipe_t* h, unsigned flags) {
+	if (h) h->route = flags;
+	else g_createRoute = flags;
+	return OCTPIPE_OK;
+}
+int octpipe_debug_last_grid(const octpipe_t* h, int* blocks) {
+	if (!h || !blocks) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*blocks = h->lastGrid;
+	return OCTPIPE_OK;
+}
+
 int octpipe_register_streaming_buffers(octpipe_t* h, void* b1, void* b2, size_t bytesPerBuffer) {  // cu:659-666
 	if (!h || !b1 || !b2) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	if (bytesPerBuffer < (h->S / 2) * (size_t)h->bytesPerSample) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "streaming buffers too small");
@@ -1153,6 +1217,7 @@ int octpipe_register_streaming_buffers(octpipe_t* h, void* b1, void* b2, size_t 
 int octpipe_unregister_streaming_buffers(octpipe_t* h) {  // cu:668-675
 	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
 	if (h->stream) hipStreamSynchronize(h->stream);
+	if (h->outStream) hipStreamSynchronize(h->outStream);
 	for (int i = 0; i < 2; ++i) if (h->h_stream[i]) { hipHostUnregister(h->h_stream[i]); h->h_stream[i] = nullptr; }
 	return OCTPIPE_OK;
 }
@@ -1169,6 +1234,7 @@ int octpipe_register_float_streaming_buffers(octpipe_t* h, void* b1, void* b2, s
 int octpipe_unregister_float_streaming_buffers(octpipe_t* h) {  // cu:687-695
 	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
 	if (h->stream) hipStreamSynchronize(h->stream);
+	if (h->outStream) hipStreamSynchronize(h->outStream);
 	for (int i = 0; i < 2; ++i) if (h->h_floatStream[i]) { hipHostUnregister(h->h_floatStream[i]); h->h_floatStream[i] = nullptr; }
 	h->floatStreamingRegistered = false;
 	return OCTPIPE_OK;
@@ -1186,11 +1252,13 @@ int octpipe_set_callbacks(octpipe_t* h, octpipe_data_callback onStreamingData, o
 int octpipe_change_displayed_bscan_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1223-1240
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	int rc = setDevice(h); if (rc) return rc;
+	h->displaySig = 0;  // the frame no longer shows what params describe: the next buffer extracts both frames in full (cu:1571-1578)
 	return updateDisplay(h, true, frameNr, frames, fn, false, 0, 1, 0);
 }
 int octpipe_change_displayed_enface_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1243-1265
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	int rc = setDevice(h); if (rc) return rc;
+	h->displaySig = 0;
 	return updateDisplay(h, false, 0, 1, 0, true, frameNr, frames, fn);
 }
 int octpipe_get_display_buffers(octpipe_t* h, void** d_bscanFrame, size_t* bscanCount, void** d_enFaceFrame, size_t* enFaceCount) {

@@ -1,7 +1,6 @@
 // real2_inst.hip -- instantiates the real-input kernel (two A-scans per complex transform, N = 1024)
 #include "launch.h"
 #include "real2_kernel.h"
-#include "pair_kernel.h"
 
 namespace oct {
 
@@ -29,21 +28,6 @@ hipError_t launch_real2_mode(bool logScale, const FusedArgs& a, hipStream_t stre
 	return logScale ? launch_real2_one<RS, MODE_LOG>(a, stream) : launch_real2_one<RS, 0>(a, stream);
 }
 }  // namespace
-
-// N = 1024, uint16 rows, cubic resampling, complex transform input, image output: two A-scans per wave iteration (pair_kernel.h)
-hipError_t launch_pair(bool logScale, const FusedArgs& a, hipStream_t stream) {
-	auto kernel = logScale ? oct_pair_kernel<MODE_LOG> : oct_pair_kernel<0>;
-	KernelLaunchInfo info;
-	hipError_t e = kernel_launch_info(kernel, PAIR_WAVES * 64, PAIR_LDS_BYTES, &info);
-	if (e != hipSuccess) return e;
-	const unsigned pairs = (a.numLines + 1u) / 2u;
-	const unsigned need = (pairs + PAIR_WAVES - 1) / PAIR_WAVES;
-	unsigned blocks = (unsigned)info.numCU;  // 148 KiB of LDS: one persistent workgroup per CU
-	if (blocks > need) blocks = need;
-	if (blocks == 0) return hipSuccess;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(PAIR_WAVES * 64), PAIR_LDS_BYTES, stream, a);
-	return hipGetLastError();
-}
 
 // uint16 input, no / linear / cubic resampling, no rolling average, no dispersion compensation, image output, N = 1024
 hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {

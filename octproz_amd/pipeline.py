@@ -17,7 +17,7 @@ from .params import OctAlgorithmParameters
 
 
 class Pipeline:
-    def __init__(self, params: OctAlgorithmParameters, device=0, h_buffer1=None, h_buffer2=None, sample_format=0):
+    def __init__(self, params: OctAlgorithmParameters, device=0, h_buffer1=None, h_buffer2=None, sample_format=0, route=0):
         self.params = params
         self._h = C.c_void_p()
         self._lib = _lib.lib()
@@ -27,7 +27,12 @@ class Pipeline:
         b1 = h_buffer1.ctypes.data if h_buffer1 is not None else None
         b2 = h_buffer2.ctypes.data if h_buffer2 is not None else None
         # sample_format: OCTPIPE_FORMAT_* (0 = the reference's rule, 1/2 packed 12 bit, 3/4/5 int8/int16/int32)
-        rc = self._lib.octpipe_create_with_format(C.byref(self._h), device, C.byref(acq), C.byref(pod), b1, b2, int(sample_format))
+        # route: OCTPIPE_ROUTE_* flags (tests / A-B measurements); the FFT-backend flags are read at creation (thread-local default)
+        self._lib.octpipe_debug_set_route(None, int(route))
+        try:
+            rc = self._lib.octpipe_create_with_format(C.byref(self._h), device, C.byref(acq), C.byref(pod), b1, b2, int(sample_format))
+        finally:
+            self._lib.octpipe_debug_set_route(None, 0)
         if rc != 0:
             msg = self._lib.octpipe_last_error()
             if self._h:
@@ -41,8 +46,8 @@ class Pipeline:
 
     # reference-named entry points ------------------------------------------------------------
     @classmethod
-    def initializeCuda(cls, h_buffer1, h_buffer2, params, device=0, sample_format=0):
-        return cls(params, device, h_buffer1, h_buffer2, sample_format)
+    def initializeCuda(cls, h_buffer1, h_buffer2, params, device=0, sample_format=0, route=0):
+        return cls(params, device, h_buffer1, h_buffer2, sample_format, route)
 
     def octCudaPipeline(self, h_inputSignal):
         self._sync_params()
@@ -154,6 +159,15 @@ class Pipeline:
 
     def debug_force_prepared(self, on=True):
         check(self._lib.octpipe_debug_force_prepared(self._h, 1 if on else 0))
+
+    def set_route(self, flags):
+        """OCTPIPE_ROUTE_* of an existing handle (takes effect with the next buffer)"""
+        check(self._lib.octpipe_debug_set_route(self._h, int(flags)))
+
+    def last_grid(self):
+        n = C.c_int()
+        check(self._lib.octpipe_debug_last_grid(self._h, C.byref(n)))
+        return n.value
 
     def postprocess_background(self):
         out = np.empty(self.N // 2, dtype=np.float32)

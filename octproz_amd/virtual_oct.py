@@ -107,7 +107,8 @@ class VirtualOCTSystem:
     """VirtualOCTSystem (virtualoctsystem.cpp) over octhost_*: file or memory backed producer."""
 
     def __init__(self, bit_depth, width, height, depth, file_path=None, data=None, buffers_per_volume=1,
-                 buffers_from_file=2, bscan_offset=0, wait_time_us=0, copy_file_to_ram=True, sync_with_processing=True):
+                 buffers_from_file=2, bscan_offset=0, wait_time_us=0, copy_file_to_ram=True, sync_with_processing=True,
+                 copy_threads=None):
         self._lib = _lib.lib()
         self._params = VirtualParams(file_path.encode() if file_path else None, bit_depth, width, height, depth,
                                      buffers_per_volume, buffers_from_file, bscan_offset, wait_time_us,
@@ -121,6 +122,8 @@ class VirtualOCTSystem:
         if not self._s:
             raise _lib.OctPipeError(1, (self._lib.octhost_last_error() or b"").decode())
         self._s = C.c_void_p(self._s)
+        if copy_threads is not None:  # threads sharing the per-buffer copy of the "copy file to RAM" mode (1 = the reference)
+            check(self._lib.octhost_system_set_copy_threads(self._s, int(copy_threads)))
 
     def startAcquisition(self):
         rc = self._lib.octhost_system_start(self._s)

@@ -64,9 +64,11 @@ def compare_images(got, want, p, what=""):
     """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima.
 
     Non-finite values: log scaling maps a power of exactly 0 to -inf (cu:718, no guard).  -inf therefore IS the value
-    "P = 0" and is compared as such in the linear-power domain: where one side cancelled exactly against the mean line and
-    the other kept a rounding residue, the two differ by that residue, which must be below POWER_RTOL x line maximum like any
-    other bin.  NaN and +inf have no such meaning: their pattern must be identical on both sides."""
+    "P = 0".  The only way the two sides can legitimately disagree about it is the mean-line subtraction: one side cancels a
+    bin exactly, the other keeps a float32 rounding residue (~1e-14 of the line maximum in power).  So a -inf on one side
+    only is accepted when fixed-pattern-noise removal is on AND the other side's power is below DB_FLOOR x line maximum (the
+    bound under which the dB comparison does not look anyway); a kernel that zeroes a bin the other side sees above that
+    bound fails, and without the subtraction the -inf pattern must be identical.  NaN and +inf: identical pattern always."""
     half = int(p.samplesPerLine) // 2
     g = got.reshape(-1, half)
     w = want.reshape(-1, half)
@@ -82,6 +84,12 @@ def compare_images(got, want, p, what=""):
     pw = np.where(ok & ~zero_w, image_to_power(np.where(np.isfinite(w), w, 0), p), 0.0)
     line_max = pw.max(axis=1, keepdims=True)
     line_max[line_max == 0] = 1.0
+    one_sided = zero_g != zero_w
+    if one_sided.any():
+        assert p.fixedPatternNoiseRemoval, what + ": -inf pattern differs although nothing is subtracted"
+        residue = np.where(zero_g, pw, pg)[one_sided] / np.broadcast_to(line_max, pw.shape)[one_sided]
+        assert residue.max() <= DB_FLOOR, "%s: %d bins are -inf on one side only with up to %.2e of the line maximum on the other (cancellation bound %.0e)" % (
+            what, int(one_sided.sum()), float(residue.max()), DB_FLOOR)
     rel = np.abs(pg - pw) / line_max
     max_rel = float(rel.max())
     assert max_rel <= POWER_RTOL, "%s: linear-power error %.3e > %.1e" % (what, max_rel, POWER_RTOL)

@@ -30,6 +30,27 @@ def test_gpus_2_launches_two_ranks_that_share_the_blob():
     assert d["blob_checksum"] == sum(range(1024))  # every rank unpacked rank 0's mean line (max over ranks == the value)
 
 
+def test_gpus_8_launches_eight_ranks():
+    """the driver's largest form (one node, 8 GPUs), as a gloo dry run: eight rank processes, one blob, one JSON line"""
+    d = _run(["--gpus", "8", "--backend", "gloo", "--dry-run"])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["max_rank"] == 7
+    assert d["blob_checksum"] == sum(range(1024))
+
+
+def test_one_dying_rank_stops_the_launcher_quickly():
+    """rank 1 exits after the rendezvous while rank 0 waits in the broadcast: the launcher must notice that rank (not only
+    rank 0), stop the others it started and report the failing rank's code -- within seconds, not a collective timeout"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--dry-run", "--dry-run-fail-rank", "1"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 3, r.stdout + r.stderr
+    assert time.time() - t0 < 120
+    assert "rank 1 exited with code 3" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+
+
 def test_torchrun_style_environment_is_one_rank_per_process():
     """the driver's N > 1 form: WORLD_SIZE / RANK already in the environment -> no second level of launching"""
     d = _run(["--gpus", "1", "--backend", "gloo", "--dry-run"],

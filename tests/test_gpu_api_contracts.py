@@ -1,0 +1,175 @@
+"""Contracts of the C ABI that only show with more than one handle, stream or buffer in play:
+per-kernel launch geometry, the library-FFT route after octpipe_set_stream, display frames after an explicit frame change,
+and the result stream (octpipe.h "result delivery")."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+from oracle import octref
+from octproz_amd import Pipeline, _lib, synthetic_raw, v180_benchmark_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev(raw):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(raw).view(np.int16)).to("cuda:0")
+
+
+_GRID_SCRIPT = r"""
+import json, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from octproz_amd import Pipeline, synthetic_raw, v180_benchmark_params
+grids = {}
+for N in [int(a) for a in sys.argv[1:]]:
+    A, B = 512, 8                                   # 4096 A-scans: more than one persistent grid of any length
+    p = v180_benchmark_params(N, A, B)
+    p.fixedPatternNoiseRemoval = 0                  # one kernel variant per handle
+    pipe = Pipeline(p, device=0)
+    d = torch.from_numpy(synthetic_raw(N, A, B, seed=N).view(np.int16)).to("cuda:0")
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    grids[N] = pipe.last_grid()
+    pipe.close()
+print(json.dumps(grids))
+"""
+
+
+def _grids(lengths):
+    r = subprocess.run([sys.executable, "-c", _GRID_SCRIPT % ROOT] + [str(n) for n in lengths], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return {int(k): v for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+
+
+def test_every_kernel_has_its_own_launch_geometry():
+    """the persistent grid of a kernel follows ITS occupancy, not that of whichever kernel the process launched first: N = 4096
+    after N = 256 in one process gets the grid it gets in a fresh process, and the two lengths differ (N = 256 runs several
+    workgroups per CU, N = 4096 one)"""
+    alone = _grids([4096])
+    after = _grids([256, 4096])
+    first = _grids([4096, 256])
+    assert after[4096] == alone[4096] == first[4096]
+    assert after[256] == first[256]
+    assert after[256] != after[4096]
+
+
+@pytest.mark.parametrize("N", [600, 3000])
+def test_library_fft_route_follows_set_stream(N):
+    """lengths on the gather -> hipFFT -> epilogue route: after octpipe_set_stream the transform has to run on the NEW stream
+    (the plan was bound to the old, now destroyed one); a long-running kernel in front on the new stream makes a transform on
+    any other stream read its input too early"""
+    import torch
+    A, B = 64, 4
+    p = v180_benchmark_params(N, A, B)
+    raw = synthetic_raw(N, A, B, seed=N)
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    pipe = Pipeline(p, device=0)
+    pipe.set_mean_line(o.mean_line(), pin=True)
+    d = _dev(raw)
+    pipe.process_device(d.data_ptr()); pipe.synchronize()  # plans exist and are bound to the handle's own stream
+    first = pipe.processed_host()
+    s = torch.cuda.Stream()
+    pipe.set_stream(s.cuda_stream)
+    other = _dev(synthetic_raw(N, A, B, seed=N + 1))
+    big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda:0")
+    for k in range(3):
+        with torch.cuda.stream(s):
+            for _ in range(20):
+                big.add_(1)  # ~ms of work queued on the new stream in front of the chain
+        pipe.process_device((other if k % 2 == 0 else d).data_ptr())
+    pipe.process_device(d.data_ptr())
+    s.synchronize()
+    pipe.synchronize()
+    got = pipe.processed_host()
+    assert np.array_equal(got.view(np.uint32), first.view(np.uint32))
+    common.compare_images(got, want, p, "library route after set_stream, N=%d" % N)
+    pipe.close(); o.close()
+
+
+def _fetch(ptr, count, dtype):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = np.empty(count, dtype=dtype)
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(out.nbytes), 2) == 0
+    return out
+
+
+def test_frames_are_fully_re_extracted_after_an_explicit_frame_change():
+    """changeDisplayedEnFaceFrame / changeDisplayedBscanFrame (cu:1223-1265) put other frames on display than params describe;
+    the next buffer must show params' frames again, from the WHOLE volume (cu:1571-1578), not only its own A-scans"""
+    N, A, B, BPV = 512, 16, 4, 2
+    p = v180_benchmark_params(N, A, B, buffers_per_volume=BPV)
+    p.signalGrayscaleMax, p.signalGrayscaleMin = 110.0, 20.0
+    p.bscanViewEnabled, p.enFaceViewEnabled = 1, 1
+    p.frameNr, p.frameNrEnFaceView = 5, 40  # B-scan 5 lives in buffer slot 1
+    W = N // 2
+    pipe = Pipeline(p, device=0)
+    (pb, nb), (pe, ne) = pipe.display_buffers()
+    raws = [synthetic_raw(N, A, B, seed=900 + k) for k in range(4)]
+    vol = np.zeros(BPV * A * B * W, np.float32)
+    for k, r in enumerate(raws):
+        if k == 2:
+            # other plane / other B-scan on display, then the next buffer (slot 0) arrives
+            pipe.change_displayed_enface_frame(100, 1, 0)
+            pipe.change_displayed_bscan_frame(1, 1, 0)  # a B-scan of slot 0, the slot the next buffer goes to
+            assert np.array_equal(_fetch(pe, ne, np.float32).view(np.uint32), octref.display_enface(vol, W, ne, 100, 1, 0).view(np.uint32))
+        d = _dev(r)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        _, _, nr = pipe.processed_device()
+        vol[nr * A * B * W:(nr + 1) * A * B * W] = pipe.processed_host()
+        want_b = octref.display_bscan(vol, BPV * B, nb, p.frameNr, 1, 0)
+        want_e = octref.display_enface(vol, W, ne, p.frameNrEnFaceView, 1, 0)
+        assert np.array_equal(_fetch(pb, nb, np.float32).view(np.uint32), want_b.view(np.uint32)), "B-scan frame after buffer %d" % k
+        assert np.array_equal(_fetch(pe, ne, np.float32).view(np.uint32), want_e.view(np.uint32)), "en-face frame after buffer %d" % k
+    pipe.close()
+
+
+def test_float_streaming_with_one_buffer_per_volume_alternates_two_processed_buffers():
+    """octpipe.h: with buffersPerVolume == 1 and float streaming on, consecutive buffers go to two alternating processed buffers
+    (so the D2H of buffer k does not hold up buffer k+1); octpipe_get_processed_device / copy_processed_to_host follow the one
+    written last, and without streaming the single buffer is back"""
+    N, A, B = 1024, 64, 4
+    p = v180_benchmark_params(N, A, B)
+    raws = [synthetic_raw(N, A, B, seed=950 + k) for k in range(3)]
+    ref = Pipeline(p, device=0)
+    ds = [_dev(r) for r in raws]
+    ref.process_device(ds[0].data_ptr()); ref.synchronize()
+    mean = ref.mean_line()
+    ref.set_mean_line(mean, pin=True)
+    expected = []
+    for d in ds:
+        ref.process_device(d.data_ptr()); ref.synchronize()
+        expected.append(ref.processed_host())
+    base = ref.processed_device()[0]
+    ref.close()
+    p.streamFloatToHost = 1
+    pipe = Pipeline(p, device=0)
+    pipe.set_mean_line(mean, pin=True)
+    S2 = N * A * B // 2
+    fb = [np.zeros(S2, np.float32), np.zeros(S2, np.float32)]
+    pipe.register_float_streaming_buffers(fb[0], fb[1])
+    delivered = []
+    pipe.set_callbacks(on_float_streaming=lambda buf, *a: delivered.append(int(buf)))
+    ptrs = []
+    for k, d in enumerate(ds):
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        ptrs.append(pipe.processed_device()[0])
+        assert np.array_equal(pipe.processed_host().view(np.uint32), expected[k].view(np.uint32))
+        host = fb[0] if delivered[-1] == fb[0].ctypes.data else fb[1]
+        assert np.array_equal(host.view(np.uint32), expected[k].view(np.uint32))
+    assert len(delivered) == 3 and ptrs[0] != ptrs[1] and ptrs[2] == ptrs[0]
+    p.streamFloatToHost = 0
+    pipe.process_device(ds[1].data_ptr()); pipe.synchronize()
+    assert len(delivered) == 3
+    assert np.array_equal(pipe.processed_host().view(np.uint32), expected[1].view(np.uint32))
+    del base
+    pipe.unregister_float_streaming_buffers()
+    pipe.close()

@@ -1,0 +1,186 @@
+"""BASELINE config 5 at its real size: continuous 1024 x 512 x 256 buffers (256 MiB raw each) from the virtual OCT system's
+2-slot ring through octpipe_process, with the results streamed back to host memory, EVERY delivered buffer compared bit for
+bit while the run is going on -- and the file-backed leg: a 1664-sample recording on disk -> virtual system -> GPU ->
+Recorder, file against the oracle.
+
+What bounds the rates asserted here (PCIe Gen5 x16, ~57 GB/s measured per direction on the pool's boxes):
+  raw in            256 MiB per buffer  ->  <= 27.8 M A-scans/s whatever else happens
+  float32 out       256 MiB per buffer  ->  the same bound on the other direction (full duplex: both can run at once)
+  float32 + uint16  384 MiB per buffer  ->  <= 18.6 M A-scans/s
+and on the host the comparison itself (reading 2 x 256..384 MiB per buffer) plus, in "copy to RAM" mode, the producer's
+256 MiB copy per buffer compete with the DMA traffic for memory bandwidth.  So the asserted floors are per leg, a margin
+under what was measured (profiles/r3*_streaming*.json), not the 25 M of the unchecked preloaded run.
+
+OCT_STREAM_SECONDS (default 10) sets the duration; 60 is the BASELINE form."""
+import ctypes as C
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import common
+from oracle import octref
+from octproz_amd import Pipeline, Recorder, VirtualOCTSystem, synthetic_raw, v180_benchmark_params
+
+pytestmark = pytest.mark.gpu
+SECONDS = float(os.environ.get("OCT_STREAM_SECONDS", "10"))
+
+
+class ParallelChecker:
+    """callback side: memcmp of the delivered buffer against the expected image of buffer `count % n`, split over a pool of
+    threads (libc memcmp through ctypes runs without the GIL); returns when the whole buffer has been compared, i.e. before
+    the pipeline may overwrite it two buffers later"""
+
+    def __init__(self, expected, workers):
+        self.expected = expected
+        self.nbytes = expected[0].nbytes
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.workers = workers
+        self.memcmp = C.CDLL(None).memcmp
+        self.memcmp.restype = C.c_int
+        self.memcmp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.count, self.bad = 0, []
+
+    def __call__(self, buf, bit_depth, spl, lines, frames, bpv, nr, user):
+        k = self.count
+        self.count += 1
+        want = self.expected[k % len(self.expected)].ctypes.data
+        step = (self.nbytes // self.workers + 4095) & ~4095
+        futs = [self.pool.submit(self.memcmp, buf + off, want + off, min(step, self.nbytes - off)) for off in range(0, self.nbytes, step)]
+        if any(f.result() != 0 for f in futs):
+            self.bad.append(k)
+
+    def close(self):
+        self.pool.shutdown()
+
+
+def _expected_images(p, raws_dev):
+    """float image of every buffer through the device-resident entry point, mean line of the first buffer pinned"""
+    q = Pipeline(p, device=0)
+    q.process_device(raws_dev[0].data_ptr()); q.synchronize()
+    mean = q.mean_line()
+    q.set_mean_line(mean, pin=True)
+    out = []
+    for d in raws_dev:
+        q.process_device(d.data_ptr()); q.synchronize()
+        out.append(q.processed_host())
+    q.close()
+    return out, mean
+
+
+# measured on the pool's boxes (profiles/r3*_streaming_checked.json); floors = a margin under the slowest box seen
+FLOORS = {("preloaded", "float"): 20e6, ("ram", "float"): 15e6, ("ram", "float+u16"): 11e6}
+
+
+@pytest.mark.parametrize("mode,streams", [("preloaded", "float"), ("ram", "float"), ("ram", "float+u16")])
+def test_config5_full_size_streaming_every_buffer_bit_exact(mode, streams):
+    import torch
+    from octproz_amd.virtual_oct import synthetic_raw_torch
+    N, A, B = 1024, 512, 256
+    n_buf = 2 if mode == "preloaded" else 4
+    dev = torch.device("cuda", 0)
+    raws_dev = [synthetic_raw_torch(N, A, B, dev, seed=5000 + i) for i in range(n_buf)]
+    p = v180_benchmark_params(N, A, B)
+    expected, mean = _expected_images(p, raws_dev)
+    assert not np.array_equal(expected[0], expected[1])
+    data = np.concatenate([d.cpu().numpy().view(np.uint16).reshape(-1) for d in raws_dev])
+    del raws_dev
+    torch.cuda.empty_cache()
+    quant = streams == "float+u16"
+    expected_q = [octref.float_to_output(e, 12) for e in expected] if quant else None
+
+    p.streamFloatToHost, p.streamToHost, p.streamingBuffersToSkip = 1, 1 if quant else 0, 0
+    system = VirtualOCTSystem(12, N, A, B, data=data, buffers_from_file=n_buf, copy_file_to_ram=True, sync_with_processing=True)
+    system.startAcquisition()
+    ring = system.buffer
+    assert ring.bytesPerBuffer == 256 << 20
+    pipe = Pipeline.initializeCuda(ring.slot(0, np.uint16), ring.slot(1, np.uint16), p)
+    pipe.set_mean_line(mean, pin=True)
+    S2 = N * A * B // 2
+    fb = [np.zeros(S2, np.float32), np.zeros(S2, np.float32)]
+    pipe.register_float_streaming_buffers(fb[0], fb[1])
+    workers = min(32, max(4, (os.cpu_count() or 8) // 4))
+    cf = ParallelChecker(expected, workers)
+    cq = None
+    if quant:
+        qb = [np.zeros(S2, np.uint16), np.zeros(S2, np.uint16)]
+        pipe.register_streaming_buffers(qb[0], qb[1])
+        cq = ParallelChecker(expected_q, workers)
+    pipe.set_callbacks(on_streaming=cq, on_float_streaming=cf)
+    pipe._sync_params()
+    system.run_pipeline(pipe, max_buffers=4)  # page-fault / clock warm-up, checked like the rest
+    stats = system.run_pipeline(pipe, max_seconds=SECONDS)  # returns after octpipe_synchronize: every callback has fired
+    system.stopAcquisition()
+    total = int(stats.buffersProcessed) + 4
+    print("config5 %s %s: %.2f M A-scans/s, %d buffers in %.1f s, %.1f GB/s in" % (
+        mode, streams, stats.ascansPerSecond / 1e6, stats.buffersProcessed, stats.elapsedSeconds, stats.dataThroughputMBs * 1048576 / 1e9))
+    assert cf.count == total and (cq is None or cq.count == total)
+    assert cf.bad == [] and (cq is None or cq.bad == []), "corrupted buffers: float %r quantised %r" % (cf.bad[:8], cq.bad[:8] if cq else None)
+    assert np.array_equal(pipe.processed_host().view(np.uint32), expected[(total - 1) % n_buf].view(np.uint32))
+    assert stats.elapsedSeconds >= SECONDS
+    assert stats.ascansPerSecond >= FLOORS[(mode, streams)], "%.2f M A-scans/s" % (stats.ascansPerSecond / 1e6)
+    pipe.unregister_float_streaming_buffers()
+    if quant:
+        pipe.unregister_streaming_buffers()
+    cf.close()
+    if cq:
+        cq.close()
+    pipe.close(); system.close()
+
+
+def test_recording_on_disk_through_the_gpu_into_the_recorder(tmp_path):
+    """the file-backed path end to end: a 1664-sample raw recording (the reference data set's A-scan length,
+    performance_v100.md:101) read buffer by buffer from disk by the virtual OCT system (virtualoctsystem.cpp:226-288), through
+    octpipe_process on the GPU, float results into the "processed" Recorder from the streaming callback
+    (gpu2hostnotifier.cpp:75-86 -> recorder.cpp:100-134), raw ring slots into the "raw" Recorder (processing.cpp:187-189).
+    The raw file must come back bit for bit; the processed file must hold the oracle's image of every buffer."""
+    N, A, B, n = 1664, 64, 8, 4
+    bufs = [synthetic_raw(N, A, B, seed=1664 + i) for i in range(n)]
+    src = tmp_path / "recording_1664.raw"
+    np.concatenate([b.reshape(-1) for b in bufs]).tofile(str(src))
+    p = v180_benchmark_params(N, A, B)
+    o = common.make_oracle(p)
+    want = [o.process(b).copy() for b in bufs]  # first call determines the mean line; later ones reuse it (cu:1521)
+
+    p.streamFloatToHost = 1
+    system = VirtualOCTSystem(12, N, A, B, file_path=str(src), buffers_from_file=n, copy_file_to_ram=False, sync_with_processing=True)
+    system.startAcquisition()
+    ring = system.buffer
+    pipe = Pipeline.initializeCuda(ring.slot(0, np.uint16), ring.slot(1, np.uint16), p)
+    pipe.set_mean_line(o.mean_line(), pin=True)
+    S2 = N * A * B // 2
+    fb = [np.zeros(S2, np.float32), np.zeros(S2, np.float32)]
+    pipe.register_float_streaming_buffers(fb[0], fb[1])
+    rec_p, rec_r = Recorder("processed"), Recorder("raw")
+    rec_p.slot_init(str(tmp_path), S2 * 4, n, timestamp="T", file_name="gpu")
+    rec_r.slot_init(str(tmp_path), bufs[0].nbytes, n, timestamp="T", file_name="gpu")
+    lock = threading.Lock()
+
+    def on_float(buf, bit_depth, spl, lines, frames, bpv, nr, user):
+        with lock:
+            rec_p.slot_record_ptr(buf, nr)
+    pipe.set_callbacks(on_float_streaming=on_float)
+    pipe._sync_params()
+
+    def consume(ptr, nr):  # Processing::slot_start: record the raw slot, then process it (processing.cpp:187-190)
+        rec_r.slot_record_ptr(ptr, nr)
+        return pipe._lib.octpipe_process(pipe.handle, C.c_void_p(ptr))
+    rc, stats = system.run_processing(consume, max_buffers=n)
+    pipe.synchronize()
+    system.stopAcquisition()
+    assert rc == 0 and stats.buffersProcessed == n
+    assert rec_r.state["finished"] and rec_p.state["finished"]
+    assert os.path.basename(rec_p.path) == "T_gpu_processed.raw"
+    assert np.array_equal(np.fromfile(rec_r.path, np.uint16), np.fromfile(str(src), np.uint16))
+    got = np.fromfile(rec_p.path, np.float32).reshape(n, -1)
+    assert got.shape[1] == S2
+    for k in range(n):
+        common.compare_images(got[k], want[k], p, "recorded buffer %d" % k)
+    assert not np.array_equal(got[0], got[1])
+    # and the recording replays: the processed file is a valid float "recording" for the virtual system's reader (headerless)
+    assert os.path.getsize(rec_p.path) == n * S2 * 4
+    pipe.unregister_float_streaming_buffers()
+    rec_p.close(); rec_r.close()
+    pipe.close(); system.close(); o.close()

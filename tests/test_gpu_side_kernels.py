@@ -8,7 +8,7 @@ import pytest
 
 import common
 from oracle import octref
-from octproz_amd import Pipeline, synthetic_raw, v180_benchmark_params
+from octproz_amd import Pipeline, _lib, synthetic_raw, v180_benchmark_params
 
 pytestmark = pytest.mark.gpu
 
@@ -200,17 +200,15 @@ def test_incremental_display_extraction_equals_the_extraction_from_the_whole_vol
     pipe.close()
 
 
-def test_full_display_extraction_switch(monkeypatch):
-    """OCTPIPE_FULL_DISPLAY=1 extracts from the whole volume on every buffer (A/B switch): same frames"""
+def test_full_display_extraction_switch():
+    """OCTPIPE_ROUTE_FULL_DISPLAY extracts from the whole volume on every buffer (A/B route): same frames"""
     N, A, B = 1024, 16, 2
     p = v180_benchmark_params(N, A, B)
     _grey(p)
     raws = [synthetic_raw(N, A, B, seed=800 + k) for k in range(3)]
     frames = []
-    for env in (None, "1"):
-        if env:
-            monkeypatch.setenv("OCTPIPE_FULL_DISPLAY", env)
-        pipe = Pipeline(p, device=0)
+    for full in (False, True):
+        pipe = Pipeline(p, device=0, route=_lib.ROUTE_FULL_DISPLAY if full else 0)
         (pb, nb), (pe, ne) = pipe.display_buffers()
         for r in raws:
             d = _dev(r)
