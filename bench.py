@@ -130,7 +130,10 @@ def cpu_baseline(p, seed):
     from oracle import octref
     N, A = int(p.samplesPerLine), int(p.ascansPerBscan)
     L = octref.lib()
-    all_cores = L.octref_num_threads()
+    from octproz_amd import _lib as plib
+    # the OpenMP default is every hardware thread; a container with a CPU quota (16 of 256 on the pool's boxes) only gets
+    # throttled by more threads than that
+    all_cores = max(1, min(L.octref_num_threads(), int(plib.lib().octhost_usable_cpus())))
 
     def run(threads, bscans, seconds):
         L.octref_set_num_threads(threads)
@@ -152,7 +155,7 @@ def cpu_baseline(p, seed):
     many, repsn, dtn = run(all_cores, 64, 10.0)
     L.octref_set_num_threads(all_cores)
     return {"value": many, "unit": "A-scans/s", "cores": all_cores, "kind": "port",
-            "sample": "%d x %d x 64 (N x A x B) synthetic buffer, %d repetitions, %.1f s on %d OpenMP threads; CPU restatement "
+            "sample": "%d x %d x 64 (N x A x B) synthetic buffer, %d repetitions, %.1f s on %d OpenMP threads (= the CPUs the container may use: hardware threads capped by its cgroup quota); CPU restatement "
                       "of the reference algorithm (oracle/octref.c); the reference has no CPU path" % (N, A, repsn, dtn, all_cores),
             "one_core": {"value": one, "unit": "A-scans/s", "cores": 1,
                          "sample": "%d x %d x 4 buffer, %d repetitions, %.1f s on 1 thread" % (N, A, reps1, dt1)}}

@@ -61,9 +61,11 @@ int  octhost_system_start(octhost_system_t* s);   /* startAcquisition on its own
 int  octhost_system_stop(octhost_system_t* s);    /* stopAcquisition: acqusitionRunning=false, joins the thread */
 int  octhost_system_running(const octhost_system_t* s);
 /* Threads that share the per-buffer host copy of the "copy file to RAM" feeding mode (virtualoctsystem.cpp:335 does it with
- * one memcpy, which caps that mode near 10 GB/s): 1 = the reference's single copy, 0 (default) = min(8, hardware threads / 4).
+ * one memcpy, which caps that mode near 10 GB/s): 1 = the reference's single copy, 0 (default) = min(8, usable CPUs / 2).
  * Call before octhost_system_start. */
 int  octhost_system_set_copy_threads(octhost_system_t* s, unsigned threads);
+/* hardware threads capped by the cgroup CPU quota of the container (what helper-thread counts are derived from) */
+unsigned octhost_usable_cpus(void);
 octhost_buffer_t* octhost_system_buffer(octhost_system_t* s);
 int  octhost_system_acquisition_params(const octhost_system_t* s, OctPipeAcquisitionParams* out);
 const char* octhost_last_error(void);

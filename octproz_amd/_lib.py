@@ -113,7 +113,7 @@ OCTHOST_SYMBOLS = [
     "octhost_buffer_count", "octhost_buffer_bytes", "octhost_buffer_slot", "octhost_buffer_ready",
     "octhost_buffer_set_ready", "octhost_buffer_curr_index", "octhost_buffer_set_curr_index",
     "octhost_virtual_system_create", "octhost_memory_system_create", "octhost_system_destroy",
-    "octhost_system_start", "octhost_system_stop", "octhost_system_running", "octhost_system_set_copy_threads", "octhost_system_buffer",
+    "octhost_system_start", "octhost_system_stop", "octhost_system_running", "octhost_system_set_copy_threads", "octhost_usable_cpus", "octhost_system_buffer",
     "octhost_system_acquisition_params", "octhost_last_error",
     "octhost_processing_run", "octhost_processing_run_pipeline", "octhost_processing_run_group",
     "octhost_load_settings_ini", "octhost_save_settings_ini", "octhost_load_curve_csv", "octhost_save_curve_csv",
@@ -205,6 +205,7 @@ def lib():
         L.octpipe_debug_set_route.argtypes = [C.c_void_p, C.c_uint]
         L.octpipe_debug_last_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.octhost_system_set_copy_threads.argtypes = [C.c_void_p, C.c_uint]
+        L.octhost_usable_cpus.restype = C.c_uint
         L.octpipe_register_streaming_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.octpipe_register_float_streaming_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.octpipe_set_callbacks.argtypes = [C.c_void_p, DATA_CALLBACK, DATA_CALLBACK, EVENT_CALLBACK, C.c_void_p]

@@ -23,6 +23,27 @@
 namespace {
 thread_local std::string g_hostError;
 int hostFail(const std::string& m) { g_hostError = m; return OCTPIPE_ERR_INVALID_ARGUMENT; }
+
+// CPUs this process may really use: the hardware threads, capped by the cgroup CPU quota (a container on a 256-thread host
+// may be limited to 16 CPUs' worth of time; helper threads beyond that only get the whole process throttled)
+unsigned usableCpus() {
+	unsigned hw = std::thread::hardware_concurrency();
+	if (hw == 0) hw = 1;
+	double quota = 0.0;
+	if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+		char q[32] = {0};
+		long long period = 0;
+		if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0) quota = atof(q) / (double)period;
+		fclose(f);
+	} else {  // cgroup v1
+		long long q = -1, period = 0;
+		if (FILE* a = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(a, "%lld", &q) != 1) q = -1; fclose(a); }
+		if (FILE* b = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(b, "%lld", &period) != 1) period = 0; fclose(b); }
+		if (q > 0 && period > 0) quota = (double)q / (double)period;
+	}
+	if (quota >= 1.0 && quota < (double)hw) hw = (unsigned)quota;
+	return hw;
+}
 }  // namespace
 
 struct octhost_buffer {
@@ -95,7 +116,7 @@ private:
 
 struct octhost_system {
 	OctHostVirtualParams p{};
-	unsigned copyThreads = 0;  // 0 = choose: min(8, hardware threads / 4), at least 1
+	unsigned copyThreads = 0;  // 0 = choose: min(8, usable CPUs / 2), at least 1
 
 	std::string path;
 	const unsigned char* mem = nullptr;
@@ -172,8 +193,8 @@ void runFromRam(octhost_system* s, FILE* f) {
 	int streamIdx = (int)n - 1;
 	unsigned threads = s->copyThreads;
 	if (threads == 0) {
-		const unsigned hw = std::thread::hardware_concurrency();
-		threads = hw / 4 > 8 ? 8 : (hw / 4 < 1 ? 1 : hw / 4);
+		const unsigned cpus = usableCpus();
+		threads = cpus / 2 > 8 ? 8 : (cpus / 2 < 1 ? 1 : cpus / 2);
 	}
 	CopyPool pool(threads - 1);
 	s->started = true;
@@ -354,6 +375,8 @@ int octhost_system_set_copy_threads(octhost_system_t* s, unsigned threads) {
 	s->copyThreads = threads;
 	return OCTPIPE_OK;
 }
+
+unsigned octhost_usable_cpus(void) { return usableCpus(); }
 
 int octhost_system_running(const octhost_system_t* s) { return s && s->running.load() ? 1 : 0; }
 octhost_buffer_t* octhost_system_buffer(octhost_system_t* s) { return s ? s->buffer : nullptr; }
