@@ -48,6 +48,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the host_loop and real_input records (A/B runs, profiler passes)")
     ap.add_argument("--host-loop-seconds", type=float, default=3.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
+    ap.add_argument("--group", action="store_true",
+                    help="ONE process drives --gpus N devices through the native group (octpipe_group_*: per-member submit threads, "
+                         "RCCL broadcast of the calibration blob) instead of one process per GPU; members wrap around the visible devices")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (exercises the RCCL setup, barrier and all-reduce on a 1-GPU box)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="test hook of the launcher: this rank exits with code 3 right after the rendezvous of a --dry-run")
     ap.add_argument("--dry-run", action="store_true",
@@ -250,9 +253,60 @@ def host_loop_record(p, vols, seconds):
     return rec
 
 
+def group_run(args):
+    """`--group`: the native multi-GPU path of the library from ONE process: device-resident slabs, octpipe_group_process_device
+    per step (one submitting thread per member inside the library), calibration from member 0 over RCCL.  Same JSON shape."""
+    import torch
+    from octproz_amd import PipelineGroup, v180_benchmark_params
+    from octproz_amd.virtual_oct import synthetic_raw_torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    n, ndev = args.gpus, torch.cuda.device_count()
+    devices = [i % ndev for i in range(n)]
+    N, A, B = args.samples, args.ascans, args.bscans
+    slots = max(1, args.out_slots)
+    p = v180_benchmark_params(N, A, B * n, buffers_per_volume=slots)  # the WHOLE buffer: n slabs of B B-scans
+    g = PipelineGroup(p, devices)
+    if n > 1 and ndev == 1:
+        g.set_submit_threads(True)  # exercise the threaded submission on a one-GPU box too
+    vols = []
+    for v in range(max(1, args.volumes)):
+        vols.append([synthetic_raw_torch(N, A, B, torch.device("cuda", devices[i]), seed=1000 * i + 7 + v) for i in range(n)])
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    ptrs = [[t.data_ptr() for t in v] for v in vols]
+    g.process_device(ptrs[0]); g.synchronize()  # calibration on member 0 + broadcast
+    i = 0
+    for _ in range(args.warmup):
+        g.process_device(ptrs[i % len(ptrs)]); i += 1
+    g.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.warmup_seconds:
+        for _ in range(32):
+            g.process_device(ptrs[i % len(ptrs)]); i += 1
+        g.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        g.process_device(ptrs[(i + k) % len(ptrs)])
+    g.synchronize()
+    dt = time.perf_counter() - t0
+    info = g.info
+    out = {"metric": "A-scans/s", "value": n * A * B * args.steps / dt, "unit": "A-scans/s", "n_gpus": n, "rccl_ranks": 0,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%dx%dx%d 12-bit-in-uint16 raw slab per GPU, full chain, reference v1.8.0 settings" % (N, A, B),
+                      "parallelism": "native group x%d in one process (backend %s, %d submit threads, devices %s)" % (n, g.backend, info["submit_threads"], devices),
+                      "distinct_input_buffers": len(vols), "output_slots_rotated": slots},
+           "group": {"backend": g.backend, "broadcasts": g.broadcasts, **info}}
+    g.close()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
+    if args.group:
+        sys.exit(group_run(args))
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 

@@ -293,6 +293,13 @@ int octpipe_group_destroy(octpipe_group_t* g);                                  
 int octpipe_group_size(const octpipe_group_t* g);
 octpipe_t* octpipe_group_member(octpipe_group_t* g, int i);   /* NULL for a member without B-scans */
 int octpipe_group_slab(const octpipe_group_t* g, int i, unsigned* firstBscan, unsigned* bscanCount);
+/* One submitting host thread per member (persistent, asleep between buffers): on by default when the members sit on distinct
+ * devices, so that the n enqueue sequences of a call run side by side instead of one after the other; can be switched on
+ * for members that share a device (tests on a one-GPU box) and off.  octpipe_group_info reports the thread count (0 = the
+ * caller's thread submits) and how many member slabs of the ring slots could be moved to the NUMA node of their GPU
+ * (mbind, best effort; 0 on single-node hosts or where the container forbids it). */
+int octpipe_group_set_submit_threads(octpipe_group_t* g, int enable);
+int octpipe_group_info(const octpipe_group_t* g, int* submitThreads, int* slabsPlacedOnGpuNode);
 const char* octpipe_group_backend(const octpipe_group_t* g);   /* "rccl" or "copy" */
 uint64_t octpipe_group_broadcast_count(const octpipe_group_t* g);
 const char* octpipe_group_last_error(void);

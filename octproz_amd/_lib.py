@@ -102,6 +102,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_get_volume_view_buffer", "octpipe_register_gl_buffer_bscan", "octpipe_register_gl_buffer_enface_view", "octpipe_register_gl_buffer_volume_view",
     "octpipe_enable_kernel_timing", "octpipe_kernel_timing",
     "octpipe_group_create", "octpipe_group_destroy", "octpipe_group_size", "octpipe_group_member", "octpipe_group_slab",
+    "octpipe_group_set_submit_threads", "octpipe_group_info",
     "octpipe_group_backend", "octpipe_group_broadcast_count", "octpipe_group_last_error", "octpipe_group_set_params",
     "octpipe_group_update_resample_curve", "octpipe_group_update_dispersion_curve", "octpipe_group_update_window_curve",
     "octpipe_group_update_postprocess_background", "octpipe_group_set_mean_line", "octpipe_group_process",
@@ -225,6 +226,8 @@ def lib():
         L.octpipe_group_broadcast_count.argtypes = [C.c_void_p]
         L.octpipe_group_last_error.restype = C.c_char_p
         L.octpipe_group_slab.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.octpipe_group_set_submit_threads.argtypes = [C.c_void_p, C.c_int]
+        L.octpipe_group_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("octpipe_group_destroy", "octpipe_group_size", "octpipe_group_broadcast_calibration", "octpipe_group_synchronize"):
             getattr(L, name).argtypes = [C.c_void_p]
         for name in ("octpipe_group_set_params", "octpipe_group_process", "octpipe_group_process_device", "octpipe_group_copy_processed_to_host"):

@@ -69,6 +69,7 @@ hipError_t launch_real2n(int log2n, int rs, bool logScale, const FusedArgs& a, h
 // N = 1664 = 32 x 4 x 13 (the reference recording's length): mixed-radix transform in registers (mixed1664.h)
 constexpr unsigned kMixedLength = 1664;
 hipError_t launch_mixed1664(int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream);
+int mixed1664_lanczos_unit(int sample, int c);  // 16-byte unit of weights 4 c .. 4 c + 3 of a sample in the table this kernel reads
 // the same length with a real transform input (no dispersion compensation): two A-scans per transform (mixed1664_real2.h)
 hipError_t launch_mixed1664_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 

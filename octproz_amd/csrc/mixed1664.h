@@ -135,13 +135,18 @@ constexpr int k2_kept_min(int d) { return lane1_larger(d) ? k2_kept(0, d) : k2_k
 }  // namespace mr
 
 // INTYPE: IN_U16 (raw) or IN_F32 (prepared by oct_prepare_kernel: other containers / formats, rolling average).
-// RS: RS_NONE / RS_LINEAR / RS_CUBIC (Lanczos at this length stays on the Bluestein path).  MODE: MODE_SPECTRUM, MODE_LOG.
+// RS: RS_NONE / RS_LINEAR / RS_CUBIC / RS_LANCZOS.  MODE: MODE_SPECTRUM, MODE_LOG, MODE_BG.
+// Lanczos (cu:297-326): the row is staged with its 8-sample halos straight from the buffer (the taps cross line borders, and
+// line 0 reads 8 samples late: cu:313-314), the 16 tap weights of a sample are A-scan invariant and come from the table the
+// host computed (FusedArgs::lanczosW in the layout of lanczos_unit below: 104 KiB, L2 resident -- it does not fit the LDS next
+// to the transform's tables), summed in the reference's order.  Bluestein served this variant before (22 M A-scans/s).
+// unit (16 bytes = weights 4 c .. 4 c + 3) of sample 52 q + n2: consecutive lanes n2 read consecutive units
+constexpr int mr_lanczos_unit(int q, int c, int n2) { return (q * 4 + c) * MR_N2 + n2; }
 template <int INTYPE, int RS, int MODE>
 __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const FusedArgs a) {
 	constexpr int N = MR_N, N1 = MR_N1, N2 = MR_N2, THREADS = MR_WAVES * 64;
 	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	constexpr int CB = INTYPE == IN_U16 ? 8 : 16, NL = 7;  // 4 samples per lane and load: 7 x 256 >= 1664
-	static_assert(RS != RS_LANCZOS, "Lanczos: Bluestein path");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* rhoL = reinterpret_cast<float*>(smem);
 	f2* wphL = reinterpret_cast<f2*>(smem + N * 4);
@@ -192,14 +197,41 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 			else pre[i] = __builtin_bit_cast(u32x4, buf_load128(rawR, lane * CB, i * 64 * CB));
 		}
 	};
-	if (line < a.numLines) prefetch(line);
+	if constexpr (RS != RS_LANCZOS) { if (line < a.numLines) prefetch(line); }
+	const __amdgpu_buffer_rsrc_t lanczosR = make_rsrc(a.lanczosW, N * 64u);
 
 	for (; line < a.numLines; line += wavesTotal) {
+		if constexpr (RS == RS_LANCZOS) {
+			// stage [off - 8, off + N + 8) of the buffer, off = clamp(line N, 8, S - 9) (cu:313-314), 0 outside the buffer: 16-byte
+			// loads through a descriptor that ends with the buffer (N x 2 and 16 are multiples of 16: the window is aligned)
+			const long long S = (long long)a.linesInBuffer * N;
+			long long off = (long long)line * N;
+			if (off < 8) off = 8;
+			if (off > S - 9) off = S - 9;
+			constexpr int SPU = INTYPE == IN_U16 ? 8 : 4, UNITS = (N + 16) / SPU;  // samples per 16-byte unit
+			const char* g = reinterpret_cast<const char*>(a.raw) + (off - 8) * (INTYPE == IN_U16 ? 2 : 4);
+			const long long left = (S - (off - 8)) * (INTYPE == IN_U16 ? 2 : 4), want = (long long)UNITS * 16;
+			const __amdgpu_buffer_rsrc_t haloR = make_rsrc(g, (uint32_t)(left < want ? left : want));
+#pragma unroll
+			for (int i = 0; i < (UNITS + 63) / 64; i++) {
+				const int u = lane + 64 * i;
+				if (u < UNITS) {
+					const u32x4 c = __builtin_bit_cast(u32x4, buf_load128(haloR, u * 16, 0));
+					if constexpr (INTYPE == IN_U16) {
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 8 * u]) = chunk_to_float<IN_U16>(c, 0, shift);
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 8 * u + 4]) = chunk_to_float<IN_U16>(c, 1, shift);
+					} else {
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 4 * u]) = chunk_to_float<IN_F32>(c, 0, 0u);
+					}
+				}
+			}
+		} else {
 		// ---- stage the row in LDS as float32 (the last chunk overshoots the row inside the slice: harmless)
 #pragma unroll
 		for (int i = 0; i < NL; i++)
 			*reinterpret_cast<float4*>(&row[ROW_OFF + 4 * lane + 256 * i]) = chunk_to_float<INTYPE>(pre[i], 0, INTYPE == IN_U16 ? shift : 0u);
 		if (line + wavesTotal < a.numLines) prefetch(line + wavesTotal);
+		}
 		wave_sync_lds();
 		if constexpr (RS == RS_CUBIC) {
 			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
@@ -215,6 +247,16 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 			float y;
 			if constexpr (RS == RS_NONE) {
 				y = row[ROW_OFF + j];
+			} else if constexpr (RS == RS_LANCZOS) {
+				const int n0 = (int)rhoL[j];
+				const float* t = &row[ROW_OFF + n0];
+				f32x4 w[4];
+#pragma unroll
+				for (int c = 0; c < 4; c++) w[c] = buf_load128(lanczosR, n2 * 16, mr_lanczos_unit(q, c, 0) * 16);
+				float sum = 0.0f;
+#pragma unroll
+				for (int i = -7; i <= 8; i++) sum += t[i] * w[(i + 7) >> 2][(i + 7) & 3];  // the order of cu:315-321
+				y = sum;
 			} else {
 				const float rho = rhoL[j];
 				const int n1 = (int)rho;

@@ -59,12 +59,16 @@ hipError_t launch_mixed_rs(int rs, bool spectrum, bool logScale, const FusedArgs
 	case RS_NONE: return launch_mixed_out<INTYPE, RS_NONE>(spectrum, logScale, a, st);
 	case RS_LINEAR: return launch_mixed_out<INTYPE, RS_LINEAR>(spectrum, logScale, a, st);
 	case RS_CUBIC: return launch_mixed_out<INTYPE, RS_CUBIC>(spectrum, logScale, a, st);
-	default: return hipErrorInvalidValue;  // Lanczos: Bluestein path
+	case RS_LANCZOS: return launch_mixed_out<INTYPE, RS_LANCZOS>(spectrum, logScale, a, st);
+	default: return hipErrorInvalidValue;
 	}
 }
 }  // namespace
 
-// intype: IN_U16 or IN_F32 (prepared); rs: RS_NONE / RS_LINEAR / RS_CUBIC; FusedArgs::twiddle = W_1664^{n2 k1} as [k1][n2]
+// intype: IN_U16 or IN_F32 (prepared); rs: RS_*; FusedArgs::twiddle = W_1664^{n2 k1} as [k1][n2]; RS_LANCZOS: FusedArgs::lanczosW in
+// the unit layout of mr_lanczos_unit
+int mixed1664_lanczos_unit(int sample, int c) { return mr_lanczos_unit(sample / MR_N2, c, sample % MR_N2); }
+
 hipError_t launch_mixed1664(int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	if (intype == IN_U16) return launch_mixed_rs<IN_U16>(rs, spectrum, logScale, a, stream);
 	if (intype == IN_F32) return launch_mixed_rs<IN_F32>(rs, spectrum, logScale, a, stream);

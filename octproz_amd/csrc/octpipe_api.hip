@@ -207,6 +207,12 @@ int uploadLut(octpipe* h) {
 				w[(size_t)j * 16 + (size_t)(i + 7)] = (ax < 0.00001f) ? 1.0f : (s1 * s8);
 			}
 		}
+		if (h->mixed) {  // the mixed-radix kernel reads the weights of sample 52 q + n2 as units [q][c][n2] (coalesced across lanes)
+			std::vector<float> r(w.size());
+			for (int j = 0; j < N; ++j)
+				for (int c = 0; c < 4; ++c) std::memcpy(&r[(size_t)oct::mixed1664_lanczos_unit(j, c) * 4], &w[(size_t)j * 16 + (size_t)c * 4], 16);
+			w.swap(r);
+		}
 		if (!h->d_lanczosW) HIP_TRY(hipMalloc((void**)&h->d_lanczosW, sizeof(float) * w.size()));
 		HIP_TRY(hipMemcpyAsync(h->d_lanczosW, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice, h->stream));
 		HIP_TRY(hipStreamSynchronize(h->stream));
@@ -352,7 +358,7 @@ size_t rawBytes(const octpipe* h) {
 // Lanczos taps reach 8 samples into the neighbour rows: with the rolling average on, those have to be the corrected samples
 bool needsPrepared(const octpipe* h) {
 	return h->libfft || h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO ||
-	       (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS && (h->params.backgroundRemoval != 0 || h->mixed));
+	       (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS && h->params.backgroundRemoval != 0);
 }
 
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
@@ -383,7 +389,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	}
 	a.raw = d_raw;
 	// N = 1664: the mixed-radix kernel takes uint16 directly; other containers / formats and the rolling average come prepared
-	const bool useMixed = h->mixed && rs != oct::RS_LANCZOS;
+	const bool useMixed = h->mixed;
 	const bool mixedDirect = useMixed && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
 	// packed 12-bit rows are decoded inside the fused kernel (1.5 B per sample from HBM) wherever the general kernel runs on
 	// raw rows; the prepared float32 route remains for N = 256, the rolling average, Lanczos and the non-power-of-two lengths
@@ -459,7 +465,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	} else if (useMixed) {
 		a.lut = h->d_lutPlain;
 		a.twiddle = h->d_twMixed;
-		if (intype == oct::IN_U16 && !spectrum && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT))  // real FFT input: two A-scans per transform
+		if (intype == oct::IN_U16 && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT))  // real FFT input: two A-scans per transform
 			HIP_TRY(oct::launch_mixed1664_real2(rs, p.signalLogScaling != 0, a, h->stream));
 		else
 			HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));

@@ -11,9 +11,16 @@
 // link dependency on it, and a process that already holds an RCCL (PyTorch brings its own copy) reuses that one.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
+#include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/octpipe.h"
@@ -50,9 +57,105 @@ bool loadRccl(RcclApi* api) {
 	return api->ok();
 }
 
+// One submitting thread per member.  A call of octpipe_group_process enqueues an H2D copy and the chain on EVERY member; from
+// one host thread that is n x (hipSetDevice + ~10 enqueues), ~0.1 ms each, one after the other -- at 8 members longer than a
+// member's 32 MiB copy takes over its own PCIe link.  The workers are persistent, sleep between buffers and run the same
+// octpipe_* calls the single-threaded path makes, each for its own handle (a handle is only ever touched by one thread at a
+// time: the caller blocks until all workers are done).
+class MemberWorkers {
+public:
+	explicit MemberWorkers(size_t n) : jobs_(n), rc_(n, 0), err_(n) {
+		for (size_t i = 0; i < n; ++i) threads_.emplace_back([this, i] { run(i); });
+	}
+	~MemberWorkers() {
+		{ std::lock_guard<std::mutex> l(m_); quit_ = true; ++gen_; }
+		wake_.notify_all();
+		for (auto& t : threads_) t.join();
+	}
+	// runs f(i) for every i with active[i] on worker i; returns the first failing member's code (its message in *err)
+	int run_all(const std::vector<char>& active, const std::function<int(size_t)>& f, std::string* err) {
+		{
+			std::lock_guard<std::mutex> l(m_);
+			fn_ = &f;
+			pending_ = 0;
+			for (size_t i = 0; i < jobs_.size(); ++i) { jobs_[i] = active[i]; if (active[i]) ++pending_; }
+			if (pending_ == 0) return OCTPIPE_OK;
+			++gen_;
+		}
+		wake_.notify_all();
+		std::unique_lock<std::mutex> l(m_);
+		done_.wait(l, [this] { return pending_ == 0; });
+		for (size_t i = 0; i < rc_.size(); ++i)
+			if (active[i] && rc_[i]) { if (err) *err = err_[i]; return rc_[i]; }
+		return OCTPIPE_OK;
+	}
+
+private:
+	void run(size_t i) {
+		uint64_t seen = 0;
+		for (;;) {
+			const std::function<int(size_t)>* f = nullptr;
+			{
+				std::unique_lock<std::mutex> l(m_);
+				wake_.wait(l, [&] { return gen_ != seen; });
+				seen = gen_;
+				if (quit_) return;
+				if (!jobs_[i]) continue;
+				f = fn_;
+			}
+			const int rc = (*f)(i);
+			std::lock_guard<std::mutex> l(m_);
+			rc_[i] = rc;
+			if (rc) err_[i] = octpipe_last_error();  // the message lives in this thread's storage
+			if (--pending_ == 0) done_.notify_all();
+		}
+	}
+	std::vector<std::thread> threads_;
+	std::mutex m_;
+	std::condition_variable wake_, done_;
+	std::vector<char> jobs_;
+	std::vector<int> rc_;
+	std::vector<std::string> err_;
+	const std::function<int(size_t)>* fn_ = nullptr;
+	uint64_t gen_ = 0;
+	size_t pending_ = 0;
+	bool quit_ = false;
+};
+
+// NUMA node of a HIP device (sysfs entry of its PCI function), -1 when unknown
+int deviceNumaNode(int device) {
+	char bdf[64] = {0};
+	if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return -1;
+	for (char* c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+	const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+	FILE* f = fopen(path.c_str(), "r");
+	if (!f) return -1;
+	int node = -1;
+	if (fscanf(f, "%d", &node) != 1) node = -1;
+	fclose(f);
+	return node;
+}
+// best effort: move the pages of [p, p + bytes) to `node` and prefer it from now on (mbind with MPOL_MF_MOVE; no libnuma needed)
+bool placeOnNode(void* p, size_t bytes, int node) {
+	if (node < 0 || node >= 64 || bytes == 0) return false;
+	const long page = sysconf(_SC_PAGESIZE);
+	const uintptr_t lo = ((uintptr_t)p + (uintptr_t)page - 1) & ~((uintptr_t)page - 1), hi = ((uintptr_t)p + bytes) & ~((uintptr_t)page - 1);
+	if (hi <= lo) return false;
+	unsigned long mask = 1ul << node;
+	const int MPOL_PREFERRED_ = 1, MPOL_MF_MOVE_ = 2;
+#ifdef SYS_mbind
+	return syscall(SYS_mbind, (void*)lo, (unsigned long)(hi - lo), MPOL_PREFERRED_, &mask, (unsigned long)(sizeof(mask) * 8), (unsigned)MPOL_MF_MOVE_) == 0;
+#else
+	(void)mask; (void)MPOL_PREFERRED_; (void)MPOL_MF_MOVE_;
+	return false;
+#endif
+}
+
 }  // namespace
 
 struct octpipe_group {
+	MemberWorkers* workers = nullptr;    // one submitting thread per member (distinct devices, or when asked for)
+	int numaPlaced = 0;                  // member slabs of the ring slots that could be moved next to their GPU
 	std::vector<int> devices;
 	std::vector<octpipe_t*> members;
 	std::vector<unsigned> first, count;  // B-scan slab of every member
@@ -134,6 +237,21 @@ int forMembers(octpipe_group* g, F f) {
 		if (g->members[i]) { const int rc = f(i, g->members[i]); if (rc) return gfail(rc, octpipe_last_error()); }
 	return OCTPIPE_OK;
 }
+// the same over members first..n-1, each on its own submitting thread when the group has them
+template <typename F>
+int forMembersParallel(octpipe_group* g, size_t first, F f) {
+	if (!g->workers) {
+		for (size_t i = first; i < g->members.size(); ++i)
+			if (g->members[i]) { const int rc = f(i, g->members[i]); if (rc) return gfail(rc, octpipe_last_error()); }
+		return OCTPIPE_OK;
+	}
+	std::vector<char> active(g->members.size(), 0);
+	for (size_t i = first; i < g->members.size(); ++i) active[i] = g->members[i] ? 1 : 0;
+	const std::function<int(size_t)> job = [&](size_t i) { return f(i, g->members[i]); };
+	std::string err;
+	const int rc = g->workers->run_all(active, job, &err);
+	return rc ? gfail(rc, err) : OCTPIPE_OK;
+}
 
 int processCommon(octpipe_group* g, const void* h_buffer, const void* const* d_slabs) {
 	auto enqueue = [&](size_t i, octpipe_t* m) -> int {
@@ -150,13 +268,12 @@ int processCommon(octpipe_group* g, const void* h_buffer, const void* const* d_s
 		if (g->params.fixedPatternNoiseRemoval) g->fpnKnown = true;
 		g->params.redetermineFixedPatternNoise = 0;
 		g->params.postProcessBackgroundRecordingRequested = 0;
-		for (size_t i = 1; i < g->members.size(); ++i)
-			if (g->members[i] && (rc = enqueue(i, g->members[i]))) return gfail(rc, octpipe_last_error());
+		if ((rc = forMembersParallel(g, 1, enqueue))) return rc;
 	} else {
-		int rc = forMembers(g, enqueue);
+		int rc = forMembersParallel(g, 0, enqueue);
 		if (rc) return rc;
 	}
-	if (h_buffer) return forMembers(g, [](size_t, octpipe_t* m) { return octpipe_wait_input(m); });
+	if (h_buffer) return forMembersParallel(g, 0, [](size_t, octpipe_t* m) { return octpipe_wait_input(m); });
 	return OCTPIPE_OK;
 }
 
@@ -195,10 +312,15 @@ int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const
 	octpipe_raw_buffer_bytes(g->members[0], &raw0);
 	g->bytesPerBscan = raw0 / g->count[0];
 	g->outPerBscan = (size_t)(acq->samplesPerLine / 2) * acq->ascansPerBscan;
-	// ring slots: pinned once, portable across the members' devices (cu:1135-1136)
+	// ring slots: every member's slab is moved next to its GPU (the pages of a slab are only ever read by that GPU's DMA
+	// engine; on a two-socket node half of the GPUs hang off the other socket), then pinned once, portable across the
+	// members' devices (cu:1135-1136)
 	void* hb[2] = {h_buffer1, h_buffer2};
 	for (int k = 0; k < 2; ++k)
 		if (hb[k]) {
+			for (int i = 0; i < n; ++i)
+				if (g->members[i] && placeOnNode(static_cast<char*>(hb[k]) + (size_t)g->first[i] * g->bytesPerBscan, (size_t)g->count[i] * g->bytesPerBscan, deviceNumaNode(devices[i])))
+					g->numaPlaced++;
 			if (hipSetDevice(devices[0]) != hipSuccess || hipHostRegister(hb[k], g->bytesPerBscan * acq->bscansPerBuffer, hipHostRegisterPortable) != hipSuccess)
 				return gfail(OCTPIPE_ERR_DEVICE, "pinning the ring slots failed");
 			g->pinned[k] = hb[k];
@@ -207,6 +329,7 @@ int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const
 	bool distinct = n > 0;
 	for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (devices[i] == devices[j]) distinct = false;
 	for (int i = 0; i < n; ++i) if (!g->members[i]) distinct = false;
+	if (distinct && n > 1) g->workers = new MemberWorkers((size_t)n);
 	if (distinct && loadRccl(&g->rccl)) {
 		g->comms.assign((size_t)n, nullptr);
 		const int e = g->rccl.CommInitAll(g->comms.data(), n, devices);
@@ -238,6 +361,8 @@ int octpipe_group_destroy(octpipe_group_t* g) {
 			if (g->comms[i]) g->rccl.CommDestroy(g->comms[i]);
 		}
 	}
+	delete g->workers;
+	g->workers = nullptr;
 	for (int k = 0; k < 2; ++k) if (g->pinned[k]) hipHostUnregister(g->pinned[k]);
 	for (octpipe_t* m : g->members) octpipe_destroy(m);
 	delete g;
@@ -248,6 +373,21 @@ int octpipe_group_size(const octpipe_group_t* g) { return g ? (int)g->members.si
 octpipe_t* octpipe_group_member(octpipe_group_t* g, int i) { return (g && i >= 0 && i < (int)g->members.size()) ? g->members[i] : nullptr; }
 const char* octpipe_group_backend(const octpipe_group_t* g) { return !g ? "" : (g->useRccl ? "rccl" : "copy"); }
 uint64_t octpipe_group_broadcast_count(const octpipe_group_t* g) { return g ? g->broadcasts : 0; }
+
+int octpipe_group_set_submit_threads(octpipe_group_t* g, int enable) {
+	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
+	int rc = octpipe_group_synchronize(g);
+	if (rc) return rc;
+	if (enable && !g->workers) g->workers = new MemberWorkers(g->members.size());
+	if (!enable && g->workers) { delete g->workers; g->workers = nullptr; }
+	return OCTPIPE_OK;
+}
+int octpipe_group_info(const octpipe_group_t* g, int* submitThreads, int* slabsPlacedOnGpuNode) {
+	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
+	if (submitThreads) *submitThreads = g->workers ? (int)g->members.size() : 0;
+	if (slabsPlacedOnGpuNode) *slabsPlacedOnGpuNode = g->numaPlaced;
+	return OCTPIPE_OK;
+}
 
 int octpipe_group_slab(const octpipe_group_t* g, int i, unsigned* firstBscan, unsigned* bscanCount) {
 	if (!g || i < 0 || i >= (int)g->members.size()) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "member index out of range");

@@ -299,6 +299,16 @@ class PipelineGroup:
     def size(self):
         return self._lib.octpipe_group_size(self._g)
 
+    def set_submit_threads(self, enable=True):
+        """one submitting host thread per member (default: on when the members sit on distinct devices)"""
+        self._check(self._lib.octpipe_group_set_submit_threads(self._g, 1 if enable else 0))
+
+    @property
+    def info(self):
+        t, n = C.c_int(), C.c_int()
+        self._check(self._lib.octpipe_group_info(self._g, C.byref(t), C.byref(n)))
+        return {"submit_threads": t.value, "slabs_placed_on_gpu_node": n.value}
+
     def slab(self, i):
         f, n = C.c_uint(), C.c_uint()
         self._check(self._lib.octpipe_group_slab(self._g, i, C.byref(f), C.byref(n)))

@@ -85,3 +85,12 @@ def test_gpus_flag_launches_rank_processes_on_the_gpu_box():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2
     assert d["config"]["parallelism"] == "bscan-slab x2"
     assert d["value"] > 1e6
+
+
+@pytest.mark.gpu
+def test_group_mode_measures_the_native_multi_gpu_path():
+    """`--group --gpus 4` on a one-GPU box: ONE process, four members on device 0 behind octpipe_group_* with one submitting
+    thread per member; same JSON contract"""
+    d = _run(["--group", "--gpus", "4", "--steps", "6", "--warmup", "2", "--warmup-seconds", "0.2", "--bscans", "16"], timeout=900)
+    assert d["n_gpus"] == 4 and d["value"] > 1e6
+    assert d["group"]["submit_threads"] == 4 and d["group"]["broadcasts"] == 1

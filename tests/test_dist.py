@@ -108,3 +108,19 @@ def test_sharding_restrictions_are_reported_and_empty_slabs_possible():
     p.bscansForNoiseDetermination = 3
     assert len(odist.check_sharding_exact(p, slab_bscans=2)) == 3
     assert odist.slab_bounds(2, 4) == [(0, 2), (2, 0), (2, 0), (2, 0)]  # ranks 1..3 own nothing and must skip octpipe_create
+
+
+def test_config4_slabs_on_eight_gpus():
+    """BASELINE config 4: 1024 x 512 x 2048 over 8 GPUs = eight slabs of 256 B-scans, i.e. one config-2 buffer per GPU"""
+    from octproz_amd.dist import slab_bounds
+    assert slab_bounds(2048, 8) == [(256 * r, 256) for r in range(8)]
+    # ragged cases keep every slab on an even B-scan and cover the volume exactly once
+    for total, world in [(2048, 3), (2050, 8), (255, 8), (2, 8), (1, 2)]:
+        sl = slab_bounds(total, world)
+        assert len(sl) == world and sum(n for _, n in sl) == total
+        assert all(f % 2 == 0 for f, n in sl if n)
+        pos = 0
+        for f, n in sl:
+            if n:
+                assert f == pos
+                pos += n

@@ -110,3 +110,35 @@ def test_processing_loop_over_a_group():
     assert stats.buffersProcessed == 2 * n + 1
     assert np.array_equal(g.processed_host().view(np.uint32), want[(2 * n) % n].view(np.uint32))
     g.close(); system.close()
+
+
+@pytest.mark.parametrize("members,B", [(2, 8), (4, 12), (8, 32)])
+def test_group_with_one_submitting_thread_per_member(members, B):
+    """the per-member submit threads (default on distinct devices) forced on for members that share device 0: same output bit
+    for bit, through the host-buffer entry point (H2D per member) and the host loop, with ring slots handed to the group
+    (pinned, slabs placed next to their GPU where the host allows it)"""
+    N, A = 1024, 64
+    p = v180_benchmark_params(N, A, B)
+    p.bscanFlip = 1
+    raws = [synthetic_raw(N, A, B, seed=180 + i) for i in range(4)]
+    want, _ = _single(p, raws)
+    system = VirtualOCTSystem(12, N, A, B, data=np.concatenate([r.reshape(-1) for r in raws]), buffers_from_file=4,
+                              copy_file_to_ram=True, sync_with_processing=True)
+    system.startAcquisition()
+    ring = system.buffer
+    g = PipelineGroup(p, [0] * members, ring.slot(0, np.uint16), ring.slot(1, np.uint16))
+    assert g.info["submit_threads"] == 0  # members share a device: the caller's thread submits unless asked otherwise
+    g.set_submit_threads(True)
+    assert g.info["submit_threads"] == members
+    for k, r in enumerate(raws):
+        g.octCudaPipeline(r)
+        g.synchronize()
+        assert np.array_equal(g.processed_host().view(np.uint32), want[k].view(np.uint32)), "buffer %d" % k
+    stats = system.run_group(g, max_buffers=8)
+    system.stopAcquisition()
+    assert stats.buffersProcessed == 8
+    assert any(np.array_equal(g.processed_host().view(np.uint32), w.view(np.uint32)) for w in want)
+    g.set_submit_threads(False)
+    g.octCudaPipeline(raws[0]); g.synchronize()
+    assert np.array_equal(g.processed_host().view(np.uint32), want[0].view(np.uint32))
+    g.close(); system.close()

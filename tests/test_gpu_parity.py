@@ -417,6 +417,51 @@ def test_mixed_radix_1664_agrees_with_the_bluestein_route():
     pipe.close(); blue.close(); o.close()
 
 
+@pytest.mark.parametrize("variant", ["v180", "no_dispersion_flip", "rolling8", "lin_bitshift", "bg"])
+@pytest.mark.parametrize("A,B", [(24, 3), (5, 1)])
+def test_lanczos_on_the_mixed_radix_kernel_of_1664(variant, A, B):
+    """Lanczos resampling (cu:297-326) at the recording's native length runs on the mixed-radix kernel: rows with their 8-sample
+    halos straight from the buffer (taps cross line borders; line 0 reads 8 samples late, cu:313-314; the last line is clamped
+    at S - 9), tap weights from the host's table.  Against the oracle, and against the Bluestein route of the same settings
+    (OCTPIPE_ROUTE_NO_MIXED), which evaluates the weights with sinf in the kernel: really different code."""
+    N = 1664
+    p = v180_benchmark_params(N, A, B)
+    p.resamplingInterpolation = INTERPOLATION.LANCZOS
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    {"v180": mutate(), "no_dispersion_flip": mutate(dispersionCompensation=0, bscanFlip=1),
+     "rolling8": mutate(backgroundRemoval=1, rollingAverageWindowSize=8),
+     "lin_bitshift": mutate(signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0, bitshift=1),
+     "bg": mutate(postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.7, postProcessBackgroundOffset=0.02,
+                  signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0
+    if p.postProcessBackgroundRemoval:
+        p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=A + len(variant), msb_aligned=bool(p.bitshift))
+    o, pipe, d, want, got = run_both(p, raw)
+    p.postProcessBackgroundUpdated = True
+    blue = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXED | _lib.ROUTE_NO_LIBFFT)
+    if p.fixedPatternNoiseRemoval:
+        blue.set_mean_line(o.mean_line(), pin=True)
+    blue.process_device(d.data_ptr()); blue.synchronize()
+    ref = blue.processed_host()
+    if p.postProcessBackgroundRemoval:
+        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3 and 0.0 <= got.min() and got.max() <= 1.0
+    else:
+        common.compare_images(got, want, p, "mixed-radix Lanczos %s" % variant)
+        common.compare_images(ref, want, p, "Bluestein Lanczos %s" % variant)
+        common.compare_images(got, ref, p, "mixed-radix vs Bluestein %s" % variant)
+        if not p.bscanFlip:
+            spec = pipe.debug_spectrum(d.data_ptr(), A * B)
+            ospec = o.last_spectrum().reshape(-1, N).copy()
+            if p.fixedPatternNoiseRemoval:
+                ospec[:, :N // 2] += o.mean_line()[:N // 2]
+            common.compare_spectra(spec, ospec, N, variant)
+    assert not np.array_equal(got, ref)
+    pipe.close(); blue.close(); o.close()
+
+
 @pytest.mark.parametrize("N", [512, 1024, 2048, 1664])
 def test_real_input_route_agrees_with_the_complex_route(N):
     """dispersion compensation off: the two-A-scans-per-transform kernels and the general kernel of the length
