@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")
 
 OCTPIPE_OK = 0
 # OCTPIPE_ROUTE_* (include/octpipe.h, octpipe_debug_set_route): keep a configuration on the slower / more general of two routes
-ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED = 1, 2, 4, 16, 32, 64
+ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED = 1, 2, 4, 8, 16, 32, 64
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE"}
 
 

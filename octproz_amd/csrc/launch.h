@@ -62,6 +62,28 @@ OCT_DECL_LAUNCH(12)
 // input, two A-scans per complex transform (real2_kernel.h)
 hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 
+// N = 4096 / uint16 / image output (rs = RS_NONE, RS_LINEAR or RS_CUBIC): one A-scan per team of four waves, lane-invariant tables
+// in registers (team_kernel.h); FusedArgs::twiddle = the table of its 16 x 16 x R3 plan: [t-1][k] of pass 2 (15 x 16), then of
+// pass 3 ((R3 - 1) x 256, angle 2 pi t k / N)
+bool team_supported(int log2n);
+int team_twiddle_count(int log2n);
+int team_last_radix(int log2n);
+hipError_t launch_team_in0(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);  // one translation unit per
+hipError_t launch_team_in1(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);  // raw container (IN_*)
+hipError_t launch_team_in4(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
+hipError_t launch_team_in5(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
+hipError_t launch_team_in6(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
+inline hipError_t launch_team(int log2n, int intype, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	switch (intype) {
+	case IN_U8: return launch_team_in0(log2n, rs, logScale, a, stream);
+	case IN_U16: return launch_team_in1(log2n, rs, logScale, a, stream);
+	case IN_P12U: return launch_team_in4(log2n, rs, logScale, a, stream);
+	case IN_P12S: return launch_team_in5(log2n, rs, logScale, a, stream);
+	case IN_I16: return launch_team_in6(log2n, rs, logScale, a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
 // the other lengths with a real-input kernel (real2n_kernel.h)
 inline bool real2n_supported(int log2n) { return log2n == 8 || log2n == 9 || log2n == 11; }
 hipError_t launch_real2n(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);

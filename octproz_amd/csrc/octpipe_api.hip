@@ -106,6 +106,7 @@ struct octpipe {
 	float* d_lanczosW = nullptr;   // [N][16] Lanczos tap weights (uploaded with the LUT while that interpolation is selected)
 	float4* d_lutPlain = nullptr;  // mixed: the LUT without the Bluestein chirp folded in
 	f2* d_twMixed = nullptr;       // mixed: W_1664^{n2 k1}, [32][52]
+	f2* d_twTeam = nullptr;        // N = 4096: twiddles of the 16 x 16 x 16 plan of the one-A-scan-per-team kernel (team_kernel.h)
 	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
 	f2* d_filter = nullptr;    // [M] Bluestein filter spectrum
 	f2* d_outChirp = nullptr;  // [N] c[k] / M
@@ -328,6 +329,22 @@ int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, boo
 	return OCTPIPE_OK;
 }
 
+// twiddles of the one-A-scan-per-team kernel (plan 16 x 16 x R3): [t-1][k] = e^{+2 pi i t k / (NS R)} per pass
+int uploadTeamTables(octpipe* h) {
+	std::vector<f2> tw((size_t)oct::team_twiddle_count(h->log2n));
+	size_t pos = 0;
+	const int radix[2] = {16, oct::team_last_radix(h->log2n)}, ns[2] = {16, 256};
+	for (int pass = 0; pass < 2; ++pass)
+		for (int t = 1; t < radix[pass]; ++t)
+			for (int k = 0; k < ns[pass]; ++k) {
+				const double ang = 2.0 * 3.14159265358979323846 * (double)t * (double)k / ((double)ns[pass] * radix[pass]);
+				tw[pos++] = f2{(float)cos(ang), (float)sin(ang)};
+			}
+	HIP_TRY(hipMalloc((void**)&h->d_twTeam, sizeof(f2) * tw.size()));
+	HIP_TRY(hipMemcpy(h->d_twTeam, tw.data(), sizeof(f2) * tw.size(), hipMemcpyHostToDevice));
+	return OCTPIPE_OK;
+}
+
 // twiddles between the 32-point and the 52-point stage of the N = 1664 plan: W^{n2 k1}, W = e^{+2 pi i / 1664}, as [k1][n2]
 int uploadMixedTables(octpipe* h) {
 	const int N = 1664, N1 = 32, N2 = 52;
@@ -488,6 +505,12 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		b.sA = a.sA;
 		b.sB = a.sB;
 		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
+	} else if (h->d_twTeam && intype != oct::IN_F32 && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
+	           !(h->route & OCTPIPE_ROUTE_NO_TEAM) && (p.dispersionCompensation || intype != oct::IN_U16 || !oct::real2n_supported(h->log2n))) {
+		// N = 4096: one A-scan per team of four waves, lane-invariant tables in registers (team_kernel.h); every raw container
+		// the general kernel reads directly (uint16, int16, uint8, packed 12 bit)
+		a.twiddle = h->d_twTeam;
+		HIP_TRY(oct::launch_team(h->log2n, intype, rs, p.signalLogScaling != 0, a, h->stream));
 	} else if ((h->log2n == 10 || oct::real2n_supported(h->log2n)) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
 	           !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
 		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
@@ -892,6 +915,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	else if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
 	if (h->mixed && (rc = uploadMixedTables(h))) return rc;
+	if (!h->libfft && !h->bluestein && oct::team_supported(h->log2n) && (rc = uploadTeamTables(h))) return rc;
 	{  // cu:1093
 		std::vector<float> sc((size_t)h->A);
 		octhost::sinusoidal_curve((unsigned)h->A, sc.data());
@@ -930,7 +954,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_processedAlt, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_lanczosW};
+	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW};
 	for (void* b : bufs) if (b) hipFree(b);
 	if (h->copyStream) hipStreamDestroy(h->copyStream);
 	if (h->outStream) hipStreamDestroy(h->outStream);

@@ -1,0 +1,69 @@
+// team_inst.hip -- instantiates the one-A-scan-per-team kernel (team_kernel.h) for ONE raw sample container (-DOCT_TEAM_INTYPE=
+// IN_U16 1, IN_P12U 4, IN_P12S 5, IN_I16 6, IN_U8 0: one translation unit each so that they build in parallel): N = 4096 in the
+// product; N = 2048 as well when built with -DOCT_TEAM11=1 (round-3 experiment, slower than the one-wave kernel there)
+#include "launch.h"
+#include "team_kernel.h"
+
+#ifndef OCT_TEAM_INTYPE
+#error "compile with -DOCT_TEAM_INTYPE=<0|1|4|5|6>"
+#endif
+
+namespace oct {
+
+namespace {
+constexpr int kIn = OCT_TEAM_INTYPE;
+template <int LOG2N, int RS, int MODE>
+hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
+	auto kernel = oct_team_kernel<LOG2N, kIn, RS, MODE>;
+	constexpr size_t lds = team_lds_bytes<LOG2N, MODE>();
+	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
+	KernelLaunchInfo info;
+	hipError_t e = kernel_launch_info(kernel, Team<LOG2N>::LANES, lds, &info);
+	if (e != hipSuccess) return e;
+	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);  // persistent teams: 256 VGPRs per lane -> 8 waves per CU
+	if (blocks > a.numLines) blocks = a.numLines;
+	if (blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(Team<LOG2N>::LANES), lds, stream, a);
+	return hipGetLastError();
+}
+template <int LOG2N, int RS>
+hipError_t launch_team_mode(bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (a.bgTerm) {  // post-process background removal inside the image store: plain uint16 rows, like the general kernel
+		if constexpr (kIn == IN_U16) return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_BG>(a, stream) : launch_team_one<LOG2N, RS, MODE_BG>(a, stream);
+		else return hipErrorInvalidValue;
+	}
+	return logScale ? launch_team_one<LOG2N, RS, MODE_LOG>(a, stream) : launch_team_one<LOG2N, RS, 0>(a, stream);
+}
+template <int LOG2N>
+hipError_t launch_team_rs(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	switch (rs) {
+	case RS_NONE: return launch_team_mode<LOG2N, RS_NONE>(logScale, a, stream);
+	case RS_LINEAR: return launch_team_mode<LOG2N, RS_LINEAR>(logScale, a, stream);
+	case RS_CUBIC: return launch_team_mode<LOG2N, RS_CUBIC>(logScale, a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+}  // namespace
+
+#define OCT_CAT2(a, b) a##b
+#define OCT_CAT(a, b) OCT_CAT2(a, b)
+hipError_t OCT_CAT(launch_team_in, OCT_TEAM_INTYPE)(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+#if defined(OCT_TEAM11) && OCT_TEAM11
+	if (log2n == 11) return launch_team_rs<11>(rs, logScale, a, stream);
+#endif
+	if (log2n == 12) return launch_team_rs<12>(rs, logScale, a, stream);
+	return hipErrorNotSupported;
+}
+
+#if OCT_TEAM_INTYPE == 1
+bool team_supported(int log2n) {
+#if defined(OCT_TEAM11) && OCT_TEAM11
+	if (log2n == 11) return true;
+#endif
+	return log2n == 12;
+}
+int team_twiddle_count(int log2n) { return log2n == 11 ? Team<11>::TW_COUNT : Team<12>::TW_COUNT; }
+int team_last_radix(int log2n) { return log2n == 11 ? Team<11>::R3 : Team<12>::R3; }
+#endif
+
+}  // namespace oct

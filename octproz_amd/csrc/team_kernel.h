@@ -1,0 +1,203 @@
+// team_kernel.h -- one A-scan per TEAM of waves: N / 16 lanes x 16 points (N = 4096: four waves; N = 2048: two, experiment only).
+//
+// The general kernel gives a wave64 a whole A-scan.  At N = 4096 that is 64 points per lane: nothing lane-invariant fits in
+// registers next to the data, the slice of a wave leaves room for 6 waves per CU, the resampling / window / phasor LUT does not
+// fit the LDS at all and is read through L2 for every A-scan (64 KiB of L2 traffic per 16 KiB of HBM traffic), and the cubic
+// interpolation is evaluated as a polynomial per sample: 3 007 VALU + 306 LDS + 112 vector-memory instructions per A-scan,
+// 77 M A-scans/s (0.16 of the HBM roofline).  Here a workgroup of N / 16 lanes shares an A-scan with the register budget of the
+// N = 1024 kernel: four Catmull-Rom tap weights per sample, window x phasor, the twiddles of both later passes, tap addresses
+// and the lane's mean-line bins live in VGPRs for the whole persistent loop.  LDS holds the staged row and ONE exchange buffer;
+// the two exchanges of the 16 x 16 x (N / 256) transform cross the waves of the team and are fenced with s_barrier (four per
+// A-scan: row staged / first exchange written / first exchange read by everyone / second exchange written).  Two teams per CU
+// at N = 4096 (two waves per SIMD), persistent.
+//
+//   Stockham, strided mapping with T = N / 16 butterflies per pass, element e of the exchange buffer at e + (e >> 4):
+//     pass 1  butterfly b = L:                 inputs L + T t (the gather's order), outputs 16 L + u
+//     pass 2  butterfly b = L:                 inputs L + T t, twiddle e^{+2 pi i t (L & 15) / 256}, outputs 256 (L >> 4) + (L & 15) + 16 u
+//     pass 3  butterflies b = L + T m < 256:   inputs b + 256 t, twiddle e^{+2 pi i t b / N}, bins b + 256 u, u < R3 / 2 kept (R3 = N / 256)
+// Arithmetic per stage is the general kernel's (same gather expressions, same butterflies, same epilogue).
+//
+// N = 2048 through this kernel (two waves per team; -DOCT_TEAM11=1) was measured in round 3 and is 4 % SLOWER than the
+// one-wave kernel of that length (profiles/r3g_wave2_ab.txt): two LDS round trips per wave iteration at two waves per SIMD
+// leave the SIMD idle ~25 % of the time, which the one-wave kernel's longer instruction stream hides.  At N = 4096 the
+// one-wave kernel has no such stream to hide behind (it is latency-bound on its L2 reads), and the team wins.
+#pragma once
+#include "kernels.h"
+
+namespace oct {
+
+template <int LOG2N> struct Team {
+	static_assert(LOG2N == 11 || LOG2N == 12, "N / 16 lanes per A-scan: two or four waves");
+	static constexpr int N = 1 << LOG2N, P = 16, LANES = N / 16, R3 = N / 256, NB3 = 16 / R3;
+	static constexpr int ROW_BYTES = ((N + 2 * ROW_OFF) * 4 + 15) & ~15;
+	static constexpr int X_BYTES = (N + N / 16) * 8;
+	static constexpr int PITCH = LANES + LANES / 16;  // strided read: element L + LANES q at rb[PITCH q]
+	// twiddle table of this plan in FusedArgs::twiddle: [t-1][k] for pass 2 (15 x 16), then [t-1][k] for pass 3 ((R3 - 1) x 256)
+	static constexpr int TW_PASS3 = 15 * 16, TW_COUNT = 15 * 16 + (R3 - 1) * 256;
+};
+template <int LOG2N, int MODE> constexpr int team_lds_bytes() { return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>(); }
+
+// LDS traffic of the team's waves is ordered by s_barrier; only the LDS counter is drained in front of it (a __syncthreads()
+// would also wait for the row prefetch and the image stores in flight)
+OCT_DEV void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// INTYPE: the raw containers the general kernel reads directly (IN_U16, IN_I16, IN_U8, IN_P12U, IN_P12S: kernels.h Chunk)
+template <int LOG2N, int INTYPE, int RS, int MODE>
+__global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const FusedArgs a) {
+	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
+	static_assert(INTYPE == IN_U16 || INTYPE == IN_I16 || INTYPE == IN_U8 || INTYPE == IN_P12U || INTYPE == IN_P12S, "raw rows");
+	typedef Team<LOG2N> TM;
+	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3, NB3 = TM::NB3, NBINS = NB3 * R3 / 2;
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float* row = reinterpret_cast<float*>(smem);
+	f2* xbuf = reinterpret_cast<f2*>(smem + TM::ROW_BYTES);
+	const float* termL = reinterpret_cast<const float*>(smem + TM::ROW_BYTES + TM::X_BYTES);
+	const int L = threadIdx.x;  // 0 .. T-1: "lane" of the team
+	if constexpr (BG) {
+		fill_bg_term(reinterpret_cast<float*>(smem + TM::ROW_BYTES + TM::X_BYTES), a.bgTerm, N / 2, L, T);
+		__syncthreads();
+	}
+
+	// ---- loop invariants of the lane
+	typedef __attribute__((address_space(3))) const float lds_cfloat;
+	const uint32_t tapBase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
+	f32x4 cwR[RS == RS_CUBIC ? P : 1];
+	f2 wphR[P];
+	float fracR[RS == RS_LINEAR ? P : 1];
+	uint32_t tapA[RS == RS_NONE ? 1 : P];
+#pragma unroll
+	for (int q = 0; q < P; q++) {
+		const float4 t = a.lut[L + T * q];   // {rho, window, phasor.x, phasor.y} of sample L + T q
+		wphR[q] = f2{t.y * t.z, t.y * t.w};  // window folded into the phasor like the general kernel
+		if constexpr (RS == RS_CUBIC) {
+			// cu:258-271 as weights of the four taps (kernels.h): evaluated once per lane in double, w1 = 1 - w0 - w2 - w3
+			const double p = (double)__builtin_amdgcn_fractf(t.x);
+			const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+			cwR[q] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+			tapA[q] = tapBase + 4u * (uint32_t)(int)t.x;  // tap 0 = sample n1 - 1
+		} else if constexpr (RS == RS_LINEAR) {
+			fracR[q] = __builtin_amdgcn_fractf(t.x);
+			tapA[q] = tapBase + 4u * (uint32_t)(int)t.x + 4u;  // sample n1
+		}
+	}
+	f2 tw2[15], tw3[NB3 * (R3 - 1)];
+#pragma unroll
+	for (int t = 1; t < 16; t++) tw2[t - 1] = a.twiddle[(t - 1) * 16 + (L & 15)];
+#pragma unroll
+	for (int m = 0; m < NB3; m++)
+#pragma unroll
+		for (int t = 1; t < R3; t++) tw3[m * (R3 - 1) + t - 1] = a.twiddle[TM::TW_PASS3 + (t - 1) * 256 + L + T * m];
+	f2 mreg[NBINS];  // the lane finishes the same bins of every A-scan: bin L + T m + 256 u in mreg[m + NB3 u]
+#pragma unroll
+	for (int u = 0; u < R3 / 2; u++)
+#pragma unroll
+		for (int m = 0; m < NB3; m++) mreg[m + NB3 * u] = a.subtractMean ? a.meanLine[L + T * m + 256 * u] : f2{0.0f, 0.0f};
+
+	typedef Chunk<INTYPE, N> CH;
+	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (T * SPL);  // chunk = SPL consecutive samples in CB bytes; NL chunks per lane and row
+	static_assert(NL * T * SPL == N, "whole chunks per lane");
+	const unsigned rowBytes = (unsigned)(N / SPL) * CB;
+	const uint32_t shift = a.bitshift ? 4u : 0u;
+	unsigned line = blockIdx.x;
+	u32x4 pre[NL];  // the lane's share of a raw row: samples SPL (T i + L) .. + SPL - 1
+	if (line < a.numLines) {
+		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
+#pragma unroll
+		for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, L * CB, i * T * CB);
+	}
+	const f2* rb = xbuf + (L + (L >> 4));                  // strided read: element L + T q at rb[PITCH q]
+	f2* wb1 = xbuf + 17 * L;                               // pass 1 output 16 L + u at wb1[u]
+	f2* wb2 = xbuf + (272 * (L >> 4) + (L & 15));          // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[17 u]
+
+	for (; line < a.numLines; line += gridDim.x) {
+		// ---- stage the raw row as float32 (cu:119-121 / 139-141)
+#pragma unroll
+		for (int i = 0; i < NL; i++) {
+#pragma unroll
+			for (int h = 0; h < SPL / 4; h++) {
+				const float4 f = chunk_to_float<INTYPE>(pre[i], h, shift);
+				*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * (L + T * i) + 4 * h]) = f;
+				if constexpr (RS == RS_CUBIC) {
+					if (i == 0 && h == 0 && L == 0) row[ROW_OFF - 1] = f.y;  // n0 = |n1 - 1| mirror tap (cu:284): sample 1 below sample 0
+				}
+			}
+		}
+		const unsigned next = line + gridDim.x;
+		if (next < a.numLines) {
+			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
+#pragma unroll
+			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, L * CB, i * T * CB);
+		}
+		team_barrier();  // the row is complete
+
+		// ---- k-linearisation x window x dispersion phasor
+		__builtin_amdgcn_s_setprio(3);
+		f2 v[P];
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+			float y;
+			if constexpr (RS == RS_CUBIC) {
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
+				const f32x4 cw = cwR[q];
+				y = __builtin_fmaf(cw.w, t[3], __builtin_fmaf(cw.z, t[2], __builtin_fmaf(cw.y, t[1], cw.x * t[0])));
+			} else if constexpr (RS == RS_LINEAR) {
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
+				y = t[0] + (t[1] - t[0]) * fracR[q];  // cu:225-228
+			} else {
+				y = row[ROW_OFF + L + T * q];
+			}
+			v[q] = wphR[q] * y;
+		}
+
+		// ---- inverse FFT, 16 x 16 x R3
+		__builtin_amdgcn_s_setprio(2);
+		octfft::Dft<16, 1, false>::run(&v[0]);
+#pragma unroll
+		for (int u = 0; u < 16; u++) wb1[u] = v[u];
+		team_barrier();  // first exchange written (and every lane is past its gather: the row may be overwritten)
+#pragma unroll
+		for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+#pragma unroll
+		for (int t = 1; t < 16; t++) v[t] = octfft::cmul(v[t], tw2[t - 1]);
+		octfft::Dft<16, 1, false>::run(&v[0]);
+		team_barrier();  // everyone has read the first exchange
+#pragma unroll
+		for (int u = 0; u < 16; u++) wb2[17 * u] = v[u];
+		team_barrier();  // second exchange written
+#pragma unroll
+		for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+		// element L + T q = b + 256 t with b = L + T m: q = m + NB3 t
+#pragma unroll
+		for (int m = 0; m < NB3; m++)
+#pragma unroll
+			for (int t = 1; t < R3; t++) v[m + NB3 * t] = octfft::cmul(v[m + NB3 * t], tw3[m * (R3 - 1) + t - 1]);
+#pragma unroll
+		for (int m = 0; m < NB3; m++) octfft::Dft<R3, NB3, true>::run(&v[m]);
+		__builtin_amdgcn_s_setprio(1);
+
+		// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address (as in the general kernel)
+		unsigned orow = line;
+		if (a.flip) {
+			const unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
+			if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
+		}
+		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
+#pragma unroll
+		for (int u = 0; u < R3 / 2; u++) {
+			float o[NB3];
+#pragma unroll
+			for (int m = 0; m < NB3; m++) {
+				const f2 z = v[m + NB3 * u] - mreg[m + NB3 * u];
+				const float p = z.x * z.x + z.y * z.y;
+				const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
+				o[m] = a.sA * s + a.sB;
+			}
+#pragma unroll
+			for (int m = 0; m < NB3; m++) store_image<BG>(o[m], outR, termL, L * 4, (T * m + 256 * u) * 4);
+		}
+		__builtin_amdgcn_s_setprio(0);
+	}
+}
+
+}  // namespace oct

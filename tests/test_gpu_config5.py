@@ -14,6 +14,13 @@ limit), copy-to-RAM + float 11.9 M, copy-to-RAM + float + uint16 8.2 M; unchecke
 profiles/r3e_streaming.jsonl.  The floors asserted are a margin under those, per leg; 25 M with float streaming on is above
 what the link carries in both directions at once.
 
+One more factor is outside this library: WHICH HIP runtime the process runs on.  PyTorch bundles its own libamdhip64.so (HIP
+7.0.2 in this image; the system has 7.2); whichever of torch / liboctpipe.so is loaded first decides for the whole process.
+Under the bundled 7.0.2 runtime a pipelined H2D + D2H loop overlaps the two directions only partially (60 lines of HIP
+reproduce it without this library: tools/pcie_pattern.hip, 7.2-9.7 ms per 256 MiB pair against 5.7 ms on 7.2;
+profiles/r3e_pcie_pattern.txt), which puts the preloaded + float leg at ~15.6 M instead of ~24 M.  The test prints the
+runtime it ran on; the floor holds for both.
+
 OCT_STREAM_SECONDS (default 10) sets the duration; 60 is the BASELINE form."""
 import ctypes as C
 import os
@@ -112,7 +119,7 @@ def _expected_images(p, raws_dev):
 
 
 # measured on the pool's boxes (profiles/r3*_streaming_checked.json); floors = a margin under the slowest box seen
-FLOORS = {("preloaded", "float"): 20e6, ("ram", "float"): 8e6, ("ram", "float+u16"): 5.5e6}
+FLOORS = {("preloaded", "float"): 12e6, ("ram", "float"): 7e6, ("ram", "float+u16"): 5e6}
 
 
 @pytest.mark.parametrize("mode,streams", [("preloaded", "float"), ("ram", "float"), ("ram", "float+u16")])
@@ -161,8 +168,10 @@ def test_config5_full_size_streaming_every_buffer_bit_exact(mode, streams):
     cf.idle.wait()
     if cq:
         cq.idle.wait()
-    print("config5 %s %s: %.2f M A-scans/s, %d buffers in %.1f s, %.1f GB/s in" % (
-        mode, streams, stats.ascansPerSecond / 1e6, stats.buffersProcessed, stats.elapsedSeconds, stats.dataThroughputMBs * 1048576 / 1e9))
+    ver = C.c_int(0)
+    C.CDLL("libamdhip64.so").hipRuntimeGetVersion(C.byref(ver))
+    print("config5 %s %s: %.2f M A-scans/s, %d buffers in %.1f s, %.1f GB/s in (HIP runtime %d)" % (
+        mode, streams, stats.ascansPerSecond / 1e6, stats.buffersProcessed, stats.elapsedSeconds, stats.dataThroughputMBs * 1048576 / 1e9, ver.value))
     assert cf.count == total and (cq is None or cq.count == total)
     assert cf.checked == total and (cq is None or cq.checked == total)
     assert cf.bad == [] and (cq is None or cq.bad == []), "corrupted buffers: float %r quantised %r" % (cf.bad[:8], cq.bad[:8] if cq else None)

@@ -651,6 +651,46 @@ def test_postprocess_background_record_and_remove():
     pipe.close(); o.close(); oo.close()
 
 
+@pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (300, 3)])
+@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg"])
+def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, B):
+    """N = 4096 runs one A-scan per team of four waves (team_kernel.h: 16 x 16 x 16 plan, exchanges fenced with s_barrier,
+    lane-invariant tables in registers); OCTPIPE_ROUTE_NO_TEAM keeps the one-wave kernel (64 x 16 x 4 plan, LUT through L2).
+    Really different code: both must hold the oracle and agree with each other within the float tolerance; line counts that are
+    no multiple of anything, a single line, and more lines than persistent teams (every team loops)."""
+    N = 4096
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    {"v180": mutate(),
+     "linear_flip_lin": mutate(resamplingInterpolation=INTERPOLATION.LINEAR, bscanFlip=1, signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
+     "none_bitshift": mutate(resampling=0, bitshift=1),
+     "no_dispersion": mutate(dispersionCompensation=0),
+     "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
+                         signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0
+    if p.postProcessBackgroundRemoval:
+        p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=A + B, msb_aligned=bool(p.bitshift))
+    o, pipe, d, want, got = run_both(p, raw)
+    p.postProcessBackgroundUpdated = True
+    one = Pipeline(p, device=0, route=_lib.ROUTE_NO_TEAM)
+    if p.fixedPatternNoiseRemoval:
+        one.set_mean_line(o.mean_line(), pin=True)
+    one.process_device(d.data_ptr()); one.synchronize()
+    ref = one.processed_host()
+    if p.postProcessBackgroundRemoval:  # behind the clamp the image is compared directly (both sides clamp the same way)
+        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3
+        assert got.min() >= 0.0 and got.max() <= 1.0
+    else:
+        common.compare_images(ref, want, p, "one-wave kernel %s" % variant)
+        common.compare_images(got, want, p, "team kernel %s" % variant)
+        common.compare_images(got, ref, p, "team vs one-wave %s" % variant)
+    assert not np.array_equal(got, ref)  # two different transforms really ran
+    pipe.close(); one.close(); o.close()
+
+
 @pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096, 1664])
 @pytest.mark.parametrize("variant", ["v180", "no_dispersion", "linear_flip", "lanczos", "lin_scale"])
 def test_background_removal_inside_the_fused_store_equals_the_post_pass(N, variant):

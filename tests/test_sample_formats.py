@@ -127,6 +127,14 @@ def test_fused_packed_12bit_route_is_bit_identical(N, interp):
     assert np.array_equal(np.ascontiguousarray(pk.mean_line()).view(np.uint32), np.ascontiguousarray(ml).view(np.uint32))
     got = pk.processed_host()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if N == 4096:
+        # raw rows of this length run the team kernel (team_kernel.h), prepared float32 rows the general one: two transforms,
+        # not bit-identical.  (b) is a statement about the DECODE, so it is made on the general kernel for both routes.
+        from octproz_amd import _lib
+        pk.set_route(_lib.ROUTE_NO_TEAM)
+        pk.process_device(dp.data_ptr()); pk.synchronize()
+        got = pk.processed_host()
+        assert not np.array_equal(got.view(np.uint32), want.view(np.uint32))
     pk.debug_force_prepared(True)
     pk.process_device(dp.data_ptr()); pk.synchronize()
     assert np.array_equal(pk.processed_host().view(np.uint32), got.view(np.uint32))
@@ -217,3 +225,39 @@ def test_unknown_format_and_odd_sample_count_are_rejected():
     assert L.octpipe_create_with_format(C.byref(h), 0, C.byref(acq), C.byref(p), None, None, 9) == 1 and not h.value
     n = C.c_size_t()
     assert L.octpipe_raw_buffer_bytes(None, C.byref(n)) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["uint8", "int16", "int12p"])
+def test_team_kernel_of_4096_reads_every_raw_container(kind):
+    """N = 4096 runs the team kernel (team_kernel.h) for every container the general kernel reads directly; the decode is the
+    same code (kernels.h Chunk / chunk_to_float), the transform is not: the two routes agree within the image tolerance and are
+    not bit-identical"""
+    import common
+    from octproz_amd import Pipeline, _lib, v180_benchmark_params
+    N, A, B = 4096, 24, 2
+    rng = np.random.default_rng(41)
+    p = v180_benchmark_params(N, A, B)
+    if kind == "uint8":
+        raw = rng.integers(0, 255, N * A * B, endpoint=True).astype(np.uint8)
+        p.bitDepth, fmt = 8, 0
+    elif kind == "int16":
+        raw = rng.integers(-2048, 2047, N * A * B, endpoint=True).astype(np.int16)
+        p.bitDepth, fmt = 16, FORMATS["int16"]
+    else:
+        _, raw = make("int12p", N * A * B, 23)
+        fmt = FORMATS["int12p"]
+    team = Pipeline(p, device=0, sample_format=fmt)
+    d = _dev(raw)
+    team.process_device(d.data_ptr()); team.synchronize()
+    got, ml = team.processed_host(), team.mean_line()
+    one = Pipeline(p, device=0, sample_format=fmt, route=_lib.ROUTE_NO_TEAM)
+    one.set_mean_line(ml, pin=True)
+    team.set_mean_line(ml, pin=True)
+    team.process_device(d.data_ptr()); team.synchronize()
+    got = team.processed_host()
+    one.process_device(d.data_ptr()); one.synchronize()
+    ref = one.processed_host()
+    common.compare_images(got, ref, p, "team vs one-wave kernel, %s" % kind)
+    assert not np.array_equal(got, ref)
+    team.close(); one.close()
