@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -378,6 +379,31 @@ bool needsPrepared(const octpipe* h) {
 	       (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS && h->params.backgroundRemoval != 0);
 }
 
+// unpack (+ rolling average) of `count` samples (whole lines) into a float32 buffer: the "prepared" route and octpipe_debug_unpack
+int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int rollingW) {
+	const OctPipeParams& p = h->params;
+	// rolling average on integer samples whose window sums stay below 2^24 (exact in float32, whatever the order): one
+	// workgroup per row with a prefix-sum array in LDS; everything else: the element-wise kernel with the ordered loop
+	const unsigned bits = h->acq.bitDepth > 16 ? 32 : h->acq.bitDepth;
+	const bool integerRows = h->sampleFormat != OCTPIPE_FORMAT_INT32 && h->acq.bitDepth <= 16;
+	const uint64_t maxAbs = bits >= 32 ? 0xffffffffull : (((1ull << bits) - 1ull) >> (p.bitshift ? 4 : 0));
+	const size_t rowsLds = sizeof(int) * ((size_t)2 * h->N + 1 + 256);
+	if (rollingW > 0 && integerRows && 2ull * (uint64_t)rollingW * maxAbs < (1ull << 24) && rowsLds <= 150 * 1024 && count % (size_t)h->N == 0) {
+		static std::once_flag ldsOptIn[64];
+		const size_t lines = count / (size_t)h->N;
+		hipError_t e = hipSuccess;
+		std::call_once(ldsOptIn[h->device & 63], [&] { e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+		HIP_TRY(e);
+		hipLaunchKernelGGL(oct::oct_prepare_rows_kernel<256>, dim3((unsigned)(lines < 4096 ? lines : 4096)), dim3(256), rowsLds, h->stream, d_raw, d_out,
+		                   (int)h->acq.bitDepth, p.bitshift, rollingW, h->N, lines, h->sampleFormat);
+	} else {
+		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(count)), dim3(256), 0, h->stream, d_raw, d_out,
+		                   (int)h->acq.bitDepth, p.bitshift, rollingW, h->N, count, h->sampleFormat);
+	}
+	HIP_TRY(hipGetLastError());
+	return OCTPIPE_OK;
+}
+
 // one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
 // Signature of the display settings: while it is unchanged only the buffer just written can have changed the frames, and
 // the extraction (cu:1571-1578) is restricted to it: the en-face pixels of its A-scans (every pixel depends on its own
@@ -422,9 +448,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
-		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(h->S)), dim3(256), 0, h->stream, d_raw, h->d_prepared,
-		                   (int)h->acq.bitDepth, p.bitshift, roll ? p.rollingAverageWindowSize : 0, h->N, h->S, h->sampleFormat);
-		HIP_TRY(hipGetLastError());
+		if ((rc = launchPrepare(h, d_raw, h->d_prepared, h->S, roll ? p.rollingAverageWindowSize : 0))) return rc;
 		a.raw = h->d_prepared;
 		intype = oct::IN_F32;
 		roll = false;
@@ -1223,10 +1247,9 @@ int octpipe_debug_unpack(octpipe_t* h, const void* d_raw, size_t count, float* h
 	float* d_tmp = nullptr;
 	HIP_TRY(hipMalloc((void**)&d_tmp, sizeof(float) * count));
 	const OctPipeParams& p = h->params;
-	hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(count)), dim3(256), 0, h->stream, d_raw, d_tmp, (int)h->acq.bitDepth,
-	                   p.bitshift, p.backgroundRemoval ? p.rollingAverageWindowSize : 0, h->N, count, h->sampleFormat);
-	hipError_t e = hipGetLastError();
-	if (e == hipSuccess) e = hipMemcpyAsync(hostOut, d_tmp, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream);
+	rc = launchPrepare(h, d_raw, d_tmp, count, p.backgroundRemoval ? p.rollingAverageWindowSize : 0);
+	if (rc) { hipFree(d_tmp); return rc; }
+	hipError_t e = hipMemcpyAsync(hostOut, d_tmp, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 	hipFree(d_tmp);
 	if (e != hipSuccess) return fail(OCTPIPE_ERR_DEVICE, hipGetErrorString(e));

@@ -55,6 +55,53 @@ __global__ void oct_prepare_kernel(const void* raw, float* out, int bitDepth, in
 	}
 }
 
+// The same with the rolling-average DC removal (cu:165-211) for integer samples whose window sums stay below 2^24: the
+// reference's index-order float sum of such samples is exact, i.e. it IS the integer window sum (kernels.h makes the same
+// argument for the fused kernel's prefix-sum route), so one workgroup per row decodes the row once into LDS, builds an
+// integer prefix-sum array and takes every window as a difference -- O(1) per sample instead of 2 W decodes (the kernel
+// above at W = 64 and N = 1664: 5.8 M A-scans/s for the whole chain).  Division: the IEEE quotient like the reference's `/`.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void oct_prepare_rows_kernel(const void* raw, float* out, int bitDepth, int bitshift, int W, int N, size_t lines, int format) {
+	extern __shared__ int prep_sh[];
+	int* val = prep_sh;          // [N] decoded samples of the row
+	int* pfx = prep_sh + N;      // [N + 1] pfx[j] = val[0] + ... + val[j-1]
+	int* part = pfx + N + 1;     // [THREADS]
+	const int tid = threadIdx.x;
+	const int per = (N + THREADS - 1) / THREADS;
+	const int c0 = min(N, tid * per), c1 = min(N, c0 + per);
+	for (size_t line = blockIdx.x; line < lines; line += gridDim.x) {
+		const size_t ls = line * (size_t)N;
+		for (int j = tid; j < N; j += THREADS) {
+			const size_t idx = ls + (size_t)j;
+			int v;
+			if (format == 1 || format == 2) {
+				const uint8_t* b = reinterpret_cast<const uint8_t*>(raw) + (idx >> 1) * 3;
+				const uint32_t u = (idx & 1) ? ((uint32_t)b[1] >> 4) | ((uint32_t)b[2] << 4) : (uint32_t)b[0] | (((uint32_t)b[1] & 15u) << 8);
+				v = format == 1 ? (int)u : ((int)(u << 20) >> 20);
+			} else if (format == 3) v = reinterpret_cast<const int8_t*>(raw)[idx];
+			else if (format == 4) v = reinterpret_cast<const int16_t*>(raw)[idx];
+			else if (bitDepth <= 8) v = reinterpret_cast<const uint8_t*>(raw)[idx];
+			else v = reinterpret_cast<const uint16_t*>(raw)[idx];
+			val[j] = bitshift ? (v >> 4) : v;  // arithmetic shift for the signed formats, logical value for unsigned (v >= 0)
+		}
+		__syncthreads();
+		int s = 0;
+		for (int j = c0; j < c1; j++) s += val[j];
+		part[tid] = s;
+		__syncthreads();
+		int run = 0;
+		for (int k = 0; k < tid; k++) run += part[k];
+		for (int j = c0; j < c1; j++) { pfx[j] = run; run += val[j]; }
+		if (c0 < N && c1 == N) pfx[N] = run;
+		__syncthreads();
+		for (int j = tid; j < N; j += THREADS) {
+			const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
+			out[ls + (size_t)j] = (float)val[j] - __fdiv_rn((float)(pfx[hi + 1] - pfx[lo]), (float)(hi - lo + 1));
+		}
+		__syncthreads();
+	}
+}
+
 // ------------------------------------------------------------------ fixed-pattern-noise estimate (cu:523-565)
 // split in two so that 9*width threads share the serial walk; every sum keeps the reference's order (one segment = one
 // sequential float accumulation, strict '<' over segments).

@@ -261,3 +261,26 @@ def test_team_kernel_of_4096_reads_every_raw_container(kind):
     common.compare_images(got, ref, p, "team vs one-wave kernel, %s" % kind)
     assert not np.array_equal(got, ref)
     team.close(); one.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["uint12p", "int12p", "int8", "int16", "int32"])
+@pytest.mark.parametrize("N,W,bitshift", [(1664, 64, 0), (256, 8, 1), (3000, 300, 0)])
+def test_gpu_decode_with_rolling_average_bit_exact(fmt, N, W, bitshift):
+    """the prepared route's rolling-average DC removal (cu:165-211) for every sample format against the oracle's ordered float
+    loop, bit for bit: integer formats whose window sums stay below 2^24 run the row kernel with integer prefix sums
+    (oct_prepare_rows_kernel), int32 and the wide window on 16-bit data the element-wise kernel with the ordered loop"""
+    from octproz_amd import Pipeline, v180_benchmark_params
+    A, B = 6, 2
+    v, raw = make(fmt, N * A * B, 13 + W)
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth = {"int8": 8, "int32": 32}.get(fmt, 12 if "12" in fmt else 16)
+    p.bitshift = bitshift
+    p.backgroundRemoval, p.rollingAverageWindowSize = 1, W
+    pipe = Pipeline(p, device=0, sample_format=FORMATS[fmt])
+    d = _dev(raw)
+    got = pipe.debug_unpack(d.data_ptr(), v.size)
+    x = octref.unpack_format(raw, FORMATS[fmt], bitshift, v.size)
+    want = octref.rolling_average(x, W, N, A * B).real.reshape(-1).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    pipe.close()
