@@ -393,7 +393,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_fused_kernel<10, 1, 2, 4>",
-                                    2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_team_kernel<12, 2, 4>",
+                                    2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_team_kernel<12, 1, 2, 4>", 8192: "oct_team_kernel<13, 1, 2, 4>",
                                     1664: "oct_mixed1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)"),
                          "kernel_ms": kernel_ms,
                          "kernel_ms_per_rank": {"min": min(kernel_ms_ranks), "max": max(kernel_ms_ranks), "ranks": kernel_ms_ranks},

@@ -334,13 +334,15 @@ int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, boo
 int uploadTeamTables(octpipe* h) {
 	std::vector<f2> tw((size_t)oct::team_twiddle_count(h->log2n));
 	size_t pos = 0;
-	const int radix[2] = {16, oct::team_last_radix(h->log2n)}, ns[2] = {16, 256};
-	for (int pass = 0; pass < 2; ++pass)
+	const int radix[3] = {16, oct::team_last_radix(h->log2n), 2}, ns[3] = {16, 256, 4096};
+	const int passes = h->log2n == 13 ? 3 : 2;  // N = 8192: 16 x 16 x 16 x 2
+	for (int pass = 0; pass < passes; ++pass)
 		for (int t = 1; t < radix[pass]; ++t)
 			for (int k = 0; k < ns[pass]; ++k) {
 				const double ang = 2.0 * 3.14159265358979323846 * (double)t * (double)k / ((double)ns[pass] * radix[pass]);
 				tw[pos++] = f2{(float)cos(ang), (float)sin(ang)};
 			}
+	if (pos != tw.size()) return fail(OCTPIPE_ERR_DEVICE, "team twiddle table size mismatch");
 	HIP_TRY(hipMalloc((void**)&h->d_twTeam, sizeof(f2) * tw.size()));
 	HIP_TRY(hipMemcpy(h->d_twTeam, tw.data(), sizeof(f2) * tw.size(), hipMemcpyHostToDevice));
 	return OCTPIPE_OK;
@@ -445,7 +447,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	const bool i16Direct = plainFused && h->sampleFormat == OCTPIPE_FORMAT_INT16;
 	if (u8Direct) intype = oct::IN_U8;
 	if (i16Direct) intype = oct::IN_I16;
-	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct) {
+	// lengths on the library route that also have a team kernel (N = 8192): plain uint16 rows go to it directly
+	const bool teamDirect = h->libfft && h->d_twTeam && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll &&
+	                        rs != oct::RS_LANCZOS && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
+	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
 		if ((rc = launchPrepare(h, d_raw, h->d_prepared, h->S, roll ? p.rollingAverageWindowSize : 0))) return rc;
@@ -454,7 +459,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		roll = false;
 	}
 	if (bgApplied) *bgApplied = false;
-	if (wantBg && !spectrum && intype == oct::IN_U16 && !roll && !h->libfft && (useMixed ? mixedDirect : !h->bluestein)) {
+	if (wantBg && !spectrum && intype == oct::IN_U16 && !roll && (!h->libfft || teamDirect) && (useMixed ? mixedDirect : !h->bluestein)) {
 		int rc = ensure((void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
 		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {
@@ -500,7 +505,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (h->libfft) {
+	if (teamDirect) {
+		a.twiddle = h->d_twTeam;
+		HIP_TRY(oct::launch_team(h->log2n, intype, rs, p.signalLogScaling != 0, a, h->stream));
+	} else if (h->libfft) {
 		int rc = launchLibFft(h, a, rs, spectrum, p.signalLogScaling != 0);
 		if (rc) return rc;
 	} else if (useMixed) {
@@ -939,7 +947,10 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	else if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
 	if (h->mixed && (rc = uploadMixedTables(h))) return rc;
-	if (!h->libfft && !h->bluestein && oct::team_supported(h->log2n) && (rc = uploadTeamTables(h))) return rc;
+	// power-of-two lengths with a team kernel (team_kernel.h): 4096, and 8192 next to the library route it keeps for the
+	// variants the team kernel does not cover
+	if (!h->bluestein && h->N == (1 << h->log2n) && oct::team_supported(h->log2n) && !(createRoute & OCTPIPE_ROUTE_FORCE_LIBFFT) &&
+	    (rc = uploadTeamTables(h))) return rc;
 	{  // cu:1093
 		std::vector<float> sc((size_t)h->A);
 		octhost::sinusoidal_curve((unsigned)h->A, sc.data());

@@ -52,6 +52,9 @@ hipError_t OCT_CAT(launch_team_in, OCT_TEAM_INTYPE)(int log2n, int rs, bool logS
 	if (log2n == 11) return launch_team_rs<11>(rs, logScale, a, stream);
 #endif
 	if (log2n == 12) return launch_team_rs<12>(rs, logScale, a, stream);
+#if OCT_TEAM_INTYPE == 1
+	if (log2n == 13) return launch_team_rs<13>(rs, logScale, a, stream);  // N = 8192: uint16 rows only (other containers: library route)
+#endif
 	return hipErrorNotSupported;
 }
 
@@ -60,10 +63,10 @@ bool team_supported(int log2n) {
 #if defined(OCT_TEAM11) && OCT_TEAM11
 	if (log2n == 11) return true;
 #endif
-	return log2n == 12;
+	return log2n == 12 || log2n == 13;
 }
-int team_twiddle_count(int log2n) { return log2n == 11 ? Team<11>::TW_COUNT : Team<12>::TW_COUNT; }
-int team_last_radix(int log2n) { return log2n == 11 ? Team<11>::R3 : Team<12>::R3; }
+int team_twiddle_count(int log2n) { return log2n == 11 ? Team<11>::TW_COUNT : log2n == 12 ? Team<12>::TW_COUNT : Team<13>::TW_COUNT; }
+int team_last_radix(int log2n) { return log2n == 11 ? Team<11>::R3 : log2n == 12 ? Team<12>::R3 : Team<13>::R3; }
 #endif
 
 }  // namespace oct

@@ -1,4 +1,5 @@
-// team_kernel.h -- one A-scan per TEAM of waves: N / 16 lanes x 16 points (N = 4096: four waves; N = 2048: two, experiment only).
+// team_kernel.h -- one A-scan per TEAM of waves: N / 16 lanes x 16 points (N = 4096: four waves; N = 8192: eight; N = 2048: two,
+// experiment only).
 //
 // The general kernel gives a wave64 a whole A-scan.  At N = 4096 that is 64 points per lane: nothing lane-invariant fits in
 // registers next to the data, the slice of a wave leaves room for 6 waves per CU, the resampling / window / phasor LUT does not
@@ -17,6 +18,12 @@
 //     pass 3  butterflies b = L + T m < 256:   inputs b + 256 t, twiddle e^{+2 pi i t b / N}, bins b + 256 u, u < R3 / 2 kept (R3 = N / 256)
 // Arithmetic per stage is the general kernel's (same gather expressions, same butterflies, same epilogue).
 //
+// N = 8192 (no one-wave kernel exists: 128 points per lane; the library route gather -> hipFFT -> epilogue ran it at 12 M
+// A-scans/s): eight waves, plan 16 x 16 x 16 x 2 -- pass 3 unpruned with twiddle e^{+2 pi i t (L & 255) / 4096} and outputs
+// 4096 (L >> 8) + (L & 255) + 256 u, a third exchange, and a radix-2 pass over the butterflies b = L + 512 m (inputs b, b + 4096,
+// twiddle e^{+2 pi i b / 8192}) of which only the sum (bin b < 4096) is kept.  The mean A-line moves to LDS there (the
+// fourth twiddle set takes its registers).  One team per CU.
+//
 // N = 2048 through this kernel (two waves per team; -DOCT_TEAM11=1) was measured in round 3 and is 4 % SLOWER than the
 // one-wave kernel of that length (profiles/r3g_wave2_ab.txt): two LDS round trips per wave iteration at two waves per SIMD
 // leave the SIMD idle ~25 % of the time, which the one-wave kernel's longer instruction stream hides.  At N = 4096 the
@@ -27,15 +34,20 @@
 namespace oct {
 
 template <int LOG2N> struct Team {
-	static_assert(LOG2N == 11 || LOG2N == 12, "N / 16 lanes per A-scan: two or four waves");
-	static constexpr int N = 1 << LOG2N, P = 16, LANES = N / 16, R3 = N / 256, NB3 = 16 / R3;
+	static_assert(LOG2N >= 11 && LOG2N <= 13, "N / 16 lanes per A-scan: two, four or eight waves");
+	static constexpr bool FOUR = LOG2N == 13;  // four passes: 16 x 16 x 16 x 2
+	static constexpr int N = 1 << LOG2N, P = 16, LANES = N / 16, R3 = FOUR ? 16 : N / 256, NB3 = 16 / R3;
 	static constexpr int ROW_BYTES = ((N + 2 * ROW_OFF) * 4 + 15) & ~15;
 	static constexpr int X_BYTES = (N + N / 16) * 8;
+	static constexpr int MEAN_BYTES = FOUR ? N * 4 : 0;  // N / 2 complex bins in LDS instead of registers
 	static constexpr int PITCH = LANES + LANES / 16;  // strided read: element L + LANES q at rb[PITCH q]
-	// twiddle table of this plan in FusedArgs::twiddle: [t-1][k] for pass 2 (15 x 16), then [t-1][k] for pass 3 ((R3 - 1) x 256)
-	static constexpr int TW_PASS3 = 15 * 16, TW_COUNT = 15 * 16 + (R3 - 1) * 256;
+	// twiddle table of this plan in FusedArgs::twiddle: [t-1][k] for pass 2 (15 x 16), then [t-1][k] for pass 3 ((R3 - 1) x 256,
+	// angle 2 pi t k / (256 R3)), then (FOUR) [k] for pass 4 (4096, angle 2 pi k / N)
+	static constexpr int TW_PASS3 = 15 * 16, TW_PASS4 = TW_PASS3 + (R3 - 1) * 256, TW_COUNT = TW_PASS4 + (FOUR ? 4096 : 0);
 };
-template <int LOG2N, int MODE> constexpr int team_lds_bytes() { return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>(); }
+template <int LOG2N, int MODE> constexpr int team_lds_bytes() {
+	return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + Team<LOG2N>::MEAN_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>();
+}
 
 // LDS traffic of the team's waves is ordered by s_barrier; only the LDS counter is drained in front of it (a __syncthreads()
 // would also wait for the row prefetch and the image stores in flight)
@@ -47,17 +59,19 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
 	static_assert(INTYPE == IN_U16 || INTYPE == IN_I16 || INTYPE == IN_U8 || INTYPE == IN_P12U || INTYPE == IN_P12S, "raw rows");
 	typedef Team<LOG2N> TM;
-	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3, NB3 = TM::NB3, NBINS = NB3 * R3 / 2;
-	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
+	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3, NB3 = TM::NB3, NBINS = 8;
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, FOUR = TM::FOUR;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* row = reinterpret_cast<float*>(smem);
 	f2* xbuf = reinterpret_cast<f2*>(smem + TM::ROW_BYTES);
-	const float* termL = reinterpret_cast<const float*>(smem + TM::ROW_BYTES + TM::X_BYTES);
+	f2* meanL = reinterpret_cast<f2*>(smem + TM::ROW_BYTES + TM::X_BYTES);
+	const float* termL = reinterpret_cast<const float*>(smem + TM::ROW_BYTES + TM::X_BYTES + TM::MEAN_BYTES);
 	const int L = threadIdx.x;  // 0 .. T-1: "lane" of the team
-	if constexpr (BG) {
-		fill_bg_term(reinterpret_cast<float*>(smem + TM::ROW_BYTES + TM::X_BYTES), a.bgTerm, N / 2, L, T);
-		__syncthreads();
+	if constexpr (BG) fill_bg_term(reinterpret_cast<float*>(smem + TM::ROW_BYTES + TM::X_BYTES + TM::MEAN_BYTES), a.bgTerm, N / 2, L, T);
+	if constexpr (FOUR) {
+		for (int i = L; i < N / 2; i += T) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
 	}
+	if constexpr (BG || FOUR) __syncthreads();
 
 	// ---- loop invariants of the lane
 	typedef __attribute__((address_space(3))) const float lds_cfloat;
@@ -87,12 +101,20 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 #pragma unroll
 	for (int m = 0; m < NB3; m++)
 #pragma unroll
-		for (int t = 1; t < R3; t++) tw3[m * (R3 - 1) + t - 1] = a.twiddle[TM::TW_PASS3 + (t - 1) * 256 + L + T * m];
-	f2 mreg[NBINS];  // the lane finishes the same bins of every A-scan: bin L + T m + 256 u in mreg[m + NB3 u]
+		for (int t = 1; t < R3; t++) tw3[m * (R3 - 1) + t - 1] = a.twiddle[TM::TW_PASS3 + (t - 1) * 256 + ((L + T * m) & 255)];  // w(t, b mod 256)
+	f2 tw4[FOUR ? 8 : 1];
+	if constexpr (FOUR) {
 #pragma unroll
-	for (int u = 0; u < R3 / 2; u++)
+		for (int m = 0; m < 8; m++) tw4[m] = a.twiddle[TM::TW_PASS4 + L + T * m];
+	}
+	f2 mreg[FOUR ? 1 : NBINS];  // the lane finishes the same bins of every A-scan: bin L + T m + 256 u in mreg[m + NB3 u]
+	if constexpr (!FOUR) {
 #pragma unroll
-		for (int m = 0; m < NB3; m++) mreg[m + NB3 * u] = a.subtractMean ? a.meanLine[L + T * m + 256 * u] : f2{0.0f, 0.0f};
+		for (int u = 0; u < R3 / 2; u++)
+#pragma unroll
+			for (int m = 0; m < NB3; m++) mreg[m + NB3 * u] = a.subtractMean ? a.meanLine[L + T * m + 256 * u] : f2{0.0f, 0.0f};
+	}
+	f2* wb3 = xbuf + (4352 * (L >> 8) + (L & 255) + ((L & 255) >> 4));  // FOUR: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[272 u]
 
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (T * SPL);  // chunk = SPL consecutive samples in CB bytes; NL chunks per lane and row
@@ -172,8 +194,21 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		for (int m = 0; m < NB3; m++)
 #pragma unroll
 			for (int t = 1; t < R3; t++) v[m + NB3 * t] = octfft::cmul(v[m + NB3 * t], tw3[m * (R3 - 1) + t - 1]);
+		if constexpr (FOUR) {
+			octfft::Dft<16, 1, false>::run(&v[0]);
+			team_barrier();  // everyone has read the second exchange
 #pragma unroll
-		for (int m = 0; m < NB3; m++) octfft::Dft<R3, NB3, true>::run(&v[m]);
+			for (int u = 0; u < 16; u++) wb3[272 * u] = v[u];
+			team_barrier();  // third exchange written
+#pragma unroll
+			for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+			// radix 2 over (b, b + 4096), b = L + T m: element L + T q with q = m + 8 t; only the sum (bin b) is kept
+#pragma unroll
+			for (int m = 0; m < 8; m++) v[m] = v[m] + octfft::cmul(v[m + 8], tw4[m]);
+		} else {
+#pragma unroll
+			for (int m = 0; m < NB3; m++) octfft::Dft<R3, NB3, true>::run(&v[m]);
+		}
 		__builtin_amdgcn_s_setprio(1);
 
 		// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address (as in the general kernel)
@@ -183,6 +218,15 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 			if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
 		}
 		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
+		if constexpr (FOUR) {
+#pragma unroll
+			for (int m = 0; m < 8; m++) {
+				const f2 z = v[m] - meanL[L + T * m];
+				const float p = z.x * z.x + z.y * z.y;
+				const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
+				store_image<BG>(a.sA * s + a.sB, outR, termL, L * 4, T * m * 4);
+			}
+		} else
 #pragma unroll
 		for (int u = 0; u < R3 / 2; u++) {
 			float o[NB3];

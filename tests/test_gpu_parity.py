@@ -333,8 +333,10 @@ def test_non_power_of_two_lengths_bluestein(N, interp, route):
 @pytest.mark.parametrize("N", [8192, 3000, 2500, 16384])
 @pytest.mark.parametrize("case", ["v180", "linear", "lanczos", "rolling8", "flip", "nothing", "lin_scale", "no_dispersion"])
 def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
-    """samplesPerLine > 4096 or a non-power of two above 2047: gather -> hipFFT (batched inverse C2C) -> epilogue through a
-    complex buffer, the reference's own pass structure (cu:1448-1543); image and spectrum against the oracle"""
+    """samplesPerLine > 8192 or a non-power of two above 2047: gather -> hipFFT (batched inverse C2C) -> epilogue through a
+    complex buffer, the reference's own pass structure (cu:1448-1543); image and spectrum against the oracle.  N = 8192 has a
+    team kernel for its plain variants and keeps this route for the rest (Lanczos, rolling average, spectrum output): both run
+    here, the team kernel against the library route in the test below"""
     if N == 16384 and case not in ("v180", "flip"):
         pytest.skip("longest length on two cases")
     A, B = 20, 2
@@ -352,6 +354,45 @@ def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
             ospec[:, :N // 2] += o.mean_line()[:N // 2]
         common.compare_spectra(spec, ospec, N, case)
     pipe.close(); o.close()
+
+
+@pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (130, 3)])
+@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg"])
+def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B):
+    """N = 8192: one A-scan per team of EIGHT waves (team_kernel.h: plan 16 x 16 x 16 x 2, three exchanges fenced with
+    s_barrier); OCTPIPE_ROUTE_NO_TEAM keeps the library route (gather -> hipFFT -> epilogue).  Both against the oracle's O(N^2)
+    float64 DFT and against each other; ragged line counts, a single line, more lines than persistent teams."""
+    N = 8192
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    {"v180": mutate(),
+     "linear_flip_lin": mutate(resamplingInterpolation=INTERPOLATION.LINEAR, bscanFlip=1, signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
+     "none_bitshift": mutate(resampling=0, bitshift=1),
+     "no_dispersion": mutate(dispersionCompensation=0),
+     "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
+                         signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0
+    if p.postProcessBackgroundRemoval:
+        p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=A + B, msb_aligned=bool(p.bitshift))
+    o, pipe, d, want, got = run_both(p, raw)
+    p.postProcessBackgroundUpdated = True
+    lib = Pipeline(p, device=0, route=_lib.ROUTE_NO_TEAM)
+    if p.fixedPatternNoiseRemoval:
+        lib.set_mean_line(o.mean_line(), pin=True)
+    lib.process_device(d.data_ptr()); lib.synchronize()
+    ref = lib.processed_host()
+    if p.postProcessBackgroundRemoval:
+        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3
+        assert got.min() >= 0.0 and got.max() <= 1.0
+    else:
+        common.compare_images(ref, want, p, "library route %s" % variant)
+        common.compare_images(got, want, p, "team kernel %s" % variant)
+        common.compare_images(got, ref, p, "team vs library route %s" % variant)
+    assert not np.array_equal(got, ref)
+    pipe.close(); lib.close(); o.close()
 
 
 def test_library_fft_route_determines_its_own_mean_line():
