@@ -69,7 +69,8 @@ bool team_supported(int log2n);
 int team_twiddle_count(int log2n);
 int team_last_radix(int log2n);
 hipError_t launch_team_in0(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);  // one translation unit per
-hipError_t launch_team_in1(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);  // raw container (IN_*)
+hipError_t launch_team_in1(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);  // container (IN_*)
+hipError_t launch_team_in3(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 hipError_t launch_team_in4(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 hipError_t launch_team_in5(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 hipError_t launch_team_in6(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
@@ -77,6 +78,7 @@ inline hipError_t launch_team(int log2n, int intype, int rs, bool logScale, cons
 	switch (intype) {
 	case IN_U8: return launch_team_in0(log2n, rs, logScale, a, stream);
 	case IN_U16: return launch_team_in1(log2n, rs, logScale, a, stream);
+	case IN_F32: return launch_team_in3(log2n, rs, logScale, a, stream);
 	case IN_P12U: return launch_team_in4(log2n, rs, logScale, a, stream);
 	case IN_P12S: return launch_team_in5(log2n, rs, logScale, a, stream);
 	case IN_I16: return launch_team_in6(log2n, rs, logScale, a, stream);

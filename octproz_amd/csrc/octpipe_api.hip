@@ -377,8 +377,11 @@ size_t rawBytes(const octpipe* h) {
 
 // Lanczos taps reach 8 samples into the neighbour rows: with the rolling average on, those have to be the corrected samples
 bool needsPrepared(const octpipe* h) {
+	// (N = 4096 with the rolling average stays on the one-wave kernel's in-kernel prefix sums: prepared rows + team kernel were
+	// measured at 34 M against its 39 M A-scans/s, the row kernel's three phases take longer than the team kernel itself)
+	const bool lanczos = h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS;
 	return h->libfft || h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO ||
-	       (h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS && h->params.backgroundRemoval != 0);
+	       (lanczos && h->params.backgroundRemoval != 0);
 }
 
 // unpack (+ rolling average) of `count` samples (whole lines) into a float32 buffer: the "prepared" route and octpipe_debug_unpack
@@ -389,7 +392,7 @@ int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int
 	const unsigned bits = h->acq.bitDepth > 16 ? 32 : h->acq.bitDepth;
 	const bool integerRows = h->sampleFormat != OCTPIPE_FORMAT_INT32 && h->acq.bitDepth <= 16;
 	const uint64_t maxAbs = bits >= 32 ? 0xffffffffull : (((1ull << bits) - 1ull) >> (p.bitshift ? 4 : 0));
-	const size_t rowsLds = sizeof(int) * ((size_t)2 * h->N + 1 + 256);
+	const size_t rowsLds = sizeof(int) * ((size_t)2 * (h->N + h->N / 2 + 2) + 8);  // two padded arrays (at most one pad word per two samples) + wave totals
 	if (rollingW > 0 && integerRows && 2ull * (uint64_t)rollingW * maxAbs < (1ull << 24) && rowsLds <= 150 * 1024 && count % (size_t)h->N == 0) {
 		static std::once_flag ldsOptIn[64];
 		const size_t lines = count / (size_t)h->N;
@@ -447,9 +450,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	const bool i16Direct = plainFused && h->sampleFormat == OCTPIPE_FORMAT_INT16;
 	if (u8Direct) intype = oct::IN_U8;
 	if (i16Direct) intype = oct::IN_I16;
-	// lengths on the library route that also have a team kernel (N = 8192): plain uint16 rows go to it directly
-	const bool teamDirect = h->libfft && h->d_twTeam && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll &&
-	                        rs != oct::RS_LANCZOS && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
+	// lengths on the library route that also have a team kernel (N = 8192): everything but Lanczos and the spectrum output runs
+	// on it, plain uint16 rows directly, other containers and the rolling average through the prepared float32 rows
+	const bool teamLib = h->libfft && h->d_twTeam && rs != oct::RS_LANCZOS && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
+	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
@@ -505,7 +509,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (teamDirect) {
+	if (teamLib) {
 		a.twiddle = h->d_twTeam;
 		HIP_TRY(oct::launch_team(h->log2n, intype, rs, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->libfft) {
@@ -537,10 +541,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		b.sA = a.sA;
 		b.sB = a.sB;
 		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
-	} else if (h->d_twTeam && intype != oct::IN_F32 && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
+	} else if (h->d_twTeam && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
 	           !(h->route & OCTPIPE_ROUTE_NO_TEAM) && (p.dispersionCompensation || intype != oct::IN_U16 || !oct::real2n_supported(h->log2n))) {
 		// N = 4096: one A-scan per team of four waves, lane-invariant tables in registers (team_kernel.h); every raw container
-		// the general kernel reads directly (uint16, int16, uint8, packed 12 bit)
+		// the general kernel reads directly (uint16, int16, uint8, packed 12 bit) and the prepared float32 rows (other
+		// containers; the rolling average, which the row kernel has already applied: `roll` is false here)
 		a.twiddle = h->d_twTeam;
 		HIP_TRY(oct::launch_team(h->log2n, intype, rs, p.signalLogScaling != 0, a, h->stream));
 	} else if ((h->log2n == 10 || oct::real2n_supported(h->log2n)) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&

@@ -63,11 +63,14 @@ __global__ void oct_prepare_kernel(const void* raw, float* out, int bitDepth, in
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void oct_prepare_rows_kernel(const void* raw, float* out, int bitDepth, int bitshift, int W, int N, size_t lines, int format) {
 	extern __shared__ int prep_sh[];
-	int* val = prep_sh;          // [N] decoded samples of the row
-	int* pfx = prep_sh + N;      // [N + 1] pfx[j] = val[0] + ... + val[j-1]
-	int* part = pfx + N + 1;     // [THREADS]
 	const int tid = threadIdx.x;
-	const int per = (N + THREADS - 1) / THREADS;
+	const int per = (N + THREADS - 1) / THREADS;   // thread t scans the contiguous samples [t per, (t + 1) per)
+	const int padPer = (per & 1) ? 0 : per;        // even chunk length: one pad word per chunk makes the lane stride odd (no bank conflicts)
+	auto at = [&](int j) { return padPer ? j + j / padPer : j; };
+	const int span = at(N) + 1;
+	int* val = prep_sh;                   // decoded samples of the row, at(j)
+	int* pfx = prep_sh + span;            // pfx[at(j)] = val[0] + ... + val[j-1], j <= N
+	int* waveTot = pfx + span;            // [THREADS / 64]
 	const int c0 = min(N, tid * per), c1 = min(N, c0 + per);
 	for (size_t line = blockIdx.x; line < lines; line += gridDim.x) {
 		const size_t ls = line * (size_t)N;
@@ -82,21 +85,23 @@ __global__ __launch_bounds__(THREADS) void oct_prepare_rows_kernel(const void* r
 			else if (format == 4) v = reinterpret_cast<const int16_t*>(raw)[idx];
 			else if (bitDepth <= 8) v = reinterpret_cast<const uint8_t*>(raw)[idx];
 			else v = reinterpret_cast<const uint16_t*>(raw)[idx];
-			val[j] = bitshift ? (v >> 4) : v;  // arithmetic shift for the signed formats, logical value for unsigned (v >= 0)
+			val[at(j)] = bitshift ? (v >> 4) : v;  // arithmetic shift for the signed formats, logical value for unsigned (v >= 0)
 		}
 		__syncthreads();
 		int s = 0;
-		for (int j = c0; j < c1; j++) s += val[j];
-		part[tid] = s;
+		for (int j = c0; j < c1; j++) s += val[at(j)];
+		// exclusive scan of the chunk sums over the workgroup: DPP scan inside the wave, wave totals through LDS
+		const uint32_t incl = wave_inclusive_scan((uint32_t)s);
+		if ((tid & 63) == 63) waveTot[tid >> 6] = (int)incl;
 		__syncthreads();
-		int run = 0;
-		for (int k = 0; k < tid; k++) run += part[k];
-		for (int j = c0; j < c1; j++) { pfx[j] = run; run += val[j]; }
-		if (c0 < N && c1 == N) pfx[N] = run;
+		int run = (int)incl - s;
+		for (int w = 0; w < (tid >> 6); w++) run += waveTot[w];
+		for (int j = c0; j < c1; j++) { pfx[at(j)] = run; run += val[at(j)]; }
+		if (c0 < N && c1 == N) pfx[at(N)] = run;
 		__syncthreads();
 		for (int j = tid; j < N; j += THREADS) {
 			const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
-			out[ls + (size_t)j] = (float)val[j] - __fdiv_rn((float)(pfx[hi + 1] - pfx[lo]), (float)(hi - lo + 1));
+			out[ls + (size_t)j] = (float)val[at(j)] - __fdiv_rn((float)(pfx[at(hi + 1)] - pfx[at(lo)]), (float)(hi - lo + 1));
 		}
 		__syncthreads();
 	}

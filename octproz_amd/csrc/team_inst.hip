@@ -1,11 +1,11 @@
 // team_inst.hip -- instantiates the one-A-scan-per-team kernel (team_kernel.h) for ONE raw sample container (-DOCT_TEAM_INTYPE=
-// IN_U16 1, IN_P12U 4, IN_P12S 5, IN_I16 6, IN_U8 0: one translation unit each so that they build in parallel): N = 4096 in the
+// IN_U16 1, IN_F32 3 (prepared rows), IN_P12U 4, IN_P12S 5, IN_I16 6, IN_U8 0: one translation unit each so that they build in parallel): N = 4096 in the
 // product; N = 2048 as well when built with -DOCT_TEAM11=1 (round-3 experiment, slower than the one-wave kernel there)
 #include "launch.h"
 #include "team_kernel.h"
 
 #ifndef OCT_TEAM_INTYPE
-#error "compile with -DOCT_TEAM_INTYPE=<0|1|4|5|6>"
+#error "compile with -DOCT_TEAM_INTYPE=<0|1|3|4|5|6>"
 #endif
 
 namespace oct {
@@ -52,8 +52,8 @@ hipError_t OCT_CAT(launch_team_in, OCT_TEAM_INTYPE)(int log2n, int rs, bool logS
 	if (log2n == 11) return launch_team_rs<11>(rs, logScale, a, stream);
 #endif
 	if (log2n == 12) return launch_team_rs<12>(rs, logScale, a, stream);
-#if OCT_TEAM_INTYPE == 1
-	if (log2n == 13) return launch_team_rs<13>(rs, logScale, a, stream);  // N = 8192: uint16 rows only (other containers: library route)
+#if OCT_TEAM_INTYPE == 1 || OCT_TEAM_INTYPE == 3
+	if (log2n == 13) return launch_team_rs<13>(rs, logScale, a, stream);  // N = 8192: uint16 rows, everything else comes prepared
 #endif
 	return hipErrorNotSupported;
 }

@@ -53,11 +53,12 @@ template <int LOG2N, int MODE> constexpr int team_lds_bytes() {
 // would also wait for the row prefetch and the image stores in flight)
 OCT_DEV void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// INTYPE: the raw containers the general kernel reads directly (IN_U16, IN_I16, IN_U8, IN_P12U, IN_P12S: kernels.h Chunk)
+// INTYPE: the raw containers the general kernel reads directly (IN_U16, IN_I16, IN_U8, IN_P12U, IN_P12S: kernels.h Chunk) or
+// IN_F32: float32 rows prepared by oct_prepare[_rows]_kernel (other containers, the rolling average)
 template <int LOG2N, int INTYPE, int RS, int MODE>
 __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const FusedArgs a) {
 	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
-	static_assert(INTYPE == IN_U16 || INTYPE == IN_I16 || INTYPE == IN_U8 || INTYPE == IN_P12U || INTYPE == IN_P12S, "raw rows");
+	static_assert(INTYPE == IN_U16 || INTYPE == IN_I16 || INTYPE == IN_U8 || INTYPE == IN_P12U || INTYPE == IN_P12S || INTYPE == IN_F32, "raw or prepared rows");
 	typedef Team<LOG2N> TM;
 	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3, NB3 = TM::NB3, NBINS = 8;
 	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, FOUR = TM::FOUR;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		for (int i = 0; i < NL; i++) {
 #pragma unroll
 			for (int h = 0; h < SPL / 4; h++) {
-				const float4 f = chunk_to_float<INTYPE>(pre[i], h, shift);
+				const float4 f = chunk_to_float<INTYPE>(pre[i], h, INTYPE == IN_F32 ? 0u : shift);  // prepared rows carry the shift already
 				*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * (L + T * i) + 4 * h]) = f;
 				if constexpr (RS == RS_CUBIC) {
 					if (i == 0 && h == 0 && L == 0) row[ROW_OFF - 1] = f.y;  // n0 = |n1 - 1| mirror tap (cu:284): sample 1 below sample 0
