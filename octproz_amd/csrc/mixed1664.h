@@ -28,6 +28,12 @@
 namespace oct {
 
 constexpr int MR_N = 1664, MR_N1 = 32, MR_N2 = 52, MR_PITCH = 54, MR_WAVES = 8;
+#ifndef MR_NREG_CUBIC
+#define MR_NREG_CUBIC 14   // samples per lane whose tap address + four tap weights live in registers (5 VGPRs each)
+#endif
+#ifndef MR_NREG_LINEAR
+#define MR_NREG_LINEAR 32  // samples per lane whose tap address + fraction live in registers (2 VGPRs each)
+#endif
 constexpr int MR_TABLE_BYTES = MR_N * 4 + MR_N * 8 + MR_N1 * MR_N2 * 8;                 // rho | window*phasor | W_1664^{n2 k1}
 constexpr int MR_SLICE_BYTES = MR_N1 * MR_PITCH * 8;                                    // T[32][54] complex >= the staged row
 constexpr int MR_LDS_BYTES = MR_TABLE_BYTES + MR_WAVES * MR_SLICE_BYTES;
@@ -184,6 +190,32 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 			meanR[d] = a.subtractMean ? a.meanLine[k1 + 32 * (h ? mr::k2_kept(1, d) : mr::k2_kept(0, d))] * mr::kept_sign(d, sg) : f2{0.0f, 0.0f};
 	}
 
+	// The kernel needs ~180 of the 256 VGPRs its two waves per SIMD may use.  The spare ones hold, for the FIRST MR_NREG of the 32
+	// samples a lane gathers (the same sample indices for every A-scan of the persistent wave), what the loop would otherwise
+	// recompute per A-scan: the LDS address of tap 0 and -- cubic -- the four Catmull-Rom tap weights (cu:258-271 as weights of
+	// the taps, evaluated once per lane in double: the form of the N = 1024 kernel) resp. -- linear -- the fraction.  Per such
+	// sample: 1 LDS read (rho) and 12 (cubic) / 3 (linear) VALU instructions less.
+	constexpr int NREG = RS == RS_CUBIC ? MR_NREG_CUBIC : RS == RS_LINEAR ? MR_NREG_LINEAR : 0;
+	typedef __attribute__((address_space(3))) const float lds_cfloat;
+	uint32_t tapA[NREG > 0 ? NREG : 1];
+	f32x4 cwR[RS == RS_CUBIC && NREG > 0 ? NREG : 1];
+	float fracR[RS == RS_LINEAR && NREG > 0 ? NREG : 1];
+	if constexpr (NREG > 0) {
+		const uint32_t tapBase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(row + ROW_OFF - 1));
+#pragma unroll
+		for (int q = 0; q < NREG; q++) {
+			const float rho = a.lut[N2 * q + n2].x;
+			tapA[q] = tapBase + 4u * (uint32_t)(int)rho;  // tap 0 = sample n1 - 1
+			const double p = (double)__builtin_amdgcn_fractf(rho);
+			if constexpr (RS == RS_CUBIC) {
+				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+				cwR[q] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+			} else {
+				fracR[q] = (float)p;
+			}
+		}
+	}
+
 	const unsigned wavesTotal = gridDim.x * (unsigned)MR_WAVES;
 	unsigned line = blockIdx.x * (unsigned)MR_WAVES + (unsigned)wave;
 	const unsigned rowBytes = (unsigned)N * (INTYPE == IN_U16 ? 2u : 4u);
@@ -257,6 +289,14 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 #pragma unroll
 				for (int i = -7; i <= 8; i++) sum += t[i] * w[(i + 7) >> 2][(i + 7) & 3];  // the order of cu:315-321
 				y = sum;
+			} else if (q < NREG) {  // (a constant after unrolling) tap address and weights / fraction from registers
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q < NREG ? q : 0]);
+				if constexpr (RS == RS_CUBIC) {
+					const f32x4 cw = cwR[q < NREG ? q : 0];
+					y = __builtin_fmaf(cw.w, t[3], __builtin_fmaf(cw.z, t[2], __builtin_fmaf(cw.y, t[1], cw.x * t[0])));
+				} else {
+					y = t[1] + (t[2] - t[1]) * fracR[q < NREG ? q : 0];
+				}
 			} else {
 				const float rho = rhoL[j];
 				const int n1 = (int)rho;

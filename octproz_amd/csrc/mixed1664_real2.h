@@ -20,6 +20,12 @@
 namespace oct {
 
 constexpr int MR2_PAD = 16;
+#ifndef MR2_NREG_CUBIC
+#define MR2_NREG_CUBIC 6    // samples per lane with tap address + four window-weighted tap weights in registers (5 VGPRs each)
+#endif
+#ifndef MR2_NREG_LINEAR
+#define MR2_NREG_LINEAR 18  // samples per lane with tap address + (fraction, window) in registers (3 VGPRs each)
+#endif
 constexpr int MR2_TABLE_BYTES = MR_N * 4 + MR_N * 4 + MR_N1 * MR_N2 * 8;  // rho | window | W_1664^{n2 k1}
 constexpr int MR2_LDS_BYTES = MR2_TABLE_BYTES + MR_WAVES * MR_SLICE_BYTES;
 static_assert((MR_N + 2 * ROW_OFF) * 8 <= MR_SLICE_BYTES, "the two interleaved rows fit the slice");
@@ -77,6 +83,29 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_real2_kernel(c
 	const float sA = LOGSCALE ? a.sA : 0.5f * a.sA, sB = LOGSCALE ? a.sB - 2.0f * a.sA : a.sB;
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 
+	// spare VGPRs (the kernel needs ~200 of 256): tap address + the four tap weights with the (real) window folded in, resp. the
+	// fraction and the window, of the first NREG samples of the lane -- see mixed1664.h
+	constexpr int NREG = RS == RS_CUBIC ? MR2_NREG_CUBIC : RS == RS_LINEAR ? MR2_NREG_LINEAR : 0;
+	typedef __attribute__((address_space(3))) const f2 lds_cf2;
+	uint32_t tapA[NREG > 0 ? NREG : 1];
+	f32x4 cwR[RS == RS_CUBIC && NREG > 0 ? NREG : 1];
+	f2 fwR[RS == RS_LINEAR && NREG > 0 ? NREG : 1];  // (fraction, window)
+	if constexpr (NREG > 0) {
+		const uint32_t tapBase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) f2*)(rowp + ROW_OFF - 1));
+#pragma unroll
+		for (int q = 0; q < NREG; q++) {
+			const float4 t = a.lut[N2 * q + n2];
+			tapA[q] = tapBase + 8u * (uint32_t)(int)t.x;  // tap 0 = element n1 - 1 of the interleaved rows
+			const double p = (double)__builtin_amdgcn_fractf(t.x), wn = (double)(t.y * t.z);
+			if constexpr (RS == RS_CUBIC) {
+				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+				cwR[q] = f32x4{(float)(wn * w0), (float)(wn * (1.0 - w0 - w2 - w3)), (float)(wn * w2), (float)(wn * w3)};
+			} else {
+				fwR[q] = f2{(float)p, t.y * t.z};
+			}
+		}
+	}
+
 	const unsigned numPairs = (a.numLines + 1u) / 2u, pairsStride = gridDim.x * (unsigned)MR_WAVES;
 	unsigned pi = blockIdx.x * (unsigned)MR_WAVES + (unsigned)wave;
 	u32x2 pre[2 * NL];  // chunk c of row r: samples 256 c + 4 lane .. + 3 (7 x 256 >= 1664: reads past the row give 0)
@@ -119,6 +148,16 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_real2_kernel(c
 			f2 y;
 			if constexpr (RS == RS_NONE) {
 				y = rowp[ROW_OFF + j];
+			} else if (q < NREG) {  // (a constant after unrolling)
+				lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[q < NREG ? q : 0]);
+				if constexpr (RS == RS_CUBIC) {
+					const f32x4 cw = cwR[q < NREG ? q : 0];  // window folded in: no multiply after the gather
+					v[q] = t[3] * cw.w + (t[2] * cw.z + (t[1] * cw.y + t[0] * cw.x));
+				} else {
+					const f2 fw = fwR[q < NREG ? q : 0];
+					v[q] = (t[1] + (t[2] - t[1]) * fw.x) * fw.y;
+				}
+				continue;
 			} else {
 				const float rho = rhoL[j];
 				const int n1 = (int)rho;

@@ -119,7 +119,7 @@ def _expected_images(p, raws_dev):
 
 
 # measured on the pool's boxes (profiles/r3*_streaming_checked.json); floors = a margin under the slowest box seen
-FLOORS = {("preloaded", "float"): 12e6, ("ram", "float"): 7e6, ("ram", "float+u16"): 5e6}
+FLOORS = {("preloaded", "float"): 10e6, ("ram", "float"): 7e6, ("ram", "float+u16"): 5e6}
 
 
 @pytest.mark.parametrize("mode,streams", [("preloaded", "float"), ("ram", "float"), ("ram", "float+u16")])
