@@ -24,9 +24,12 @@ pytestmark = pytest.mark.gpu
 LENGTHS = [256, 512, 1024, 1024, 2048, 2048, 1664, 1664, 1000, 4096]  # the benchmark lengths drawn more often
 
 
-def draw(seed):
-    rng = np.random.default_rng(1000 + seed)
-    N = int(rng.choice(LENGTHS))
+TEAM_LENGTHS = [4096, 8192]  # one A-scan per team of waves (team_kernel.h); N = 8192 falls back to the library route per variant
+
+
+def draw(seed, lengths=LENGTHS, offset=1000):
+    rng = np.random.default_rng(offset + seed)
+    N = int(rng.choice(lengths))
     A = int(rng.integers(3, 41))
     B = int(rng.integers(1, 5))
     p = v180_benchmark_params(N, A, B)
@@ -79,10 +82,20 @@ def draw(seed):
     return p, raw, what
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_TEAM_SEEDS", "32"))))
+def test_random_setting_combination_on_the_team_lengths(seed):
+    """the same draws restricted to N = 4096 / 8192: team kernel for the plain variants (every container at 4096; prepared rows
+    at 8192), one-wave kernel / library route for Lanczos and the rolling average, spectrum output through the other route"""
+    _check_draw(*draw(seed, TEAM_LENGTHS, 7000))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SEEDS", "96"))))  # OCT_FUZZ_SEEDS=1000 for a longer hunt
 def test_random_setting_combination_matches_oracle(seed):
+    _check_draw(*draw(seed))
+
+
+def _check_draw(p, raw, what):
     import torch
-    p, raw, what = draw(seed)
     o = common.make_oracle(p)
     want = o.process(raw)
     pipe = Pipeline(p, device=0)
@@ -93,17 +106,36 @@ def test_random_setting_combination_matches_oracle(seed):
     pipe.synchronize()
     got = pipe.processed_host()
     if p.postProcessBackgroundRemoval:
-        # behind the clamp the image no longer maps back to a power: image-domain bound (the removal itself is checked bit for
-        # bit in test_gpu_side_kernels.py and against the post pass in test_gpu_parity.py)
+        # behind the clamp the image no longer maps back to a power, so the draw is checked in two steps: (1) the same settings
+        # WITHOUT the removal against the oracle with the usual tolerances, (2) the removal stage itself bit for bit: the
+        # oracle's cu:757-767 applied to the GPU's own image of step (1) must give the GPU's image with the removal on
+        # (whether it ran inside the fused store or as the post pass)
+        from oracle import octref
         assert got.min() >= 0.0 and got.max() <= 1.0, what
-        assert np.abs(got.astype(np.float64) - want).max() < 2e-3 * max(1.0, p.signalMultiplicator), what + ": image differs behind the background removal"
-        pipe.close(); o.close()
+        p0 = copy.copy(p)
+        p0.postProcessBackgroundRemoval = 0
+        o0 = common.make_oracle(p0)
+        want0 = o0.process(raw)
+        pipe0 = Pipeline(p0, device=0)
+        if p0.fixedPatternNoiseRemoval:
+            pipe0.set_mean_line(o0.mean_line(), pin=True)
+        pipe0.process_device(d.data_ptr()); pipe0.synchronize()
+        got0 = pipe0.processed_host()
+        q = copy.copy(p0)
+        q.signalMultiplicator, q.signalAddend = 1.0, 0.0
+        unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
+        common.compare_images(unscale(got0), unscale(want0), q, what + " (without the background removal)", mean_line=o0.mean_line())
+        half = int(p.samplesPerLine) // 2
+        expect = octref.postproc_background_removal(got0, np.asarray(p.postProcessBackground, np.float32)[:half], p.postProcessBackgroundWeight,
+                                                    p.postProcessBackgroundOffset, half)
+        assert np.array_equal(got.view(np.uint32), expect.view(np.uint32)), what + ": background removal stage differs from cu:757-767 on the same input"
+        pipe0.close(); o0.close(); pipe.close(); o.close()
         return
     # the tolerances of compare_images are stated for a unit multiplicator: take multiplicator and addend out on both sides
     q = copy.copy(p)
     q.signalMultiplicator, q.signalAddend = 1.0, 0.0
     unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
-    common.compare_images(unscale(got), unscale(want), q, what)
+    common.compare_images(unscale(got), unscale(want), q, what, mean_line=o.mean_line())
     # the second buffer through the same handle (tables resident, slot logic) gives the same image
     pipe.process_device(d.data_ptr())
     pipe.synchronize()
@@ -139,6 +171,19 @@ def test_settings_changed_between_buffers(seed):
     import torch
     rng = np.random.default_rng(5000 + seed)
     N = int(rng.choice([512, 1024, 1024, 2048, 1664, 1000]))
+    _settings_sequence(seed, rng, N)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_TEAM_SEQUENCES", "6"))))
+def test_settings_changed_between_buffers_on_the_team_lengths(seed):
+    """the same at N = 4096 / 8192, where a changed setting can move the handle between the team kernel, the one-wave kernel
+    and the library route from one buffer to the next"""
+    rng = np.random.default_rng(9000 + seed)
+    _settings_sequence(seed, rng, int(rng.choice(TEAM_LENGTHS)))
+
+
+def _settings_sequence(seed, rng, N):
+    import torch
     A, B = int(rng.integers(27, 40)), int(rng.integers(1, 3))
     p = v180_benchmark_params(N, A, B)
     p.buffersPerVolume = int(rng.integers(1, 4))
@@ -165,6 +210,6 @@ def test_settings_changed_between_buffers(seed):
         what = "seed %d step %d: N=%d rs=%d/%d win=%d/%d disp=%d roll=%d/%d fpn=%d log=%d flip=%d bpv=%d" % (
             seed, step, N, p.resampling, int(p.resamplingInterpolation), p.windowing, int(p.window), p.dispersionCompensation, p.backgroundRemoval,
             p.rollingAverageWindowSize, p.fixedPatternNoiseRemoval, p.signalLogScaling, p.bscanFlip, p.buffersPerVolume)
-        common.compare_images(pipe.processed_host(), want, p, what)
+        common.compare_images(pipe.processed_host(), want, p, what, mean_line=o.mean_line())
         o.close()
     pipe.close()
