@@ -69,11 +69,12 @@ def compare_images(got, want, p, what="", mean_line=None):
     """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima.
 
     Non-finite values: log scaling maps a power of exactly 0 to -inf (cu:718, no guard).  -inf therefore IS the value
-    "P = 0".  The only way the two sides can legitimately disagree about it is the mean-line subtraction: one side cancels a
-    bin exactly, the other keeps a float32 rounding residue (~1e-14 of the line maximum in power).  So a -inf on one side
-    only is accepted when fixed-pattern-noise removal is on AND the other side's power is below DB_FLOOR x line maximum (the
-    bound under which the dB comparison does not look anyway); a kernel that zeroes a bin the other side sees above that
-    bound fails, and without the subtraction the -inf pattern must be identical.  NaN and +inf: identical pattern always."""
+    "P = 0".  The two sides can legitimately disagree about it where float32 cancels exactly and float64 keeps a residue:
+    in the mean-line subtraction (~1e-14 of the line maximum in power), and in the transform's own butterflies at bins 150 dB
+    under the line maximum (found by the randomised tests: N = 4096, Lanczos, bin 2035 at 4e-16 of the line maximum -- the
+    oracle rounds a float64 DFT, a float32 FFT returns exactly 0 there).  So a -inf on one side only is accepted when the
+    other side's power is below DB_FLOOR x line maximum (the bound under which the dB comparison does not look anyway); a
+    kernel that zeroes a bin the other side sees above that bound fails.  NaN and +inf: identical pattern always."""
     half = int(p.samplesPerLine) // 2
     g = got.reshape(-1, half)
     w = want.reshape(-1, half)
@@ -91,7 +92,6 @@ def compare_images(got, want, p, what="", mean_line=None):
     line_max[line_max == 0] = 1.0
     one_sided = zero_g != zero_w
     if one_sided.any():
-        assert p.fixedPatternNoiseRemoval, what + ": -inf pattern differs although nothing is subtracted"
         residue = np.where(zero_g, pw, pg)[one_sided] / np.broadcast_to(line_max, pw.shape)[one_sided]
         assert residue.max() <= DB_FLOOR, "%s: %d bins are -inf on one side only with up to %.2e of the line maximum on the other (cancellation bound %.0e)" % (
             what, int(one_sided.sum()), float(residue.max()), DB_FLOOR)
@@ -100,7 +100,10 @@ def compare_images(got, want, p, what="", mean_line=None):
     assert max_rel <= POWER_RTOL, "%s: linear-power error %.3e > %.1e" % (what, max_rel, POWER_RTOL)
     max_db = 0.0
     if p.signalLogScaling:
-        strong = np.isfinite(g) & np.isfinite(w) & (pw > DB_FLOOR * line_max)
+        # float32 rounding of the transform grows with its length: beyond N = 4096 the floor moves up with N (at N = 8192 a
+        # bin at 1e-6 of a DC-dominated line maximum carries 0.9 % amplitude error = 0.075 dB, found by the randomised tests)
+        floor = DB_FLOOR * max(1.0, int(p.samplesPerLine) / 4096.0)
+        strong = np.isfinite(g) & np.isfinite(w) & (pw > floor * line_max)
         if mean_line is not None and p.fixedPatternNoiseRemoval:
             m2 = np.abs(np.asarray(mean_line).astype(np.complex128)[:half]) ** 2
             strong &= pw >= CANCEL_FLOOR * m2[None, :]
