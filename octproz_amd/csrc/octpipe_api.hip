@@ -309,7 +309,7 @@ int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, boo
 	if (rc) return rc;
 	f2* work = spectrum ? a.spectrum : h->d_cplx;
 	hipLaunchKernelGGL(oct::oct_lib_gather_kernel, dim3(gridFor(lines * N)), dim3(256), 0, h->stream, reinterpret_cast<const float*>(a.raw), work, a.lut,
-	                   h->N, lines, (size_t)a.linesInBuffer, rs);
+	                   h->N, lines, (size_t)a.linesInBuffer, rs, rs == oct::RS_LANCZOS ? a.lanczosW : nullptr);
 	HIP_TRY(hipGetLastError());
 	int slot = -1;
 	for (int i = 0; i < 2; ++i) if (h->fftPlanBatch[i] == lines) slot = i;

@@ -390,7 +390,9 @@ namespace oct {
 // (cu:1140); here they take the reference's own pass structure -- gather (k-linearisation x window x phasor, cu:213-489) ->
 // batched inverse C2C (hipFFT, bound with dlopen) -> epilogue (cu:567-584, cu:699-741, flip cu:787-807) -- through a complex
 // buffer in HBM.  A completeness route: ~28 B of traffic per sample instead of 4.
-__global__ __launch_bounds__(256) void oct_lib_gather_kernel(const float* samples, f2* out, const float4* lut, int N, size_t lines, size_t linesInBuffer, int rs) {
+// lanczosW: the host's [N][16] table of tap weights (they depend on the sample index only); nullptr = evaluate them here
+__global__ __launch_bounds__(256) void oct_lib_gather_kernel(const float* samples, f2* out, const float4* lut, int N, size_t lines, size_t linesInBuffer, int rs,
+                                                             const float* lanczosW) {
 	const size_t total = lines * (size_t)N, S = linesInBuffer * (size_t)N;
 	for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
 		const size_t line = idx / (size_t)N;
@@ -414,13 +416,24 @@ __global__ __launch_bounds__(256) void oct_lib_gather_kernel(const float* sample
 			if (off > (long long)S - 9) off = (long long)S - 9;
 			const int n0 = (int)L.x;
 			float sum = 0.0f;
-			for (int i = -7; i <= 8; i++) {
-				const long long gi = off + n0 + i;
-				const float t = (gi >= 0 && gi < (long long)S) ? samples[gi] : 0.0f;
-				const float x = L.x - (float)(n0 + i), ax = fabsf(x);
-				const float PI_F = 3.141592654f, PI_OVER_8 = 0.3926990817f;
-				const float k = (ax < 0.00001f) ? 1.0f : (sinf(PI_F * ax) / (PI_F * ax)) * (sinf(PI_OVER_8 * ax) / (PI_OVER_8 * ax));
-				sum += t * k;
+			if (lanczosW) {  // 32 sinf per sample and A-scan replaced by four 16-byte loads from an L2-resident table
+				const f32x4* wq = reinterpret_cast<const f32x4*>(lanczosW) + (size_t)j * 4;
+				const f32x4 w[4] = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+				for (int i = -7; i <= 8; i++) {
+					const long long gi = off + n0 + i;
+					const float t = (gi >= 0 && gi < (long long)S) ? samples[gi] : 0.0f;
+					sum += t * w[(i + 7) >> 2][(i + 7) & 3];
+				}
+			} else {
+				for (int i = -7; i <= 8; i++) {
+					const long long gi = off + n0 + i;
+					const float t = (gi >= 0 && gi < (long long)S) ? samples[gi] : 0.0f;
+					const float x = L.x - (float)(n0 + i), ax = fabsf(x);
+					const float PI_F = 3.141592654f, PI_OVER_8 = 0.3926990817f;
+					const float k = (ax < 0.00001f) ? 1.0f : (sinf(PI_F * ax) / (PI_F * ax)) * (sinf(PI_OVER_8 * ax) / (PI_OVER_8 * ax));
+					sum += t * k;
+				}
 			}
 			y = sum;
 		}
