@@ -74,6 +74,9 @@ hipError_t launch_team_in3(int log2n, int rs, bool logScale, const FusedArgs& a,
 hipError_t launch_team_in4(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 hipError_t launch_team_in5(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 hipError_t launch_team_in6(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
+// N = 4096 / uint16 / no dispersion compensation: two A-scans per team transform (team_real2_kernel.h); same twiddle table
+bool team_real2_supported(int log2n);
+hipError_t launch_team_real2(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 inline hipError_t launch_team(int log2n, int intype, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	switch (intype) {
 	case IN_U8: return launch_team_in0(log2n, rs, logScale, a, stream);

@@ -541,6 +541,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		b.sA = a.sA;
 		b.sB = a.sB;
 		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
+	} else if (h->d_twTeam && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
+	           !p.dispersionCompensation && !(h->route & (OCTPIPE_ROUTE_NO_TEAM | OCTPIPE_ROUTE_NO_REAL_INPUT))) {
+		// N = 4096, real FFT input (the reference's default: no dispersion compensation): two A-scans per team transform
+		a.twiddle = h->d_twTeam;
+		HIP_TRY(oct::launch_team_real2(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->d_twTeam && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
 	           !(h->route & OCTPIPE_ROUTE_NO_TEAM) && (p.dispersionCompensation || intype != oct::IN_U16 || !oct::real2n_supported(h->log2n))) {
 		// N = 4096: one A-scan per team of four waves, lane-invariant tables in registers (team_kernel.h); every raw container

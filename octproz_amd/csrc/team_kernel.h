@@ -33,14 +33,18 @@
 
 namespace oct {
 
+#ifndef OCT_TEAM_PAD
+#define OCT_TEAM_PAD 1  // pad elements per 16 of the exchange buffer: element e at e + PAD (e >> 4)
+#endif
 template <int LOG2N> struct Team {
+	static constexpr int PAD = OCT_TEAM_PAD;
 	static_assert(LOG2N >= 11 && LOG2N <= 13, "N / 16 lanes per A-scan: two, four or eight waves");
 	static constexpr bool FOUR = LOG2N == 13;  // four passes: 16 x 16 x 16 x 2
 	static constexpr int N = 1 << LOG2N, P = 16, LANES = N / 16, R3 = FOUR ? 16 : N / 256, NB3 = 16 / R3;
 	static constexpr int ROW_BYTES = ((N + 2 * ROW_OFF) * 4 + 15) & ~15;
-	static constexpr int X_BYTES = (N + N / 16) * 8;
+	static constexpr int X_BYTES = (N + PAD * N / 16) * 8;
 	static constexpr int MEAN_BYTES = FOUR ? N * 4 : 0;  // N / 2 complex bins in LDS instead of registers
-	static constexpr int PITCH = LANES + LANES / 16;  // strided read: element L + LANES q at rb[PITCH q]
+	static constexpr int PITCH = LANES + PAD * LANES / 16;  // strided read: element L + LANES q at rb[PITCH q]
 	// twiddle table of this plan in FusedArgs::twiddle: [t-1][k] for pass 2 (15 x 16), then [t-1][k] for pass 3 ((R3 - 1) x 256,
 	// angle 2 pi t k / (256 R3)), then (FOUR) [k] for pass 4 (4096, angle 2 pi k / N)
 	static constexpr int TW_PASS3 = 15 * 16, TW_PASS4 = TW_PASS3 + (R3 - 1) * 256, TW_COUNT = TW_PASS4 + (FOUR ? 4096 : 0);
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 #pragma unroll
 			for (int m = 0; m < NB3; m++) mreg[m + NB3 * u] = a.subtractMean ? a.meanLine[L + T * m + 256 * u] : f2{0.0f, 0.0f};
 	}
-	f2* wb3 = xbuf + (4352 * (L >> 8) + (L & 255) + ((L & 255) >> 4));  // FOUR: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[272 u]
+	constexpr int PD = TM::PAD, S16 = 16 + PD, S256 = 256 + 16 * PD;
+	f2* wb3 = xbuf + ((4096 + 256 * PD) * (L >> 8) + (L & 255) + PD * ((L & 255) >> 4));  // FOUR: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[S256 u]
 
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (T * SPL);  // chunk = SPL consecutive samples in CB bytes; NL chunks per lane and row
@@ -129,9 +134,9 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 #pragma unroll
 		for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, L * CB, i * T * CB);
 	}
-	const f2* rb = xbuf + (L + (L >> 4));                  // strided read: element L + T q at rb[PITCH q]
-	f2* wb1 = xbuf + 17 * L;                               // pass 1 output 16 L + u at wb1[u]
-	f2* wb2 = xbuf + (272 * (L >> 4) + (L & 15));          // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[17 u]
+	const f2* rb = xbuf + (L + TM::PAD * (L >> 4));                       // strided read: element L + T q at rb[PITCH q]
+	f2* wb1 = xbuf + (16 + TM::PAD) * L;                                  // pass 1 output 16 L + u at wb1[u]
+	f2* wb2 = xbuf + ((256 + 16 * TM::PAD) * (L >> 4) + (L & 15));        // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[(16 + PAD) u]
 
 	for (; line < a.numLines; line += gridDim.x) {
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141)
@@ -176,8 +181,10 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		// ---- inverse FFT, 16 x 16 x R3
 		__builtin_amdgcn_s_setprio(2);
 		octfft::Dft<16, 1, false>::run(&v[0]);
+#ifndef TEAM_SKIP_W1
 #pragma unroll
 		for (int u = 0; u < 16; u++) wb1[u] = v[u];
+#endif
 		team_barrier();  // first exchange written (and every lane is past its gather: the row may be overwritten)
 #pragma unroll
 		for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
@@ -185,8 +192,10 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		for (int t = 1; t < 16; t++) v[t] = octfft::cmul(v[t], tw2[t - 1]);
 		octfft::Dft<16, 1, false>::run(&v[0]);
 		team_barrier();  // everyone has read the first exchange
+#ifndef TEAM_SKIP_W2
 #pragma unroll
-		for (int u = 0; u < 16; u++) wb2[17 * u] = v[u];
+		for (int u = 0; u < 16; u++) wb2[S16 * u] = v[u];
+#endif
 		team_barrier();  // second exchange written
 #pragma unroll
 		for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 			octfft::Dft<16, 1, false>::run(&v[0]);
 			team_barrier();  // everyone has read the second exchange
 #pragma unroll
-			for (int u = 0; u < 16; u++) wb3[272 * u] = v[u];
+			for (int u = 0; u < 16; u++) wb3[S256 * u] = v[u];
 			team_barrier();  // third exchange written
 #pragma unroll
 			for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
