@@ -238,7 +238,7 @@ enum {
 	OCTPIPE_ROUTE_NO_REAL_INPUT = 1,   /* dispersion compensation off: keep the general kernel instead of the two-A-scans-per-transform kernels */
 	OCTPIPE_ROUTE_NO_FUSED_BG   = 2,   /* post-process background removal always as the post pass (cu:1567), never inside the image store */
 	OCTPIPE_ROUTE_FULL_DISPLAY  = 4,   /* display frames re-extracted from the whole volume for every buffer (cu:1571-1578 literally) */
-	OCTPIPE_ROUTE_NO_TEAM       = 8,   /* samplesPerLine = 4096: keep the one-wave-per-A-scan kernel instead of the four-wave team kernel */
+	OCTPIPE_ROUTE_NO_TEAM       = 8,   /* samplesPerLine = 4096 / 1664: keep the one-wave-per-A-scan kernel instead of the team kernel (8192: the library route) */
 	OCTPIPE_ROUTE_NO_LIBFFT     = 16,  /* creation: Bluestein on the in-register FFT instead of hipFFT for lengths without a fused kernel (<= 2047) */
 	OCTPIPE_ROUTE_FORCE_LIBFFT  = 32,  /* creation: every length through unpack -> gather -> hipFFT -> epilogue (the reference's pass structure) */
 	OCTPIPE_ROUTE_NO_MIXED      = 64   /* creation: samplesPerLine = 1664 without the mixed-radix kernel */

@@ -360,6 +360,19 @@ int uploadMixedTables(octpipe* h) {
 	HIP_TRY(hipMalloc((void**)&h->d_twMixed, sizeof(f2) * tw.size()));
 	HIP_TRY(hipMemcpy(h->d_twMixed, tw.data(), sizeof(f2) * tw.size(), hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void**)&h->d_lutPlain, sizeof(float4) * N));
+	// the two-wave team kernel of the length (team1664_kernel.h, 13 x 16 x 8): [t-1][r] of pass 2, then [t-1][b] of pass 3
+	std::vector<f2> tt((size_t)oct::team1664_twiddle_count());
+	size_t pos = 0;
+	const int radix[2] = {16, 8}, ns[2] = {13, 208};
+	for (int pass = 0; pass < 2; ++pass)
+		for (int t = 1; t < radix[pass]; ++t)
+			for (int k = 0; k < ns[pass]; ++k) {
+				const double ang = 2.0 * 3.14159265358979323846 * (double)t * (double)k / ((double)ns[pass] * radix[pass]);
+				tt[pos++] = f2{(float)cos(ang), (float)sin(ang)};
+			}
+	if (pos != tt.size()) return fail(OCTPIPE_ERR_DEVICE, "team twiddle table size mismatch");
+	HIP_TRY(hipMalloc((void**)&h->d_twTeam, sizeof(f2) * tt.size()));
+	HIP_TRY(hipMemcpy(h->d_twTeam, tt.data(), sizeof(f2) * tt.size(), hipMemcpyHostToDevice));
 	return OCTPIPE_OK;
 }
 
@@ -520,7 +533,13 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		a.twiddle = h->d_twMixed;
 		if (intype == oct::IN_U16 && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT))  // real FFT input: two A-scans per transform
 			HIP_TRY(oct::launch_mixed1664_real2(rs, p.signalLogScaling != 0, a, h->stream));
-		else
+		else if (!spectrum && rs == oct::RS_CUBIC && !(h->route & OCTPIPE_ROUTE_NO_TEAM)) {
+			// cubic: two waves per A-scan, the tap weights of all 13 samples of a lane in registers (team1664_kernel.h; +5 %).  Linear
+			// and no resampling are faster on the one-wave kernel (its 32 fractions per lane fit in registers): measured 354 vs 390 M
+			// and 366 vs 398 M A-scans/s
+			a.twiddle = h->d_twTeam;
+			HIP_TRY(oct::launch_team1664(intype, rs, p.signalLogScaling != 0, a, h->stream));
+		} else
 			HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->bluestein) {
 		oct::BluesteinArgs b{};

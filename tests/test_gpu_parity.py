@@ -735,6 +735,48 @@ def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, 
     pipe.close(); one.close(); o.close()
 
 
+@pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (700, 3)])
+@pytest.mark.parametrize("variant", ["v180", "flip_lin", "bitshift", "rolling", "int32", "no_fpn_bg"])
+def test_team_kernel_of_1664_matches_oracle_and_the_one_wave_kernel(variant, A, B):
+    """N = 1664 with cubic resampling runs one A-scan per team of TWO waves (team1664_kernel.h: plan 13 x 16 x 8, 13 samples per
+    lane, tables in registers); OCTPIPE_ROUTE_NO_TEAM keeps the one-wave mixed-radix kernel (mixed1664.h: 32 x 4 x 13).  Both
+    against the oracle and against each other; uint16 rows and prepared float32 rows (rolling average, 32-bit containers)."""
+    N = 1664
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    {"v180": mutate(),
+     "flip_lin": mutate(bscanFlip=1, signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
+     "bitshift": mutate(bitshift=1),
+     "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),
+     "int32": mutate(bitDepth=32),
+     "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
+                         signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0
+    if p.postProcessBackgroundRemoval:
+        p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=A + B, msb_aligned=bool(p.bitshift))
+    if variant == "int32":
+        raw = (raw.astype(np.float64) / 4095.0 * 2 ** 20).astype(np.uint32)
+    o, pipe, d, want, got = run_both(p, raw)
+    p.postProcessBackgroundUpdated = True
+    one = Pipeline(p, device=0, route=_lib.ROUTE_NO_TEAM)
+    if p.fixedPatternNoiseRemoval:
+        one.set_mean_line(o.mean_line(), pin=True)
+    one.process_device(d.data_ptr()); one.synchronize()
+    ref = one.processed_host()
+    if p.postProcessBackgroundRemoval:
+        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3
+        assert got.min() >= 0.0 and got.max() <= 1.0
+    else:
+        common.compare_images(ref, want, p, "one-wave kernel %s" % variant)
+        common.compare_images(got, want, p, "team kernel %s" % variant)
+        common.compare_images(got, ref, p, "team vs one-wave %s" % variant)
+    assert not np.array_equal(got, ref)  # two different transforms really ran
+    pipe.close(); one.close(); o.close()
+
+
 @pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096, 1664])
 @pytest.mark.parametrize("variant", ["v180", "no_dispersion", "linear_flip", "lanczos", "lin_scale"])
 def test_background_removal_inside_the_fused_store_equals_the_post_pass(N, variant):
