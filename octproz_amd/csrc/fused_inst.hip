@@ -44,9 +44,9 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 template <int INTYPE, int RS, int ROLLBIT>
 hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, hipStream_t st, int* bu) {
 	if (spectrum) return launch_one<INTYPE, RS, ROLLBIT | MODE_SPECTRUM>(a, rb, st, bu);
-	// post-process background removal inside the image store (a.bgTerm set): instantiated for raw uint16 rows without the
-	// in-kernel rolling average; the caller keeps the post pass for everything else
-	if constexpr (INTYPE == IN_U16 && ROLLBIT == 0) {
+	// post-process background removal inside the image store (a.bgTerm set): every container, but not together with the
+	// in-kernel rolling average (the caller keeps the post pass there)
+	if constexpr (ROLLBIT == 0) {
 		if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, rb, st, bu) : launch_one<INTYPE, RS, MODE_BG>(a, rb, st, bu);
 	} else if (a.bgTerm) {
 		return hipErrorInvalidValue;

@@ -45,11 +45,8 @@ hipError_t launch_mixed_real2_mode(bool logScale, const FusedArgs& a, hipStream_
 template <int INTYPE, int RS>
 hipError_t launch_mixed_out(bool spectrum, bool logScale, const FusedArgs& a, hipStream_t st) {
 	if (spectrum) return launch_mixed_one<INTYPE, RS, MODE_SPECTRUM>(a, st);
-	if constexpr (INTYPE == IN_U16) {  // a.bgTerm: post-process background removal inside the image store
-		if (a.bgTerm) return logScale ? launch_mixed_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, st) : launch_mixed_one<INTYPE, RS, MODE_BG>(a, st);
-	} else if (a.bgTerm) {
-		return hipErrorInvalidValue;
-	}
+	// a.bgTerm: post-process background removal inside the image store
+	if (a.bgTerm) return logScale ? launch_mixed_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, st) : launch_mixed_one<INTYPE, RS, MODE_BG>(a, st);
 	if (logScale) return launch_mixed_one<INTYPE, RS, MODE_LOG>(a, st);
 	return launch_mixed_one<INTYPE, RS, 0>(a, st);
 }

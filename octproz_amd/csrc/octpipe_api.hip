@@ -389,24 +389,36 @@ size_t rawBytes(const octpipe* h) {
 }
 
 // Lanczos taps reach 8 samples into the neighbour rows: with the rolling average on, those have to be the corrected samples
+// rolling average on integer samples whose window sums stay below 2^24 (exact in float32, whatever the order): the row kernel
+// (oct_prepare_rows_kernel: one workgroup per row, prefix sums in LDS) applies
+size_t rowsKernelLds(const octpipe* h) { return sizeof(int) * ((size_t)2 * (h->N + h->N / 2 + 2) + 8); }  // two padded arrays (at most one pad word per two samples) + wave totals
+bool rowsKernelApplies(const octpipe* h, int rollingW, size_t count) {
+	const OctPipeParams& p = h->params;
+	const unsigned bits = h->acq.bitDepth > 16 ? 32 : h->acq.bitDepth;
+	const bool integerRows = h->sampleFormat != OCTPIPE_FORMAT_INT32 && h->acq.bitDepth <= 16;
+	const uint64_t maxAbs = bits >= 32 ? 0xffffffffull : (((1ull << bits) - 1ull) >> (p.bitshift ? 4 : 0));
+	return rollingW > 0 && integerRows && 2ull * (uint64_t)rollingW * maxAbs < (1ull << 24) && rowsKernelLds(h) <= 150 * 1024 && count % (size_t)h->N == 0;
+}
+
 bool needsPrepared(const octpipe* h) {
 	// (N = 4096 with the rolling average stays on the one-wave kernel's in-kernel prefix sums: prepared rows + team kernel were
 	// measured at 34 M against its 39 M A-scans/s, the row kernel's three phases take longer than the team kernel itself)
 	const bool lanczos = h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS;
+	// a rolling-average window beyond the fused kernel's prefix-sum range (ROLL_PAD): the row kernel takes any width whose sums
+	// are exact, the in-kernel fallback is the reference's ordered loop (1024 x 512 x 256, W = 300: 6.7 M A-scans/s)
+	const bool wideRoll = h->params.backgroundRemoval != 0 && h->params.rollingAverageWindowSize > oct::ROLL_PAD &&
+	                      rowsKernelApplies(h, h->params.rollingAverageWindowSize, h->S);
 	return h->libfft || h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO ||
-	       (lanczos && h->params.backgroundRemoval != 0);
+	       (lanczos && h->params.backgroundRemoval != 0) || wideRoll;
 }
 
 // unpack (+ rolling average) of `count` samples (whole lines) into a float32 buffer: the "prepared" route and octpipe_debug_unpack
 int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int rollingW) {
 	const OctPipeParams& p = h->params;
-	// rolling average on integer samples whose window sums stay below 2^24 (exact in float32, whatever the order): one
-	// workgroup per row with a prefix-sum array in LDS; everything else: the element-wise kernel with the ordered loop
-	const unsigned bits = h->acq.bitDepth > 16 ? 32 : h->acq.bitDepth;
-	const bool integerRows = h->sampleFormat != OCTPIPE_FORMAT_INT32 && h->acq.bitDepth <= 16;
-	const uint64_t maxAbs = bits >= 32 ? 0xffffffffull : (((1ull << bits) - 1ull) >> (p.bitshift ? 4 : 0));
-	const size_t rowsLds = sizeof(int) * ((size_t)2 * (h->N + h->N / 2 + 2) + 8);  // two padded arrays (at most one pad word per two samples) + wave totals
-	if (rollingW > 0 && integerRows && 2ull * (uint64_t)rollingW * maxAbs < (1ull << 24) && rowsLds <= 150 * 1024 && count % (size_t)h->N == 0) {
+	// rolling average with exact integer window sums: one workgroup per row with a prefix-sum array in LDS; everything else: the
+	// element-wise kernel with the ordered loop
+	const size_t rowsLds = rowsKernelLds(h);
+	if (rowsKernelApplies(h, rollingW, count)) {
 		static std::once_flag ldsOptIn[64];
 		const size_t lines = count / (size_t)h->N;
 		hipError_t e = hipSuccess;
@@ -476,7 +488,9 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		roll = false;
 	}
 	if (bgApplied) *bgApplied = false;
-	if (wantBg && !spectrum && intype == oct::IN_U16 && !roll && (!h->libfft || teamDirect) && (useMixed ? mixedDirect : !h->bluestein)) {
+	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
+	// and the prepared float32 rows; not with the in-kernel rolling average (`roll` still set here), Bluestein or the library route
+	if (wantBg && !spectrum && !roll && (!h->libfft || teamLib) && !h->bluestein) {
 		int rc = ensure((void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
 		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {

@@ -21,10 +21,7 @@ hipError_t launch_team1664_one(const FusedArgs& a, hipStream_t stream) {
 }
 template <int INTYPE, int RS>
 hipError_t launch_team1664_mode(bool logScale, const FusedArgs& a, hipStream_t stream) {
-	if (a.bgTerm) {
-		if constexpr (INTYPE == IN_U16) return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_BG>(a, stream);
-		else return hipErrorInvalidValue;
-	}
+	if (a.bgTerm) return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_BG>(a, stream);
 	return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG>(a, stream) : launch_team1664_one<INTYPE, RS, 0>(a, stream);
 }
 template <int INTYPE>

@@ -28,10 +28,8 @@ hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
 }
 template <int LOG2N, int RS>
 hipError_t launch_team_mode(bool logScale, const FusedArgs& a, hipStream_t stream) {
-	if (a.bgTerm) {  // post-process background removal inside the image store: plain uint16 rows, like the general kernel
-		if constexpr (kIn == IN_U16) return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_BG>(a, stream) : launch_team_one<LOG2N, RS, MODE_BG>(a, stream);
-		else return hipErrorInvalidValue;
-	}
+	if (a.bgTerm)  // post-process background removal inside the image store
+		return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_BG>(a, stream) : launch_team_one<LOG2N, RS, MODE_BG>(a, stream);
 	return logScale ? launch_team_one<LOG2N, RS, MODE_LOG>(a, stream) : launch_team_one<LOG2N, RS, 0>(a, stream);
 }
 template <int LOG2N>

@@ -104,8 +104,9 @@ def test_lanczos_on_raw_rows_equals_the_prepared_route_bitwise(N, A, B, bitshift
 
 @pytest.mark.parametrize("N,W,bits", [(1024, 200, 12), (1024, 256, 12), (2048, 250, 12), (512, 255, 10), (1024, 129, 16), (1024, 300, 12), (4096, 256, 12)])
 def test_rolling_average_wide_windows(N, W, bits):
-    """W <= 256 takes the prefix-sum route whenever 2 W x (largest sample) < 2^24 (12-bit data: always), the ordered float loop
-    otherwise (16-bit data beyond W = 128, W > 256): both must equal the standalone kernel's ordered sum bit for bit"""
+    """W <= 256 takes the in-kernel prefix-sum route whenever 2 W x (largest sample) < 2^24 (12-bit data: always); 16-bit data
+    beyond W = 128 the in-kernel ordered float loop; W > 256 with exact sums the row kernel in front of the fused kernel (the
+    prepared route, which the second run forces for every case): the same image bit for bit"""
     A, B = 24, 2
     rng = np.random.default_rng(W + bits)
     hi = 2 ** bits - 1

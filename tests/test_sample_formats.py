@@ -284,3 +284,52 @@ def test_gpu_decode_with_rolling_average_bit_exact(fmt, N, W, bitshift):
     want = octref.rolling_average(x, W, N, A * B).real.reshape(-1).astype(np.float32)
     assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [256, 1024, 4096, 1664, 8192])
+@pytest.mark.parametrize("kind", ["uint12p", "int12p", "uint8", "int16", "int32", "uint16_rolling"])
+def test_background_removal_in_the_store_for_every_container(N, kind):
+    """cu:757-767 inside the image store (MODE_BG) of the general, team and mixed-radix kernels for every raw container they
+    read and for prepared float32 rows (32-bit samples, the rolling average of the row kernel, N = 256): bit for bit the image
+    of the separate post pass (OCTPIPE_ROUTE_NO_FUSED_BG), which test_gpu_side_kernels.py pins against the oracle."""
+    from octproz_amd import Pipeline, _lib, v180_benchmark_params
+    A, B = 26, 2
+    n = N * A * B
+    rng = np.random.default_rng(N + len(kind))
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    fmt = 0
+    if kind == "uint8":
+        raw = rng.integers(0, 255, n, endpoint=True).astype(np.uint8)
+        p.bitDepth = 8
+    elif kind == "uint16_rolling":
+        raw = rng.integers(0, 4095, n, endpoint=True).astype(np.uint16)
+        p.backgroundRemoval, p.rollingAverageWindowSize = 1, 300  # wider than the in-kernel variant takes: prepared rows
+    else:
+        _, raw = make(kind, n, N)
+        fmt = FORMATS[kind]
+        p.bitDepth = {"int32": 32, "int16": 16}.get(kind, 12)
+        if kind == "int32":
+            raw = (raw >> 12).astype(np.int32)
+    p.signalGrayscaleMax, p.signalGrayscaleMin = 110.0, 20.0
+    p.postProcessBackgroundRemoval = 1
+    p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 0.9, 0.01
+    p.loadPostProcessingBackground(np.linspace(0.0, 0.4, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    d = _dev(raw)
+    imgs, ml = [], None
+    for post_pass in (True, False):
+        p.postProcessBackgroundUpdated = True
+        pipe = Pipeline(p, device=0, sample_format=fmt, route=_lib.ROUTE_NO_FUSED_BG if post_pass else 0)
+        if ml is not None:
+            pipe.set_mean_line(ml, pin=True)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        if ml is None:
+            ml = pipe.mean_line()
+            pipe.set_mean_line(ml, pin=True)
+            pipe.process_device(d.data_ptr()); pipe.synchronize()
+        imgs.append(pipe.processed_host())
+        pipe.close()
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    assert imgs[0].min() >= 0.0 and imgs[0].max() <= 1.0 and imgs[0].max() > imgs[0].min()
