@@ -41,7 +41,7 @@ struct FusedArgs {
 	unsigned ascansPerBscan;
 	int bitshift;
 	int rollingW;            // window half-size of the rolling average (ROLL variants)
-	int rollExact;           // 2 W x (largest sample value) < 2^24: integer window sums equal the reference's float sums
+	int rollExact;           // (host-side rule, kept for the ABI of the argument block) 2 W x (largest sample value) < 2^24: integer window sums equal the reference's float sums
 	int flip;
 	int subtractMean;
 	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
@@ -734,8 +734,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				// row is written once, already corrected.  The division is the exact IEEE quotient: with rc = RN(1/cnt),
 				// q0 = s rc, q = fma(fma(-q0, cnt, s), rc, q0) == RN(s / cnt) for all integer s < 2^24, cnt <= 512 (checked exhaustively,
 				// tests/test_oracle.py), so the result is bit-identical to the ordered float loop.
+				// (Wider windows and sample ranges whose sums are not exact never reach this kernel: the host runs the row kernels
+				// of side_kernels.h in front of the IN_F32 variant instead.)
 				const int W = a.rollingW;
-				if (W <= ROLL_PAD && a.rollExact) {
+				{
 					staged = true;
 					uint32_t* pfx = reinterpret_cast<uint32_t*>(row + N + 2 * ROW_OFF);  // [ROLL_PAD | N | ROLL_PAD]
 					uint32_t base = 0;
@@ -830,25 +832,6 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 		wave_sync_lds();
 
-		// ---- rolling average beyond the prefix-sum range: the reference's float accumulation in index order
-		if constexpr (ROLL) {
-			const int W = a.rollingW;
-			if (W > ROLL_PAD || !a.rollExact) {
-				float* tmp = row + N + 2 * ROW_OFF;  // the prefix array's space: corrected samples, then copied back
-#pragma unroll 1
-				for (int q = 0; q < P; q++) {
-					const int j = lane + 64 * q;
-					const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
-					float sum = 0.0f;
-					for (int t = lo; t <= hi; t++) sum += row[ROW_OFF + t];
-					tmp[j] = row[ROW_OFF + j] - __fdiv_rn(sum, (float)(hi - lo + 1));
-				}
-				wave_sync_lds();
-#pragma unroll 1
-				for (int q = 0; q < P; q++) rowl[64 * q] = tmp[lane + 64 * q];
-				wave_sync_lds();
-			}
-		}
 		if constexpr (RS == RS_CUBIC) {
 			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
 			wave_sync_lds();

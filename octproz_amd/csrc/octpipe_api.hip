@@ -406,8 +406,10 @@ bool needsPrepared(const octpipe* h) {
 	const bool lanczos = h->params.resampling && h->params.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS;
 	// a rolling-average window beyond the fused kernel's prefix-sum range (ROLL_PAD): the row kernel takes any width whose sums
 	// are exact, the in-kernel fallback is the reference's ordered loop (1024 x 512 x 256, W = 300: 6.7 M A-scans/s)
-	const bool wideRoll = h->params.backgroundRemoval != 0 && h->params.rollingAverageWindowSize > oct::ROLL_PAD &&
-	                      rowsKernelApplies(h, h->params.rollingAverageWindowSize, h->S);
+	// ... and window sums that are not exact in float32 (16-bit samples beyond W = 128) keep the reference's ordered loop, which
+	// oct_prepare_rows_ordered_kernel runs over a row in LDS: the fused kernel's rolling average is the prefix-sum route alone
+	const bool wideRoll = h->params.backgroundRemoval != 0 &&
+	                      (h->params.rollingAverageWindowSize > oct::ROLL_PAD || !rowsKernelApplies(h, h->params.rollingAverageWindowSize, h->S));
 	return h->libfft || h->bluestein || h->forcePrepared || h->bytesPerSample != 2 || h->sampleFormat != OCTPIPE_FORMAT_AUTO ||
 	       (lanczos && h->params.backgroundRemoval != 0) || wideRoll;
 }
@@ -425,6 +427,15 @@ int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int
 		std::call_once(ldsOptIn[h->device & 63], [&] { e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
 		HIP_TRY(e);
 		hipLaunchKernelGGL(oct::oct_prepare_rows_kernel<256>, dim3((unsigned)(lines < 4096 ? lines : 4096)), dim3(256), rowsLds, h->stream, d_raw, d_out,
+		                   (int)h->acq.bitDepth, p.bitshift, rollingW, h->N, lines, h->sampleFormat);
+	} else if (rollingW >= 2 && count % (size_t)h->N == 0 && sizeof(float) * ((size_t)h->N + 2 * (size_t)rollingW + 3) <= 150 * 1024) {
+		// window sums that are not exact in float32: the reference's ordered loop, over a row staged in LDS
+		static std::once_flag ldsOptIn[64];
+		const size_t lines = count / (size_t)h->N, lds = sizeof(float) * ((size_t)h->N + 2 * (size_t)rollingW + 3);
+		hipError_t e = hipSuccess;
+		std::call_once(ldsOptIn[h->device & 63], [&] { e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_ordered_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+		HIP_TRY(e);
+		hipLaunchKernelGGL(oct::oct_prepare_rows_ordered_kernel<256>, dim3((unsigned)(lines < 8192 ? lines : 8192)), dim3(256), lds, h->stream, d_raw, d_out,
 		                   (int)h->acq.bitDepth, p.bitshift, rollingW, h->N, lines, h->sampleFormat);
 	} else {
 		hipLaunchKernelGGL(oct::oct_prepare_kernel, dim3(gridFor(count)), dim3(256), 0, h->stream, d_raw, d_out,

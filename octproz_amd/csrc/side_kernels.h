@@ -23,35 +23,77 @@ OCT_DEV float saturate01(float v) { return !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f
 // ------------------------------------------------------------------ input decode to float32 ("prepared" route)
 // unpack (+ rolling average) for uint8 / uint32 containers, the signed / packed formats and everything in front of the
 // Lanczos variant.  format: OCTPIPE_FORMAT_* (0 = by bit depth as the reference cu:109-147; 1/2 packed 12 bit, 3/4/5 signed)
+OCT_DEV float prepare_decode(const void* raw, size_t idx, int bitDepth, int bitshift, int format) {
+	if (format == 1 || format == 2) {
+		// samples 2p, 2p+1 live in bytes 3p .. 3p+2
+		const uint8_t* b = reinterpret_cast<const uint8_t*>(raw) + (idx >> 1) * 3;
+		const uint32_t v = (idx & 1) ? ((uint32_t)b[1] >> 4) | ((uint32_t)b[2] << 4) : (uint32_t)b[0] | (((uint32_t)b[1] & 15u) << 8);
+		if (format == 1) return (float)(bitshift ? (v >> 4) : v);
+		const int sv = (int)(v << 20) >> 20;  // sign-extend 12 bits
+		return (float)(bitshift ? (sv >> 4) : sv);
+	}
+	if (format == 3) { const int v = reinterpret_cast<const int8_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
+	if (format == 4) { const int v = reinterpret_cast<const int16_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
+	if (format == 5) { const int v = reinterpret_cast<const int32_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
+	if (bitDepth <= 8) { uint32_t v = reinterpret_cast<const uint8_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
+	if (bitDepth <= 16) { uint32_t v = reinterpret_cast<const uint16_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
+	uint32_t v = reinterpret_cast<const uint32_t*>(raw)[idx];
+	return bitshift ? (float)((double)v * (1.0 / 4294967296.0)) : __uint2float_rd(v);
+}
 __global__ void oct_prepare_kernel(const void* raw, float* out, int bitDepth, int bitshift, int rollingW, int N, size_t S, int format) {
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < S; i += (size_t)gridDim.x * blockDim.x) {
-		auto get = [&](size_t idx) -> float {
-			if (format == 1 || format == 2) {
-				// samples 2p, 2p+1 live in bytes 3p .. 3p+2
-				const uint8_t* b = reinterpret_cast<const uint8_t*>(raw) + (idx >> 1) * 3;
-				const uint32_t v = (idx & 1) ? ((uint32_t)b[1] >> 4) | ((uint32_t)b[2] << 4) : (uint32_t)b[0] | (((uint32_t)b[1] & 15u) << 8);
-				if (format == 1) return (float)(bitshift ? (v >> 4) : v);
-				const int sv = (int)(v << 20) >> 20;  // sign-extend 12 bits
-				return (float)(bitshift ? (sv >> 4) : sv);
-			}
-			if (format == 3) { const int v = reinterpret_cast<const int8_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
-			if (format == 4) { const int v = reinterpret_cast<const int16_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
-			if (format == 5) { const int v = reinterpret_cast<const int32_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
-			if (bitDepth <= 8) { uint32_t v = reinterpret_cast<const uint8_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
-			if (bitDepth <= 16) { uint32_t v = reinterpret_cast<const uint16_t*>(raw)[idx]; return (float)(bitshift ? (v >> 4) : v); }
-			uint32_t v = reinterpret_cast<const uint32_t*>(raw)[idx];
-			return bitshift ? (float)((double)v * (1.0 / 4294967296.0)) : __uint2float_rd(v);
-		};
-		float x = get(i);
+		float x = prepare_decode(raw, i, bitDepth, bitshift, format);
 		if (rollingW > 0) {
 			const size_t ls = (i / N) * N;
 			const int j = (int)(i - ls);
 			const int lo = max(0, j - rollingW + 1), hi = min(N - 1, j + rollingW);
 			float sum = 0.0f;
-			for (int t = lo; t <= hi; t++) sum += get(ls + t);
+			for (int t = lo; t <= hi; t++) sum += prepare_decode(raw, ls + t, bitDepth, bitshift, format);
 			x = x - __fdiv_rn(sum, (float)(hi - lo + 1));
 		}
 		out[i] = x;
+	}
+}
+
+// The rolling average where the window sums are NOT exact in float32 (32-bit samples, 16-bit samples with wide windows): the
+// result depends on the order of the additions, so every sample keeps the reference's own loop (cu:165-211: index order, one
+// accumulator) -- but over a row that a workgroup has decoded ONCE into LDS instead of 2 W decodes from memory per sample
+// (1024 x 512 x 256, int32, W = 64: 13 M A-scans/s for the whole chain with the kernel above).  A thread owns FOUR consecutive
+// samples: their windows overlap in all but three positions, so every LDS read feeds four accumulators.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void oct_prepare_rows_ordered_kernel(const void* raw, float* out, int bitDepth, int bitshift, int W, int N, size_t lines, int format) {
+	extern __shared__ float prep_f[];  // [W + N + W + 3]: the row with zeros on both sides (x + 0.0f == x for every finite x, so a
+	                                   // clipped window may run over the pad; the divisor below counts the real samples)
+	const int tid = threadIdx.x;
+	float* rowf = prep_f + W;
+	for (size_t line = blockIdx.x; line < lines; line += gridDim.x) {
+		const size_t ls = line * (size_t)N;
+		for (int j = tid; j < N; j += THREADS) rowf[j] = prepare_decode(raw, ls + (size_t)j, bitDepth, bitshift, format);
+		for (int j = tid; j < W + 3; j += THREADS) { prep_f[j < W ? j : 0] = 0.0f; rowf[N + j] = 0.0f; }
+		__syncthreads();
+		for (int j0 = 4 * tid; j0 < N; j0 += 4 * THREADS) {
+			// sample j0 + c sums t = j0 + c - W + 1 .. j0 + c + W in index order; positions left of the row are skipped (a sum that
+			// starts with 0.0f + x is x), positions right of it add 0.0f
+			float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+			const float* w = rowf + (j0 - W + 1);
+			{ const float x = w[0]; s0 += x; }
+			{ const float x = w[1]; s0 += x; s1 += x; }
+			{ const float x = w[2]; s0 += x; s1 += x; s2 += x; }
+			for (int t = 3; t < 2 * W; t++) { const float x = w[t]; s0 += x; s1 += x; s2 += x; s3 += x; }
+			{ const float x = w[2 * W]; s1 += x; s2 += x; s3 += x; }
+			{ const float x = w[2 * W + 1]; s2 += x; s3 += x; }
+			{ const float x = w[2 * W + 2]; s3 += x; }
+			const float s[4] = {s0, s1, s2, s3};
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const int j = j0 + c;
+				if (j < N) {
+					const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
+					out[ls + (size_t)j] = rowf[j] - __fdiv_rn(s[c], (float)(hi - lo + 1));
+				}
+			}
+		}
+		__syncthreads();
 	}
 }
 

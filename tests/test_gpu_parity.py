@@ -133,7 +133,7 @@ def test_rolling_average_prefix_sum_route_is_bit_identical_to_the_ordered_float_
     """W <= 128: the fused kernel takes window sums from an integer prefix-sum array; the standalone
     unpack kernel accumulates floats in index order like cu:165-211.  Full-range uint16 input keeps every
     window sum below 2^24, where both are exact: the two routes must give the same image bit for bit
-    (W = 200 exercises the ordered fallback inside the fused kernel)."""
+    (W = 200 on 16-bit data is beyond that range: ordered loop over a row in LDS, oct_prepare_rows_ordered_kernel, on both runs)."""
     A, B = 24, 2
     rng = np.random.default_rng(W)
     raw = rng.integers(0, 65535, size=(B, A, N), endpoint=True).astype(np.uint16)

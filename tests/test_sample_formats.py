@@ -265,11 +265,12 @@ def test_team_kernel_of_4096_reads_every_raw_container(kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt", ["uint12p", "int12p", "int8", "int16", "int32"])
-@pytest.mark.parametrize("N,W,bitshift", [(1664, 64, 0), (256, 8, 1), (3000, 300, 0)])
+@pytest.mark.parametrize("N,W,bitshift", [(1664, 64, 0), (256, 8, 1), (3000, 300, 0), (512, 1, 0), (512, 2, 0), (510, 3, 1), (1024, 700, 0)])
 def test_gpu_decode_with_rolling_average_bit_exact(fmt, N, W, bitshift):
     """the prepared route's rolling-average DC removal (cu:165-211) for every sample format against the oracle's ordered float
     loop, bit for bit: integer formats whose window sums stay below 2^24 run the row kernel with integer prefix sums
-    (oct_prepare_rows_kernel), int32 and the wide window on 16-bit data the element-wise kernel with the ordered loop"""
+    (oct_prepare_rows_kernel); int32 and the wide window on 16-bit data keep the ordered loop, over a row staged in LDS with four
+    samples per thread (oct_prepare_rows_ordered_kernel; W = 1: the element-wise kernel)"""
     from octproz_amd import Pipeline, v180_benchmark_params
     A, B = 6, 2
     v, raw = make(fmt, N * A * B, 13 + W)
