@@ -109,10 +109,10 @@ __global__ __launch_bounds__(THREADS) void oct_prepare_rows_kernel(const void* r
 	const int per = (N + THREADS - 1) / THREADS;   // thread t scans the contiguous samples [t per, (t + 1) per)
 	const int padPer = (per & 1) ? 0 : per;        // even chunk length: one pad word per chunk makes the lane stride odd (no bank conflicts)
 	auto at = [&](int j) { return padPer ? j + j / padPer : j; };
-	const int span = at(N) + 1;
-	int* val = prep_sh;                   // decoded samples of the row, at(j)
-	int* pfx = prep_sh + span;            // pfx[at(j)] = val[0] + ... + val[j-1], j <= N
-	int* waveTot = pfx + span;            // [THREADS / 64]
+	// ONE array: the decoded samples of the row, turned in place into pfx[at(j)] = x[0] + ... + x[j-1], j <= N (a sample is the
+	// difference of two neighbours again); prepare_rows_lds_ints() is its size
+	int* pfx = prep_sh;
+	int* waveTot = prep_sh + at(N) + 1;   // [THREADS / 64]
 	const int c0 = min(N, tid * per), c1 = min(N, c0 + per);
 	for (size_t line = blockIdx.x; line < lines; line += gridDim.x) {
 		const size_t ls = line * (size_t)N;
@@ -127,26 +127,32 @@ __global__ __launch_bounds__(THREADS) void oct_prepare_rows_kernel(const void* r
 			else if (format == 4) v = reinterpret_cast<const int16_t*>(raw)[idx];
 			else if (bitDepth <= 8) v = reinterpret_cast<const uint8_t*>(raw)[idx];
 			else v = reinterpret_cast<const uint16_t*>(raw)[idx];
-			val[at(j)] = bitshift ? (v >> 4) : v;  // arithmetic shift for the signed formats, logical value for unsigned (v >= 0)
+			pfx[at(j)] = bitshift ? (v >> 4) : v;  // arithmetic shift for the signed formats, logical value for unsigned (v >= 0)
 		}
 		__syncthreads();
 		int s = 0;
-		for (int j = c0; j < c1; j++) s += val[at(j)];
+		for (int j = c0; j < c1; j++) s += pfx[at(j)];
 		// exclusive scan of the chunk sums over the workgroup: DPP scan inside the wave, wave totals through LDS
 		const uint32_t incl = wave_inclusive_scan((uint32_t)s);
 		if ((tid & 63) == 63) waveTot[tid >> 6] = (int)incl;
 		__syncthreads();
 		int run = (int)incl - s;
 		for (int w = 0; w < (tid >> 6); w++) run += waveTot[w];
-		for (int j = c0; j < c1; j++) { pfx[at(j)] = run; run += val[at(j)]; }
+		for (int j = c0; j < c1; j++) { const int v = pfx[at(j)]; pfx[at(j)] = run; run += v; }
 		if (c0 < N && c1 == N) pfx[at(N)] = run;
 		__syncthreads();
 		for (int j = tid; j < N; j += THREADS) {
 			const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
-			out[ls + (size_t)j] = (float)val[at(j)] - __fdiv_rn((float)(pfx[at(hi + 1)] - pfx[at(lo)]), (float)(hi - lo + 1));
+			const int p0 = pfx[at(j)];
+			out[ls + (size_t)j] = (float)(pfx[at(j + 1)] - p0) - __fdiv_rn((float)(pfx[at(hi + 1)] - pfx[at(lo)]), (float)(hi - lo + 1));
 		}
 		__syncthreads();
 	}
+}
+// 32-bit words of LDS the kernel above needs for rows of N samples with `threads` threads
+inline size_t prepare_rows_lds_ints(int N, int threads) {
+	const int per = (N + threads - 1) / threads, padPer = (per & 1) ? 0 : per;
+	return (size_t)(padPer ? N + N / padPer : N) + 1 + (size_t)threads / 64;
 }
 
 // ------------------------------------------------------------------ fixed-pattern-noise estimate (cu:523-565)
