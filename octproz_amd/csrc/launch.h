@@ -68,27 +68,28 @@ hipError_t launch_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t s
 bool team_supported(int log2n);
 int team_twiddle_count(int log2n);
 int team_last_radix(int log2n);
-hipError_t launch_team_in0(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);  // one translation unit per
-hipError_t launch_team_in1(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);  // container (IN_*)
-hipError_t launch_team_in3(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
-hipError_t launch_team_in4(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
-hipError_t launch_team_in5(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
-hipError_t launch_team_in6(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
+hipError_t launch_team_in0(int log2n, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream);  // one translation unit per
+hipError_t launch_team_in1(int log2n, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream);  // container (IN_*)
+hipError_t launch_team_in3(int log2n, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream);
+hipError_t launch_team_in4(int log2n, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream);
+hipError_t launch_team_in5(int log2n, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream);
+hipError_t launch_team_in6(int log2n, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream);
 // N = 4096 / uint16 / no dispersion compensation: two A-scans per team transform (team_real2_kernel.h); same twiddle table
 bool team_real2_supported(int log2n);
 hipError_t launch_team_real2(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 // N = 1664 on a team of two waves (team1664_kernel.h: 13 x 16 x 8); intype IN_U16 or IN_F32; FusedArgs::twiddle = [t-1][r] of pass 2
 // (15 x 13, angle 2 pi t r / 208), then [t-1][b] of pass 3 (7 x 208, angle 2 pi t b / 1664)
 int team1664_twiddle_count();
-hipError_t launch_team1664(int intype, int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
-inline hipError_t launch_team(int log2n, int intype, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+hipError_t launch_team1664(int intype, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream);
+// roll: rolling-average DC removal inside the team (IN_U16 only; W <= ROLL_PAD with exact window sums: the caller's rule)
+inline hipError_t launch_team(int log2n, int intype, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	switch (intype) {
-	case IN_U8: return launch_team_in0(log2n, rs, logScale, a, stream);
-	case IN_U16: return launch_team_in1(log2n, rs, logScale, a, stream);
-	case IN_F32: return launch_team_in3(log2n, rs, logScale, a, stream);
-	case IN_P12U: return launch_team_in4(log2n, rs, logScale, a, stream);
-	case IN_P12S: return launch_team_in5(log2n, rs, logScale, a, stream);
-	case IN_I16: return launch_team_in6(log2n, rs, logScale, a, stream);
+	case IN_U8: return launch_team_in0(log2n, rs, roll, logScale, a, stream);
+	case IN_U16: return launch_team_in1(log2n, rs, roll, logScale, a, stream);
+	case IN_F32: return launch_team_in3(log2n, rs, roll, logScale, a, stream);
+	case IN_P12U: return launch_team_in4(log2n, rs, roll, logScale, a, stream);
+	case IN_P12S: return launch_team_in5(log2n, rs, roll, logScale, a, stream);
+	case IN_I16: return launch_team_in6(log2n, rs, roll, logScale, a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -483,7 +483,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	a.raw = d_raw;
 	// N = 1664: the mixed-radix kernel takes uint16 directly; other containers / formats and the rolling average come prepared
 	const bool useMixed = h->mixed;
-	const bool mixedDirect = useMixed && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
+	// (with the rolling average inside the two-wave team kernel, under the rule of the general kernel: W <= ROLL_PAD, exact sums)
+	const bool rollInKernel = roll && p.rollingAverageWindowSize <= oct::ROLL_PAD && rowsKernelApplies(h, p.rollingAverageWindowSize, h->S);
+	const bool mixedDirect = useMixed && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO &&
+	                         (!roll || (rollInKernel && rs != oct::RS_LANCZOS && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM)));
 	// packed 12-bit rows are decoded inside the fused kernel (1.5 B per sample from HBM) wherever the general kernel runs on
 	// raw rows; the prepared float32 route remains for N = 256, the rolling average, Lanczos and the non-power-of-two lengths
 	const bool packed = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED || h->sampleFormat == OCTPIPE_FORMAT_INT12_PACKED;
@@ -498,7 +501,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	// lengths on the library route that also have a team kernel (N = 8192): everything but Lanczos and the spectrum output runs
 	// on it, plain uint16 rows directly, other containers and the rolling average through the prepared float32 rows
 	const bool teamLib = h->libfft && h->d_twTeam && rs != oct::RS_LANCZOS && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
-	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
+	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && (!roll || rollInKernel);
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
@@ -558,21 +561,23 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	}
 	if (teamLib) {
 		a.twiddle = h->d_twTeam;
-		HIP_TRY(oct::launch_team(h->log2n, intype, rs, p.signalLogScaling != 0, a, h->stream));
+		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->libfft) {
 		int rc = launchLibFft(h, a, rs, spectrum, p.signalLogScaling != 0);
 		if (rc) return rc;
 	} else if (useMixed) {
 		a.lut = h->d_lutPlain;
 		a.twiddle = h->d_twMixed;
-		if (intype == oct::IN_U16 && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT))  // real FFT input: two A-scans per transform
+		if (intype == oct::IN_U16 && !roll && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT))  // real FFT input: two A-scans per transform
 			HIP_TRY(oct::launch_mixed1664_real2(rs, p.signalLogScaling != 0, a, h->stream));
-		else if (!spectrum && rs == oct::RS_CUBIC && !(h->route & OCTPIPE_ROUTE_NO_TEAM)) {
+		else if (!spectrum && (rs == oct::RS_CUBIC || (roll && rs != oct::RS_LANCZOS)) && !(h->route & OCTPIPE_ROUTE_NO_TEAM)) {
 			// cubic: two waves per A-scan, the tap weights of all 13 samples of a lane in registers (team1664_kernel.h; +5 %).  Linear
 			// and no resampling are faster on the one-wave kernel (its 32 fractions per lane fit in registers): measured 354 vs 390 M
 			// and 366 vs 398 M A-scans/s
 			a.twiddle = h->d_twTeam;
-			HIP_TRY(oct::launch_team1664(intype, rs, p.signalLogScaling != 0, a, h->stream));
+			// (`roll` still set: uint16 rows whose rolling average runs inside the team -- every resampling mode then, the one-wave
+			// kernel would need the row kernel in front of it)
+			HIP_TRY(oct::launch_team1664(intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
 		} else
 			HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->bluestein) {
@@ -599,13 +604,13 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		// N = 4096, real FFT input (the reference's default: no dispersion compensation): two A-scans per team transform
 		a.twiddle = h->d_twTeam;
 		HIP_TRY(oct::launch_team_real2(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
-	} else if (h->d_twTeam && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
+	} else if (h->d_twTeam && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && (!roll || intype == oct::IN_U16) && !spectrum &&
 	           !(h->route & OCTPIPE_ROUTE_NO_TEAM) && (p.dispersionCompensation || intype != oct::IN_U16 || !oct::real2n_supported(h->log2n))) {
 		// N = 4096: one A-scan per team of four waves, lane-invariant tables in registers (team_kernel.h); every raw container
 		// the general kernel reads directly (uint16, int16, uint8, packed 12 bit) and the prepared float32 rows (other
-		// containers; the rolling average, which the row kernel has already applied: `roll` is false here)
+		// containers).  `roll` still set here: uint16 rows whose rolling average runs inside the kernel (needsPrepared)
 		a.twiddle = h->d_twTeam;
-		HIP_TRY(oct::launch_team(h->log2n, intype, rs, p.signalLogScaling != 0, a, h->stream));
+		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
 	} else if ((h->log2n == 10 || oct::real2n_supported(h->log2n)) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
 	           !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
 		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform

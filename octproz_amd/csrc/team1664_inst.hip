@@ -20,16 +20,22 @@ hipError_t launch_team1664_one(const FusedArgs& a, hipStream_t stream) {
 	return hipGetLastError();
 }
 template <int INTYPE, int RS>
-hipError_t launch_team1664_mode(bool logScale, const FusedArgs& a, hipStream_t stream) {
+hipError_t launch_team1664_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (roll) {  // rolling average inside the team: uint16 rows, not together with the background removal in the store
+		if constexpr (INTYPE == IN_U16) {
+			if (a.bgTerm) return hipErrorInvalidValue;
+			return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_ROLL>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_ROLL>(a, stream);
+		} else return hipErrorInvalidValue;
+	}
 	if (a.bgTerm) return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_BG>(a, stream);
 	return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG>(a, stream) : launch_team1664_one<INTYPE, RS, 0>(a, stream);
 }
 template <int INTYPE>
-hipError_t launch_team1664_rs(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+hipError_t launch_team1664_rs(int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	switch (rs) {
-	case RS_NONE: return launch_team1664_mode<INTYPE, RS_NONE>(logScale, a, stream);
-	case RS_LINEAR: return launch_team1664_mode<INTYPE, RS_LINEAR>(logScale, a, stream);
-	case RS_CUBIC: return launch_team1664_mode<INTYPE, RS_CUBIC>(logScale, a, stream);
+	case RS_NONE: return launch_team1664_mode<INTYPE, RS_NONE>(roll, logScale, a, stream);
+	case RS_LINEAR: return launch_team1664_mode<INTYPE, RS_LINEAR>(roll, logScale, a, stream);
+	case RS_CUBIC: return launch_team1664_mode<INTYPE, RS_CUBIC>(roll, logScale, a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }
@@ -37,9 +43,9 @@ hipError_t launch_team1664_rs(int rs, bool logScale, const FusedArgs& a, hipStre
 
 int team1664_twiddle_count() { return Team1664::TW_COUNT; }
 
-hipError_t launch_team1664(int intype, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
-	if (intype == IN_U16) return launch_team1664_rs<IN_U16>(rs, logScale, a, stream);
-	if (intype == IN_F32) return launch_team1664_rs<IN_F32>(rs, logScale, a, stream);
+hipError_t launch_team1664(int intype, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (intype == IN_U16) return launch_team1664_rs<IN_U16>(rs, roll, logScale, a, stream);
+	if (intype == IN_F32) return launch_team1664_rs<IN_F32>(rs, roll, logScale, a, stream);
 	return hipErrorInvalidValue;
 }
 

@@ -18,8 +18,8 @@
 //   block of 208 elements at a pitch of 221 (208 = 16 mod 32 would put every second group of 13 lanes on the same banks).
 //   Two exchange buffers: three barriers per A-scan (row staged / first exchange written / second exchange written).
 //
-// Four teams per CU (two waves per SIMD), persistent.  uint16 rows directly, prepared float32 rows (other containers, rolling
-// average) like the other kernels; no / linear / cubic resampling; image output (the spectrum output that the mean-line
+// Four teams per CU (two waves per SIMD), persistent.  uint16 rows directly (with the rolling average inside the team:
+// team_roll_stage), prepared float32 rows (other containers) like the other kernels; no / linear / cubic resampling; image output (the spectrum output that the mean-line
 // estimate needs stays on mixed1664.h, as does Lanczos).
 #pragma once
 #include "team_kernel.h"
@@ -37,7 +37,7 @@ struct Team1664 {
 	// FusedArgs::twiddle: [t-1][r] of pass 2 (15 x 13, angle 2 pi t r / 208), then [t-1][b] of pass 3 (7 x 208, angle 2 pi t b / 1664)
 	static constexpr int TW_PASS3 = 15 * 13, TW_COUNT = TW_PASS3 + 7 * 208;
 };
-template <int MODE> constexpr int team1664_lds_bytes() { return Team1664::FIXED_BYTES + bg_lds_bytes<MODE, Team1664::N>(); }
+template <int MODE> constexpr int team1664_lds_bytes() { return Team1664::FIXED_BYTES + bg_lds_bytes<MODE, Team1664::N>() + ((MODE & 1 /* MODE_ROLL */) ? TEAM_ROLL_BYTES : 0); }
 
 template <int INTYPE, int RS, int MODE>
 __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const FusedArgs a) {
@@ -45,7 +45,9 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 	static_assert(INTYPE == IN_U16 || INTYPE == IN_F32, "raw uint16 or prepared rows");
 	typedef Team1664 TM;
 	constexpr int N = TM::N, T = TM::T, P = TM::P;
-	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0;
+	static_assert(!ROLL || INTYPE == IN_U16, "in-team rolling average: uint16 rows");
+	static_assert((TM::N + 2 * ROLL_PAD) * 4 <= TM::X2_BYTES, "the prefix array borrows the second exchange buffer");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* row = reinterpret_cast<float*>(smem);
 	f2* x2 = reinterpret_cast<f2*>(smem + TM::ROW_BYTES);
@@ -116,7 +118,11 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 	if (line < a.numLines) prefetch(line);
 
 	for (; line < a.numLines; line += gridDim.x) {
-		// ---- stage the raw row as float32 (cu:119-121 / 139-141)
+		// ---- stage the raw row as float32 (cu:119-121 / 139-141), minus the rolling average (cu:165-211; team_kernel.h)
+		if constexpr (ROLL) {
+			team_roll_stage<T, N, NL>(pre, shift, a.rollingW, reinterpret_cast<uint32_t*>(x2),
+			                          reinterpret_cast<uint32_t*>(smem + team1664_lds_bytes<MODE>() - TEAM_ROLL_BYTES), row, L, RS == RS_CUBIC);
+		} else
 #pragma unroll
 		for (int i = 0; i < NL; i++) {
 			const float4 f = chunk_to_float<INTYPE>(pre[i], 0, INTYPE == IN_F32 ? 0u : shift);  // prepared rows carry the shift already

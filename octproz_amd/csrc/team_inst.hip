@@ -27,17 +27,23 @@ hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
 	return hipGetLastError();
 }
 template <int LOG2N, int RS>
-hipError_t launch_team_mode(bool logScale, const FusedArgs& a, hipStream_t stream) {
+hipError_t launch_team_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (roll) {  // rolling average inside the team: uint16 rows, not together with the background removal in the store
+		if constexpr (kIn == IN_U16 && LOG2N >= 12) {
+			if (a.bgTerm) return hipErrorInvalidValue;
+			return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL>(a, stream);
+		} else return hipErrorInvalidValue;
+	}
 	if (a.bgTerm)  // post-process background removal inside the image store
 		return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_BG>(a, stream) : launch_team_one<LOG2N, RS, MODE_BG>(a, stream);
 	return logScale ? launch_team_one<LOG2N, RS, MODE_LOG>(a, stream) : launch_team_one<LOG2N, RS, 0>(a, stream);
 }
 template <int LOG2N>
-hipError_t launch_team_rs(int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+hipError_t launch_team_rs(int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	switch (rs) {
-	case RS_NONE: return launch_team_mode<LOG2N, RS_NONE>(logScale, a, stream);
-	case RS_LINEAR: return launch_team_mode<LOG2N, RS_LINEAR>(logScale, a, stream);
-	case RS_CUBIC: return launch_team_mode<LOG2N, RS_CUBIC>(logScale, a, stream);
+	case RS_NONE: return launch_team_mode<LOG2N, RS_NONE>(roll, logScale, a, stream);
+	case RS_LINEAR: return launch_team_mode<LOG2N, RS_LINEAR>(roll, logScale, a, stream);
+	case RS_CUBIC: return launch_team_mode<LOG2N, RS_CUBIC>(roll, logScale, a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }
@@ -45,13 +51,13 @@ hipError_t launch_team_rs(int rs, bool logScale, const FusedArgs& a, hipStream_t
 
 #define OCT_CAT2(a, b) a##b
 #define OCT_CAT(a, b) OCT_CAT2(a, b)
-hipError_t OCT_CAT(launch_team_in, OCT_TEAM_INTYPE)(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+hipError_t OCT_CAT(launch_team_in, OCT_TEAM_INTYPE)(int log2n, int rs, bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
 #if defined(OCT_TEAM11) && OCT_TEAM11
-	if (log2n == 11) return launch_team_rs<11>(rs, logScale, a, stream);
+	if (log2n == 11) return launch_team_rs<11>(rs, roll, logScale, a, stream);
 #endif
-	if (log2n == 12) return launch_team_rs<12>(rs, logScale, a, stream);
+	if (log2n == 12) return launch_team_rs<12>(rs, roll, logScale, a, stream);
 #if OCT_TEAM_INTYPE == 1 || OCT_TEAM_INTYPE == 3
-	if (log2n == 13) return launch_team_rs<13>(rs, logScale, a, stream);  // N = 8192: uint16 rows, everything else comes prepared
+	if (log2n == 13) return launch_team_rs<13>(rs, roll, logScale, a, stream);  // N = 8192: uint16 rows, everything else comes prepared
 #endif
 	return hipErrorNotSupported;
 }

@@ -49,13 +49,85 @@ template <int LOG2N> struct Team {
 	// angle 2 pi t k / (256 R3)), then (FOUR) [k] for pass 4 (4096, angle 2 pi k / N)
 	static constexpr int TW_PASS3 = 15 * 16, TW_PASS4 = TW_PASS3 + (R3 - 1) * 256, TW_COUNT = TW_PASS4 + (FOUR ? 4096 : 0);
 };
+constexpr int TEAM_ROLL_BYTES = 256;  // wave totals of the in-team rolling average: [chunk][wave], at most 4 x 16
 template <int LOG2N, int MODE> constexpr int team_lds_bytes() {
-	return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + Team<LOG2N>::MEAN_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>();
+	return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + Team<LOG2N>::MEAN_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>() + ((MODE & 1 /* MODE_ROLL */) ? TEAM_ROLL_BYTES : 0);
 }
 
 // LDS traffic of the team's waves is ordered by s_barrier; only the LDS counter is drained in front of it (a __syncthreads()
 // would also wait for the row prefetch and the image stores in flight)
 OCT_DEV void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Rolling-average DC removal (cu:165-211) inside a team, uint16 rows: the prefix-sum route of the general kernel (kernels.h:
+// integer window sums are the reference's float sums while 2 W x (largest sample) < 2^24, W <= ROLL_PAD -- the host sends
+// everything else through the row kernels) with the scan carried across the waves of the team.  Lane L holds the raw chunks
+// i < NL = samples 4 (T i + L) .. + 3.  Wave scan per chunk (DPP), wave totals through `waveTot`, barrier; every lane adds the
+// totals in front of it, writes its four inclusive prefix values per chunk to `pfx` ([ROLL_PAD | N | ROLL_PAD] with 0 in front
+// and the row total behind, so a clipped window needs no clamp), barrier; window sum = P[j + W] - P[j - W], exact IEEE quotient
+// (two FMAs with RN(1 / 2 W) where the window is whole; a true division in the wave-uniform edge slots), corrected samples to
+// `row`.  `pfx` may alias an exchange buffer: the first barrier here is behind every read of the previous A-scan.
+template <int T, int N, int NL>
+OCT_DEV void team_roll_stage(const u32x4 (&pre)[NL], uint32_t shift, int W, uint32_t* pfx, uint32_t* waveTot, float* row, int L, bool mirrorTap) {
+	constexpr int WAVES = T / 64;
+	static_assert(ROLL_PAD == 256, "pad writes: four entries per lane of the first wave");
+	asm volatile("" : "+v"(L));  // the addresses below are recomputed per A-scan: as loop invariants they would cost the kernel registers it does not have
+	const int wave = __builtin_amdgcn_readfirstlane(L >> 6);
+	uint32_t incl[NL];
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		const uint4 x = chunk_to_uint(pre[i], 0, shift);
+		incl[i] = wave_inclusive_scan(x.x + x.y + x.z + x.w);
+		if ((L & 63) == 63) waveTot[i * WAVES + wave] = incl[i];
+	}
+	team_barrier();  // wave totals written; every lane is past the previous A-scan's exchange reads
+	uint32_t run = 0;
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		uint32_t base = run;
+#pragma unroll
+		for (int w = 0; w < WAVES; w++) {
+			const uint32_t t = waveTot[i * WAVES + w];
+			base += w < wave ? t : 0u;
+			run += t;
+		}
+		const uint4 x = chunk_to_uint(pre[i], 0, shift);  // (recomputed: cheaper than live registers)
+		const uint32_t p0 = base + incl[i] - (x.y + x.z + x.w), p1 = p0 + x.y, p2 = p1 + x.z;
+		if ((i + 1) * 4 * T <= N + ROLL_PAD || 4 * (T * i + L) < N + ROLL_PAD)  // (N = 1664: the last chunk is partial; past the row x = 0 and the value is the total)
+			*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + 4 * (T * i + L)]) = uint4{p0, p1, p2, p2 + x.w};
+	}
+	if (L < 64) {
+		*reinterpret_cast<uint4*>(&pfx[4 * L]) = uint4{0u, 0u, 0u, 0u};
+		*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + N + 4 * L]) = uint4{run, run, run, run};
+	}
+	team_barrier();  // prefix array complete
+	const uint32_t* hiP = pfx + ROLL_PAD + 4 * L + W;  // P[j + W]
+	const uint32_t* loP = pfx + ROLL_PAD + 4 * L - W;  // P[j - W]
+	const float cntIn = (float)(2 * W), rcIn = __fdiv_rn(1.0f, cntIn);
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		const uint4 x = chunk_to_uint(pre[i], 0, shift);
+		const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+		const int jmin = 4 * (T * i + 64 * wave);  // the wave's samples of this chunk: jmin .. jmin + 255
+		const bool edge = jmin < W || jmin + 255 + W > N - 1;  // wave-uniform: some window of the slot is clipped
+		float o[4];
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			const float sum = (float)(hiP[4 * T * i + c] - loP[4 * T * i + c]);
+			float q;
+			if (edge) {
+				const int j = 4 * (T * i + L) + c;
+				const int lo = max(0, j - W + 1), hi = min(N - 1, j + W);
+				q = __fdiv_rn(sum, (float)(hi - lo + 1));
+			} else {
+				const float q0 = sum * rcIn;
+				q = __builtin_fmaf(__builtin_fmaf(-q0, cntIn, sum), rcIn, q0);  // == RN(sum / cnt), kernels.h
+			}
+			o[c] = (float)xs[c] - q;
+		}
+		if ((i + 1) * 4 * T <= N || 4 * (T * i + L) < N) *reinterpret_cast<float4*>(&row[ROW_OFF + 4 * (T * i + L)]) = float4{o[0], o[1], o[2], o[3]};
+		if (mirrorTap && i == 0 && L == 0) row[ROW_OFF - 1] = o[1];  // n0 = |n1 - 1| mirror tap (cu:284)
+	}
+}
 
 // INTYPE: the raw containers the general kernel reads directly (IN_U16, IN_I16, IN_U8, IN_P12U, IN_P12S: kernels.h Chunk) or
 // IN_F32: float32 rows prepared by oct_prepare[_rows]_kernel (other containers, the rolling average)
@@ -65,7 +137,9 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	static_assert(INTYPE == IN_U16 || INTYPE == IN_I16 || INTYPE == IN_U8 || INTYPE == IN_P12U || INTYPE == IN_P12S || INTYPE == IN_F32, "raw or prepared rows");
 	typedef Team<LOG2N> TM;
 	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3, NB3 = TM::NB3, NBINS = 8;
-	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, FOUR = TM::FOUR;
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, FOUR = TM::FOUR, ROLL = (MODE & MODE_ROLL) != 0;
+	static_assert(!ROLL || INTYPE == IN_U16, "in-team rolling average: uint16 rows");
+	static_assert((N + 2 * ROLL_PAD) * 4 <= TM::X_BYTES, "the prefix array borrows the exchange buffer");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* row = reinterpret_cast<float*>(smem);
 	f2* xbuf = reinterpret_cast<f2*>(smem + TM::ROW_BYTES);
@@ -139,7 +213,11 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	f2* wb2 = xbuf + ((256 + 16 * TM::PAD) * (L >> 4) + (L & 15));        // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[(16 + PAD) u]
 
 	for (; line < a.numLines; line += gridDim.x) {
-		// ---- stage the raw row as float32 (cu:119-121 / 139-141)
+		// ---- stage the raw row as float32 (cu:119-121 / 139-141), minus the rolling average (cu:165-211)
+		if constexpr (ROLL) {
+			team_roll_stage<T, N, NL>(pre, shift, a.rollingW, reinterpret_cast<uint32_t*>(xbuf),
+			                          reinterpret_cast<uint32_t*>(smem + team_lds_bytes<LOG2N, MODE>() - TEAM_ROLL_BYTES), row, L, RS == RS_CUBIC);
+		} else
 #pragma unroll
 		for (int i = 0; i < NL; i++) {
 #pragma unroll

@@ -128,9 +128,12 @@ def test_rolling_average_wide_windows(N, W, bits):
     pipe.close()
 
 
-@pytest.mark.parametrize("N,W", [(1024, 8), (1024, 100), (1024, 128), (1024, 200), (256, 32), (2048, 64)])
+@pytest.mark.parametrize("N,W", [(1024, 8), (1024, 100), (1024, 128), (1024, 200), (256, 32), (2048, 64),
+                                 (4096, 64), (4096, 128), (8192, 100), (1664, 128), (1664, 7)])
 def test_rolling_average_prefix_sum_route_is_bit_identical_to_the_ordered_float_sum(N, W):
-    """W <= 128: the fused kernel takes window sums from an integer prefix-sum array; the standalone
+    """(N = 4096, 8192, 1664: the prefix sums are carried across the waves of a team, team_roll_stage; the prepared rows of the
+    second run go through the same team kernel.)
+    W <= 128: the fused kernel takes window sums from an integer prefix-sum array; the standalone
     unpack kernel accumulates floats in index order like cu:165-211.  Full-range uint16 input keeps every
     window sum below 2^24, where both are exact: the two routes must give the same image bit for bit
     (W = 200 on 16-bit data is beyond that range: ordered loop over a row in LDS, oct_prepare_rows_ordered_kernel, on both runs)."""
@@ -361,7 +364,7 @@ def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
 
 
 @pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (130, 3)])
-@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg"])
+@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg", "rolling", "rolling256_linear"])
 def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B):
     """N = 8192: one A-scan per team of EIGHT waves (team_kernel.h: plan 16 x 16 x 16 x 2, three exchanges fenced with
     s_barrier); OCTPIPE_ROUTE_NO_TEAM keeps the library route (gather -> hipFFT -> epilogue).  Both against the oracle's O(N^2)
@@ -373,6 +376,8 @@ def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B)
      "linear_flip_lin": mutate(resamplingInterpolation=INTERPOLATION.LINEAR, bscanFlip=1, signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
      "none_bitshift": mutate(resampling=0, bitshift=1),
      "no_dispersion": mutate(dispersionCompensation=0),
+     "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),  # inside the team: team_roll_stage
+     "rolling256_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=256, resamplingInterpolation=INTERPOLATION.LINEAR),
      "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
                          signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
     if A * B < 18:
@@ -697,7 +702,7 @@ def test_postprocess_background_record_and_remove():
 
 
 @pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (300, 3)])
-@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg"])
+@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg", "rolling", "rolling256_linear"])
 def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, B):
     """N = 4096 runs one A-scan per team of four waves (team_kernel.h: 16 x 16 x 16 plan, exchanges fenced with s_barrier,
     lane-invariant tables in registers); OCTPIPE_ROUTE_NO_TEAM keeps the one-wave kernel (64 x 16 x 4 plan, LUT through L2).
@@ -710,6 +715,8 @@ def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, 
      "linear_flip_lin": mutate(resamplingInterpolation=INTERPOLATION.LINEAR, bscanFlip=1, signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
      "none_bitshift": mutate(resampling=0, bitshift=1),
      "no_dispersion": mutate(dispersionCompensation=0),
+     "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),  # inside the team: team_roll_stage
+     "rolling256_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=256, resamplingInterpolation=INTERPOLATION.LINEAR),
      "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
                          signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
     if A * B < 18:
@@ -737,7 +744,7 @@ def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, 
 
 
 @pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (700, 3)])
-@pytest.mark.parametrize("variant", ["v180", "flip_lin", "bitshift", "rolling", "int32", "no_fpn_bg"])
+@pytest.mark.parametrize("variant", ["v180", "flip_lin", "bitshift", "rolling", "rolling256_linear", "rolling_none", "int32", "no_fpn_bg"])
 def test_team_kernel_of_1664_matches_oracle_and_the_one_wave_kernel(variant, A, B):
     """N = 1664 with cubic resampling runs one A-scan per team of TWO waves (team1664_kernel.h: plan 13 x 16 x 8, 13 samples per
     lane, tables in registers); OCTPIPE_ROUTE_NO_TEAM keeps the one-wave mixed-radix kernel (mixed1664.h: 32 x 4 x 13).  Both
@@ -748,7 +755,9 @@ def test_team_kernel_of_1664_matches_oracle_and_the_one_wave_kernel(variant, A, 
     {"v180": mutate(),
      "flip_lin": mutate(bscanFlip=1, signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0),
      "bitshift": mutate(bitshift=1),
-     "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),
+     "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),  # inside the team (team_roll_stage); NO_TEAM: row kernel + one-wave kernel
+     "rolling256_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=256, resamplingInterpolation=INTERPOLATION.LINEAR),
+     "rolling_none": mutate(backgroundRemoval=1, rollingAverageWindowSize=5, resampling=0),
      "int32": mutate(bitDepth=32),
      "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
                          signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
