@@ -758,14 +758,23 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					const uint32_t* hiP = pfx + ROLL_PAD + 4 * lane + W;      // P[j + W]
 					const uint32_t* loP = pfx + ROLL_PAD + 4 * lane - W;      // P[j - W]
 					const float cntIn = (float)(2 * W), rcIn = __fdiv_rn(1.0f, cntIn);
+					const bool quad = (W & 3) == 0;  // (uniform) the lane's four P[j +- W] are 16-byte aligned: one ds_read_b128 each
 #pragma unroll
 					for (int i = 0; i < NL; i++) {
 						float o[4];
 						const uint4 x = chunk_to_uint(pre[i], 0, shift);  // (recomputed: cheaper than 16 live registers)
 						const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+						uint32_t ws[4];
+						if (quad) {
+							const uint4 h4 = *reinterpret_cast<const uint4*>(hiP + 256 * i), l4 = *reinterpret_cast<const uint4*>(loP + 256 * i);
+							ws[0] = h4.x - l4.x; ws[1] = h4.y - l4.y; ws[2] = h4.z - l4.z; ws[3] = h4.w - l4.w;
+						} else {
+#pragma unroll
+							for (int c = 0; c < 4; c++) ws[c] = hiP[256 * i + c] - loP[256 * i + c];
+						}
 #pragma unroll
 						for (int c = 0; c < 4; c++) {
-							const float sum = (float)(hiP[256 * i + c] - loP[256 * i + c]);
+							const float sum = (float)ws[c];
 							float cnt = cntIn, rc = rcIn;
 							if (i == NL - 1) { cnt = rollCnt[4 + c]; rc = rollRc[4 + c]; }  // (NL == 1: the single chunk is clipped on both sides,
 							else if (i == 0) { cnt = rollCnt[c]; rc = rollRc[c]; }          //  its counts are the "last chunk" entries)

@@ -103,16 +103,25 @@ OCT_DEV void team_roll_stage(const u32x4 (&pre)[NL], uint32_t shift, int W, uint
 	const uint32_t* hiP = pfx + ROLL_PAD + 4 * L + W;  // P[j + W]
 	const uint32_t* loP = pfx + ROLL_PAD + 4 * L - W;  // P[j - W]
 	const float cntIn = (float)(2 * W), rcIn = __fdiv_rn(1.0f, cntIn);
+	const bool quad = (W & 3) == 0;  // (uniform) the lane's four P[j +- W] are 16-byte aligned: one ds_read_b128 each
 #pragma unroll
 	for (int i = 0; i < NL; i++) {
 		const uint4 x = chunk_to_uint(pre[i], 0, shift);
 		const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+		uint32_t ws[4];
+		if (quad) {
+			const uint4 h4 = *reinterpret_cast<const uint4*>(hiP + 4 * T * i), l4 = *reinterpret_cast<const uint4*>(loP + 4 * T * i);
+			ws[0] = h4.x - l4.x; ws[1] = h4.y - l4.y; ws[2] = h4.z - l4.z; ws[3] = h4.w - l4.w;
+		} else {
+#pragma unroll
+			for (int c = 0; c < 4; c++) ws[c] = hiP[4 * T * i + c] - loP[4 * T * i + c];
+		}
 		const int jmin = 4 * (T * i + 64 * wave);  // the wave's samples of this chunk: jmin .. jmin + 255
 		const bool edge = jmin < W || jmin + 255 + W > N - 1;  // wave-uniform: some window of the slot is clipped
 		float o[4];
 #pragma unroll
 		for (int c = 0; c < 4; c++) {
-			const float sum = (float)(hiP[4 * T * i + c] - loP[4 * T * i + c]);
+			const float sum = (float)ws[c];
 			float q;
 			if (edge) {
 				const int j = 4 * (T * i + L) + c;
