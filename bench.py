@@ -45,7 +45,7 @@ def parse_args(argv=None):
     ap.add_argument("--volumes", type=int, default=4, help="distinct raw buffers rotated (1 GiB > the 256 MiB Infinity Cache)")
     ap.add_argument("--out-slots", type=int, default=4, help="processed-buffer slots rotated (buffersPerVolume; 1 GiB of output > Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the host_loop and real_input records (A/B runs, profiler passes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host_loop, real_input and rolling_average records (A/B runs, profiler passes)")
     ap.add_argument("--host-loop-seconds", type=float, default=3.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
     ap.add_argument("--group", action="store_true",
@@ -402,7 +402,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_fused_kernel<10, 1, 2, 4>",
                                     2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_team_kernel<12, 1, 2, 4>", 8192: "oct_team_kernel<13, 1, 2, 4>",
-                                    1664: "oct_mixed1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)"),
+                                    1664: "oct_team1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)"),
                          "kernel_ms": kernel_ms,
                          "kernel_ms_per_rank": {"min": min(kernel_ms_ranks), "max": max(kernel_ms_ranks), "ranks": kernel_ms_ranks},
                          "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
@@ -425,6 +425,18 @@ def main():
                              "what": "same workload, v1.8.0 settings without dispersion compensation (the reference's default): "
                                      "two A-scans per complex transform"}
         rp.close()
+        # (i') north_star's chain names the rolling background subtraction, which the reference's published benchmark settings
+        # leave off: the same workload with it on (window half-size 64, the GUI's default, sidebar.cpp:189)
+        q = v180_benchmark_params(N, A, B, buffers_per_volume=slots)
+        q.backgroundRemoval, q.rollingAverageWindowSize = 1, 64
+        q.update_all_curves()
+        rp = Pipeline(q, device=local_rank)
+        rp.process_device(vols[0].data_ptr()); rp.synchronize()
+        rdt, rms, rl = timed_run(rp, vols, max(args.steps, 200), 5, min(args.warmup_seconds, 0.5))
+        out["rolling_average"] = {"value": A * B * max(args.steps, 200) / rdt, "unit": "A-scans/s", "kernel_ms": rms,
+                                  "roofline_frac": (4.0 * N * A * B / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rms > 0 else None,
+                                  "what": "same workload, v1.8.0 settings plus the rolling-average DC removal (cu:165-211, W = 64) inside the fused kernel"}
+        rp.close()
         # (ii) the host loop incl. H2D, the reference's own metric definition
         if args.host_loop_seconds > 0:
             try:
@@ -437,7 +449,7 @@ def main():
         out["cpu_baseline"] = None
         out["cpu_baseline_note"] = "timed on rank 0 of the N = 1 run only" if ranks > 1 else "skipped (--no-cpu-baseline)"
         if ranks > 1:
-            out["extras_note"] = "real_input / host_loop records belong to the N = 1 run"
+            out["extras_note"] = "real_input / rolling_average / host_loop records belong to the N = 1 run"
 
     if distributed:
         dist.barrier()
