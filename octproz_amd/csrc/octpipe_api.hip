@@ -391,8 +391,12 @@ size_t rawBytes(const octpipe* h) {
 // Lanczos taps reach 8 samples into the neighbour rows: with the rolling average on, those have to be the corrected samples
 // rolling average on integer samples whose window sums stay below 2^24 (exact in float32, whatever the order): the row kernel
 // (oct_prepare_rows_kernel: one workgroup per row, prefix sums in LDS) applies
-int rowsKernelThreads(const octpipe* h) { return h->N > 4096 ? 512 : 256; }  // long rows: more threads per row; several rows per CU either way
-size_t rowsKernelLds(const octpipe* h) { return sizeof(int) * oct::prepare_rows_lds_ints(h->N, rowsKernelThreads(h)); }
+// rows up to 4096 samples: one WAVE per row (oct_prepare_rows_wave_kernel); longer rows: one workgroup of 512 threads per row
+bool rowsKernelPerWave(const octpipe* h) { return h->N <= 4096; }
+int rowsKernelThreads(const octpipe* h) { return 512; }
+size_t rowsKernelLds(const octpipe* h) {
+	return sizeof(int) * (rowsKernelPerWave(h) ? oct::prepare_rows_wave_lds_ints(h->N) : oct::prepare_rows_lds_ints(h->N, rowsKernelThreads(h)));
+}
 bool rowsKernelApplies(const octpipe* h, int rollingW, size_t count) {
 	const OctPipeParams& p = h->params;
 	const unsigned bits = h->acq.bitDepth > 16 ? 32 : h->acq.bitDepth;
@@ -426,17 +430,18 @@ int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int
 		const size_t lines = count / (size_t)h->N;
 		hipError_t e = hipSuccess;
 		std::call_once(ldsOptIn[h->device & 63], [&] {
-			e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-			if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+			if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 		});
 		HIP_TRY(e);
-		const unsigned grid = (unsigned)(lines < 8192 ? lines : 8192);
-		if (rowsKernelThreads(h) == 512)
-			hipLaunchKernelGGL(oct::oct_prepare_rows_kernel<512>, dim3(grid), dim3(512), rowsLds, h->stream, d_raw, d_out,
+		if (rowsKernelPerWave(h)) {
+			const size_t blocks = (lines + oct::PREP_WAVES - 1) / oct::PREP_WAVES;
+			hipLaunchKernelGGL(oct::oct_prepare_rows_wave_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(oct::PREP_WAVES * 64), rowsLds, h->stream, d_raw, d_out,
 			                   (int)h->acq.bitDepth, p.bitshift, rollingW, h->N, lines, h->sampleFormat);
-		else
-			hipLaunchKernelGGL(oct::oct_prepare_rows_kernel<256>, dim3(grid), dim3(256), rowsLds, h->stream, d_raw, d_out,
+		} else {
+			hipLaunchKernelGGL(oct::oct_prepare_rows_kernel<512>, dim3((unsigned)(lines < 8192 ? lines : 8192)), dim3(512), rowsLds, h->stream, d_raw, d_out,
 			                   (int)h->acq.bitDepth, p.bitshift, rollingW, h->N, lines, h->sampleFormat);
+		}
 	} else if (rollingW >= 2 && count % (size_t)h->N == 0 && sizeof(float) * ((size_t)h->N + 2 * (size_t)rollingW + 3) <= 150 * 1024) {
 		// window sums that are not exact in float32: the reference's ordered loop, over a row staged in LDS
 		static std::once_flag ldsOptIn[64];
