@@ -31,6 +31,10 @@ VARIANTS = [
     ("Lanczos resampling", {"resamplingInterpolation": INTERPOLATION.LANCZOS}),
     ("post-process background removal", {"postProcessBackgroundRemoval": 1, "postProcessBackgroundWeight": 0.9, "postProcessBackgroundOffset": 0.01}),
     ("sinusoidal scan correction", {"sinusoidalScanCorrection": 1}),
+    ("rolling average W=300 (row kernel in front of the fused kernel)", {"backgroundRemoval": 1, "rollingAverageWindowSize": 300}),
+    ("rolling average W=64, linear resampling", {"backgroundRemoval": 1, "rollingAverageWindowSize": 64, "resamplingInterpolation": INTERPOLATION.LINEAR}),
+    ("rolling average W=64 + B-scan flip + sinusoidal correction (north_star's full chain)",
+     {"backgroundRemoval": 1, "rollingAverageWindowSize": 64, "bscanFlip": 1, "sinusoidalScanCorrection": 1}),
 ]
 
 
