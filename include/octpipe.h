@@ -247,6 +247,19 @@ int octpipe_debug_set_route(octpipe_t* h_or_null, unsigned flags);
 /* persistent-grid size (workgroups) of the last launch of the general fused kernel: each kernel variant has its own
  * occupancy-derived grid, whatever was launched before it in the process */
 int octpipe_debug_last_grid(const octpipe_t* h, int* blocks);
+/* which implementation the image launch of the last processed buffer took (tests pin the routing with it: a silent fall-back
+ * to a slower but equally correct path would otherwise go unnoticed) */
+enum {
+	OCTPIPE_PATH_PREPARED_ROWS = 1,   /* a row kernel / unpack kernel wrote float32 rows in front of the transform kernel */
+	OCTPIPE_PATH_FUSED_BG      = 2,   /* post-process background removal inside the image store */
+	OCTPIPE_PATH_TEAM          = 4,   /* one A-scan (or pair) per team of waves: team_kernel.h, team_real2_kernel.h, team1664_kernel.h */
+	OCTPIPE_PATH_REAL_INPUT    = 8,   /* two A-scans per complex transform */
+	OCTPIPE_PATH_LIBRARY_FFT   = 16,  /* gather -> hipFFT -> epilogue */
+	OCTPIPE_PATH_ROLL_IN_KERNEL = 32, /* rolling average inside the transform kernel */
+	OCTPIPE_PATH_MIXED_RADIX   = 64,  /* mixed1664.h / mixed1664_real2.h */
+	OCTPIPE_PATH_BLUESTEIN     = 128
+};
+int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
 
 /* ------------------------------------------------------------------ result delivery
  * cuda_registerStreamingBuffers / cuda_unregisterStreamingBuffers (kernels.h:69-70, cu:659-675)

@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")
 OCTPIPE_OK = 0
 # OCTPIPE_ROUTE_* (include/octpipe.h, octpipe_debug_set_route): keep a configuration on the slower / more general of two routes
 ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED = 1, 2, 4, 8, 16, 32, 64
+# octpipe_debug_last_path (include/octpipe.h OCTPIPE_PATH_*)
+PATH_PREPARED_ROWS, PATH_FUSED_BG, PATH_TEAM, PATH_REAL_INPUT, PATH_LIBRARY_FFT, PATH_ROLL_IN_KERNEL, PATH_MIXED_RADIX, PATH_BLUESTEIN = 1, 2, 4, 8, 16, 32, 64, 128
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE"}
 
 
@@ -94,7 +96,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_process", "octpipe_process_async", "octpipe_wait_input", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
     "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_debug_spectrum",
-    "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_last_grid",
+    "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_last_grid", "octpipe_debug_last_path",
     "octpipe_register_streaming_buffers", "octpipe_unregister_streaming_buffers",
     "octpipe_register_float_streaming_buffers", "octpipe_unregister_float_streaming_buffers",
     "octpipe_set_callbacks",
@@ -205,6 +207,7 @@ def lib():
         L.octpipe_debug_force_prepared.argtypes = [C.c_void_p, C.c_int]
         L.octpipe_debug_set_route.argtypes = [C.c_void_p, C.c_uint]
         L.octpipe_debug_last_grid.argtypes = [C.c_void_p, C.c_void_p]
+        L.octpipe_debug_last_path.argtypes = [C.c_void_p, C.c_void_p]
         L.octhost_system_set_copy_threads.argtypes = [C.c_void_p, C.c_uint]
         L.octhost_usable_cpus.restype = C.c_uint
         L.octpipe_register_streaming_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]

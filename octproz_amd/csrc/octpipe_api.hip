@@ -67,6 +67,7 @@ struct octpipe {
 	int altCur = 0;
 	unsigned route = 0;                // OCTPIPE_ROUTE_* (octpipe_debug_set_route)
 	int lastGrid = 0;
+	unsigned lastPath = 0;  // OCTPIPE_PATH_* of the last image launch
 	bool ownStream = true;
 	hipEvent_t h2dDone[2] = {nullptr, nullptr};   // raw slot filled
 	hipEvent_t slotFree[2] = {nullptr, nullptr};  // fused kernel finished reading the raw slot
@@ -479,6 +480,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	const OctPipeParams& p = h->params;
 	oct::FusedArgs a{};
 	int intype = oct::IN_U16;
+	unsigned path = 0;  // OCTPIPE_PATH_* (octpipe_debug_last_path)
 	bool roll = p.backgroundRemoval != 0;
 	int rs = oct::RS_NONE;
 	if (p.resampling) {
@@ -514,11 +516,13 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		a.raw = h->d_prepared;
 		intype = oct::IN_F32;
 		roll = false;
+		path |= OCTPIPE_PATH_PREPARED_ROWS;
 	}
 	if (bgApplied) *bgApplied = false;
 	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
 	// and the prepared float32 rows; not with the in-kernel rolling average (`roll` still set here), Bluestein or the library route
-	if (wantBg && !spectrum && !roll && (!h->libfft || teamLib) && !h->bluestein) {
+	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
+	if (wantBg && !spectrum && !roll && (!h->libfft || teamLib) && (useMixed || !h->bluestein)) {
 		int rc = ensure((void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
 		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {
@@ -529,6 +533,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		}
 		a.bgTerm = h->d_bgTerm;
 		if (bgApplied) *bgApplied = true;
+		path |= OCTPIPE_PATH_FUSED_BG;
 	}
 	a.out = out;
 	a.spectrum = spectrumOut;
@@ -566,15 +571,19 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	}
 	if (teamLib) {
 		a.twiddle = h->d_twTeam;
+		path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
 		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->libfft) {
+		path |= OCTPIPE_PATH_LIBRARY_FFT;
 		int rc = launchLibFft(h, a, rs, spectrum, p.signalLogScaling != 0);
 		if (rc) return rc;
 	} else if (useMixed) {
 		a.lut = h->d_lutPlain;
 		a.twiddle = h->d_twMixed;
-		if (intype == oct::IN_U16 && !roll && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT))  // real FFT input: two A-scans per transform
+		if (intype == oct::IN_U16 && !roll && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {  // real FFT input: two A-scans per transform
+			path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_REAL_INPUT;
 			HIP_TRY(oct::launch_mixed1664_real2(rs, p.signalLogScaling != 0, a, h->stream));
+		}
 		else if (!spectrum && (rs == oct::RS_CUBIC || (roll && rs != oct::RS_LANCZOS)) && !(h->route & OCTPIPE_ROUTE_NO_TEAM)) {
 			// cubic: two waves per A-scan, the tap weights of all 13 samples of a lane in registers (team1664_kernel.h; +5 %).  Linear
 			// and no resampling are faster on the one-wave kernel (its 32 fractions per lane fit in registers): measured 354 vs 390 M
@@ -582,10 +591,14 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 			a.twiddle = h->d_twTeam;
 			// (`roll` still set: uint16 rows whose rolling average runs inside the team -- every resampling mode then, the one-wave
 			// kernel would need the row kernel in front of it)
+			path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
 			HIP_TRY(oct::launch_team1664(intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
-		} else
+		} else {
+			path |= OCTPIPE_PATH_MIXED_RADIX;
 			HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
+		}
 	} else if (h->bluestein) {
+		path |= OCTPIPE_PATH_BLUESTEIN;
 		oct::BluesteinArgs b{};
 		b.samples = h->d_prepared;
 		b.out = out;
@@ -608,6 +621,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	           !p.dispersionCompensation && !(h->route & (OCTPIPE_ROUTE_NO_TEAM | OCTPIPE_ROUTE_NO_REAL_INPUT))) {
 		// N = 4096, real FFT input (the reference's default: no dispersion compensation): two A-scans per team transform
 		a.twiddle = h->d_twTeam;
+		path |= OCTPIPE_PATH_TEAM | OCTPIPE_PATH_REAL_INPUT;
 		HIP_TRY(oct::launch_team_real2(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->d_twTeam && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && (!roll || intype == oct::IN_U16) && !spectrum &&
 	           !(h->route & OCTPIPE_ROUTE_NO_TEAM) && (p.dispersionCompensation || intype != oct::IN_U16 || !oct::real2n_supported(h->log2n))) {
@@ -615,15 +629,19 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		// the general kernel reads directly (uint16, int16, uint8, packed 12 bit) and the prepared float32 rows (other
 		// containers).  `roll` still set here: uint16 rows whose rolling average runs inside the kernel (needsPrepared)
 		a.twiddle = h->d_twTeam;
+		path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
 		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
 	} else if ((h->log2n == 10 || oct::real2n_supported(h->log2n)) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
 	           !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
 		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
+		path |= OCTPIPE_PATH_REAL_INPUT;
 		if (h->log2n == 10) HIP_TRY(oct::launch_real2(rs, p.signalLogScaling != 0, a, h->stream));
 		else HIP_TRY(oct::launch_real2n(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
 	} else {
+		path |= roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0;
 		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, &h->lastGrid));
 	}
+	if (!spectrum) h->lastPath = path;
 	if (timeIt && h->timing) {
 		HIP_TRY(hipEventRecord(t.stop, h->stream));
 		h->timed.push_back(t);
@@ -1348,6 +1366,11 @@ int octpipe_debug_force_prepared(octpipe_t* h, int enable) {
 int octpipe_debug_set_route(octpipe_t* h, unsigned flags) {
 	if (h) h->route = flags;
 	else g_createRoute = flags;
+	return OCTPIPE_OK;
+}
+int octpipe_debug_last_path(const octpipe_t* h, unsigned* path) {
+	if (!h || !path) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*path = h->lastPath;
 	return OCTPIPE_OK;
 }
 int octpipe_debug_last_grid(const octpipe_t* h, int* blocks) {

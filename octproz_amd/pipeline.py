@@ -164,6 +164,12 @@ class Pipeline:
         """OCTPIPE_ROUTE_* of an existing handle (takes effect with the next buffer)"""
         check(self._lib.octpipe_debug_set_route(self._h, int(flags)))
 
+    def last_path(self):
+        """_lib.PATH_* bits of the implementation the last buffer's image launch took"""
+        n = C.c_uint()
+        check(self._lib.octpipe_debug_last_path(self._h, C.byref(n)))
+        return n.value
+
     def last_grid(self):
         n = C.c_int()
         check(self._lib.octpipe_debug_last_grid(self._h, C.byref(n)))

@@ -173,3 +173,63 @@ def test_float_streaming_with_one_buffer_per_volume_alternates_two_processed_buf
     del base
     pipe.unregister_float_streaming_buffers()
     pipe.close()
+
+
+_P = _lib
+_ROUTING = [
+    # N, settings, sample format, route flags, expected OCTPIPE_PATH_* bits of the image launch
+    (1024, {}, 0, 0, 0),
+    (1024, {"dispersionCompensation": 0}, 0, 0, _P.PATH_REAL_INPUT),
+    (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_ROLL_IN_KERNEL),
+    (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 300}, 0, 0, _P.PATH_PREPARED_ROWS),
+    (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 200, "bitDepth": 16}, 0, 0, _P.PATH_PREPARED_ROWS),  # sums not exact
+    (1024, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_FUSED_BG),
+    (1024, {"postProcessBackgroundRemoval": 1, "sinusoidalScanCorrection": 1}, 0, 0, 0),
+    (1024, {"postProcessBackgroundRemoval": 1}, 0, _P.ROUTE_NO_FUSED_BG, 0),
+    (1024, {"postProcessBackgroundRemoval": 1}, 1, 0, _P.PATH_FUSED_BG),                      # packed 12 bit, decoded in the kernel
+    (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 8}, 1, 0, _P.PATH_PREPARED_ROWS),
+    (1024, {"bitDepth": 32, "postProcessBackgroundRemoval": 1}, 5, 0, _P.PATH_PREPARED_ROWS | _P.PATH_FUSED_BG),
+    (2048, {"dispersionCompensation": 0}, 0, 0, _P.PATH_REAL_INPUT),
+    (4096, {}, 0, 0, _P.PATH_TEAM),
+    (4096, {"dispersionCompensation": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_REAL_INPUT),
+    (4096, {"dispersionCompensation": 0}, 0, _P.ROUTE_NO_REAL_INPUT, _P.PATH_TEAM),
+    (4096, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
+    (4096, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, _P.ROUTE_NO_TEAM, _P.PATH_ROLL_IN_KERNEL),
+    (4096, {"postProcessBackgroundRemoval": 1}, 2, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG),       # signed packed 12 bit
+    (4096, {"resamplingInterpolation": 2}, 0, 0, 0),                                           # Lanczos: one-wave kernel
+    (8192, {}, 0, 0, _P.PATH_TEAM),
+    (8192, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
+    (8192, {"bitDepth": 16}, 4, 0, _P.PATH_TEAM | _P.PATH_PREPARED_ROWS),                      # int16 comes prepared at this length
+    (8192, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
+    (1664, {}, 0, 0, _P.PATH_TEAM),
+    (1664, {"resamplingInterpolation": 0}, 0, 0, _P.PATH_MIXED_RADIX),
+    (1664, {"dispersionCompensation": 0}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_REAL_INPUT),
+    (1664, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG),
+    (1664, {"postProcessBackgroundRemoval": 1, "resamplingInterpolation": 0}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_FUSED_BG),
+    (1664, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64, "resamplingInterpolation": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
+    (1664, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, _P.ROUTE_NO_TEAM, _P.PATH_MIXED_RADIX | _P.PATH_PREPARED_ROWS),
+    (1664, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX),
+    (1000, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
+    (1000, {}, 0, _P.ROUTE_NO_LIBFFT, _P.PATH_BLUESTEIN | _P.PATH_PREPARED_ROWS),
+]
+
+
+@pytest.mark.parametrize("N,settings,fmt,route,want", _ROUTING, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else ",".join("%s=%s" % kv for kv in v.items()) or "v180")
+def test_routing_table(N, settings, fmt, route, want):
+    """Which implementation a configuration runs on is part of the contract: every route gives the oracle's image, so
+    a configuration that silently fell back to a slower route would pass every parity test.  octpipe_debug_last_path pins it."""
+    A, B = 16, 2
+    p = v180_benchmark_params(N, A, B)
+    for k, v in settings.items():
+        setattr(p, k, v)
+    if p.postProcessBackgroundRemoval:
+        p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    pipe = Pipeline(p, device=0, sample_format=fmt, route=route)
+    import torch
+    nbytes = {1: N * A * B // 2 * 3, 2: N * A * B // 2 * 3, 5: N * A * B * 4}.get(fmt, N * A * B * (4 if p.bitDepth > 16 else 2))
+    d = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    got = pipe.last_path()
+    pipe.close()
+    assert got == want, "N=%d %s: path bits %#x, expected %#x" % (N, settings, got, want)
