@@ -16,7 +16,8 @@
 //   The radix-13 pass -- the expensive one (real-symmetric form, mr::dft13) -- and the gather run on all 128 lanes, passes 2 and
 //   3 and the epilogue on 81 % of them.  Exchange 1 needs no padding (lane stride 13 elements: odd), exchange 2 stores every
 //   block of 208 elements at a pitch of 221 (208 = 16 mod 32 would put every second group of 13 lanes on the same banks).
-//   Two exchange buffers: three barriers per A-scan (row staged / first exchange written / second exchange written).
+//   Two exchange buffers and the next row staged during the transform: two barriers per A-scan (first exchange written /
+//   second exchange written; three more with the rolling average).
 //
 // Four teams per CU (two waves per SIMD), persistent.  uint16 rows directly (with the rolling average inside the team:
 // team_roll_stage), prepared float32 rows (other containers) like the other kernels; no / linear / cubic resampling; image output (the spectrum output that the mean-line
@@ -27,6 +28,9 @@
 
 namespace oct {
 
+#ifndef OCT_TEAM_EARLY
+#define OCT_TEAM_EARLY 1  // stage the next row behind the gather barrier of the current A-scan (0: at the top of the loop; A/B builds)
+#endif
 struct Team1664 {
 	static constexpr int N = 1664, T = 128, P = 13;
 	static constexpr int ROW_BYTES = ((N + 2 * ROW_OFF) * 4 + 15) & ~15;
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 	typedef Team1664 TM;
 	constexpr int N = TM::N, T = TM::T, P = TM::P;
 	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0;
+	constexpr bool EARLY = !ROLL && OCT_TEAM_EARLY != 0;
 	static_assert(!ROLL || INTYPE == IN_U16, "in-team rolling average: uint16 rows");
 	static_assert((TM::N + 2 * ROLL_PAD) * 4 <= TM::X2_BYTES, "the prefix array borrows the second exchange buffer");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,13 +121,8 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 		for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, L * CB, i * T * CB);  // past the row: 0
 	};
 	if (line < a.numLines) prefetch(line);
-
-	for (; line < a.numLines; line += gridDim.x) {
-		// ---- stage the raw row as float32 (cu:119-121 / 139-141), minus the rolling average (cu:165-211; team_kernel.h)
-		if constexpr (ROLL) {
-			team_roll_stage<T, N, NL>(pre, shift, a.rollingW, reinterpret_cast<uint32_t*>(x2),
-			                          reinterpret_cast<uint32_t*>(smem + team1664_lds_bytes<MODE>() - TEAM_ROLL_BYTES), row, L, RS == RS_CUBIC);
-		} else
+	// the raw row as float32 (cu:119-121 / 139-141)
+	auto stage = [&]() {
 #pragma unroll
 		for (int i = 0; i < NL; i++) {
 			const float4 f = chunk_to_float<INTYPE>(pre[i], 0, INTYPE == IN_F32 ? 0u : shift);  // prepared rows carry the shift already
@@ -131,8 +131,29 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 				if (i == 0 && L == 0) row[ROW_OFF - 1] = f.y;  // n0 = |n1 - 1| mirror tap (cu:284)
 			}
 		}
-		if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
-		team_barrier();  // the row is complete
+	};
+	// Without the rolling average the NEXT row is staged in the shadow of this A-scan's transform (right behind the barrier that
+	// ends the gather) and is complete at the "second exchange written" barrier: two barriers per A-scan.  The first row:
+	if constexpr (EARLY) {
+		if (line < a.numLines) {
+			stage();
+			if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
+		}
+		team_barrier();
+	}
+
+	for (; line < a.numLines; line += gridDim.x) {
+		if constexpr (ROLL) {
+			// ---- the raw row minus the rolling average (cu:165-211; team_kernel.h): three barriers of its own
+			team_roll_stage<T, N, NL>(pre, shift, a.rollingW, reinterpret_cast<uint32_t*>(x2),
+			                          reinterpret_cast<uint32_t*>(smem + team1664_lds_bytes<MODE>() - TEAM_ROLL_BYTES), row, L, RS == RS_CUBIC);
+			if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
+			team_barrier();  // the row is complete
+		} else if constexpr (!EARLY) {
+			stage();
+			if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
+			team_barrier();  // the row is complete
+		}
 
 		// ---- k-linearisation x window x dispersion phasor: samples L + 128 q
 		__builtin_amdgcn_s_setprio(3);
@@ -162,6 +183,12 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 			for (int u = 0; u < 13; u++) wb1[u] = X[u];
 		}
 		team_barrier();  // first exchange written (and every lane is past its gather: the row may be overwritten)
+		if constexpr (EARLY) {
+			if (line + gridDim.x < a.numLines) {  // `pre` holds the next row; the one after it is requested right away
+				stage();
+				if (line + 2 * gridDim.x < a.numLines) prefetch(line + 2 * gridDim.x);
+			}
+		}
 		f2 v[16];
 #pragma unroll
 		for (int t = 0; t < 16; t++) v[t] = rb1[104 * t];
@@ -172,7 +199,7 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 #pragma unroll
 			for (int u = 0; u < 16; u++) wb2[13 * u] = v[u];
 		}
-		team_barrier();  // second exchange written
+		team_barrier();  // second exchange written (and the next row staged)
 #pragma unroll
 		for (int t = 0; t < 8; t++) {
 			v[2 * t] = rb2a[TM::X2_PITCH * t];
