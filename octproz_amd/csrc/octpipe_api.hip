@@ -569,7 +569,13 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (teamLib) {
+	if (teamLib && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && !roll && !p.dispersionCompensation &&
+	    !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
+		// N = 8192, real FFT input (no dispersion compensation): two A-scans per team transform
+		a.twiddle = h->d_twTeam;
+		path |= OCTPIPE_PATH_TEAM | OCTPIPE_PATH_REAL_INPUT;
+		HIP_TRY(oct::launch_team_real2(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
+	} else if (teamLib) {
 		a.twiddle = h->d_twTeam;
 		path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
 		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));

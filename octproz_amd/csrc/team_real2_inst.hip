@@ -10,7 +10,7 @@ template <int LOG2N, int RS, int MODE>
 hipError_t launch_team_real2_one(const FusedArgs& a, hipStream_t stream) {
 	auto kernel = oct_team_real2_kernel<LOG2N, RS, MODE>;
 	constexpr size_t lds = team_real2_lds_bytes<LOG2N, MODE>();
-	static_assert(2 * lds <= 160 * 1024, "two teams per CU");
+	static_assert((LOG2N == 12 ? 2 : 1) * lds <= 160 * 1024, "two teams per CU (N = 8192: one)");
 	KernelLaunchInfo info;
 	hipError_t e = kernel_launch_info(kernel, Team<LOG2N>::LANES, lds, &info);
 	if (e != hipSuccess) return e;
@@ -28,9 +28,17 @@ hipError_t launch_team_real2_mode(bool logScale, const FusedArgs& a, hipStream_t
 }
 }  // namespace
 
-bool team_real2_supported(int log2n) { return log2n == 12; }
+bool team_real2_supported(int log2n) { return log2n == 12 || log2n == 13; }
 
 hipError_t launch_team_real2(int log2n, int rs, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (log2n == 13) {
+		switch (rs) {
+		case RS_NONE: return launch_team_real2_mode<13, RS_NONE>(logScale, a, stream);
+		case RS_LINEAR: return launch_team_real2_mode<13, RS_LINEAR>(logScale, a, stream);
+		case RS_CUBIC: return launch_team_real2_mode<13, RS_CUBIC>(logScale, a, stream);
+		default: return hipErrorInvalidValue;
+		}
+	}
 	if (log2n != 12) return hipErrorNotSupported;
 	switch (rs) {
 	case RS_NONE: return launch_team_real2_mode<12, RS_NONE>(logScale, a, stream);

@@ -1,5 +1,5 @@
 // team_real2_kernel.h -- the team kernel (team_kernel.h) for a REAL transform input: dispersion compensation off (the
-// reference's default, octalgorithmparameters.cpp:72), N = 4096, uint16 rows, no / linear / cubic resampling, image output.
+// reference's default, octalgorithmparameters.cpp:72), N = 4096 and 8192, uint16 rows, no / linear / cubic resampling, image output.
 // Two consecutive A-scans share one complex transform per team iteration, like real2_kernel.h does per wave at N = 1024:
 //     z = x1 + i x2,  Z = IDFT(z)   ->   X1[k] = (Z[k] + conj Z[N-k]) / 2,   X2[k] = (Z[k] - conj Z[N-k]) / (2i)
 //   * both rows are staged interleaved, (row0[n], row1[n]) as one 8-byte LDS element: the taps of both A-scans are register
@@ -12,14 +12,15 @@
 //     1/2 is folded into the grey-scale constants (|S/2 - m|^2 = |S - 2m|^2 / 4).
 // The first exchange and the mirror use the exchange buffer, the second exchange the row region (idle after the gather): four
 // barriers per PAIR (rows staged / first exchange written / second written / mirror written) against four per A-scan of the
-// complex team kernel.
+// complex team kernel.  N = 8192 (16 x 16 x 16 x 2): the third exchange uses the exchange buffer again, the radix-2 pass is
+// unpruned, the mirror goes to the row region: six barriers per pair against six per A-scan.
 #pragma once
 #include "team_kernel.h"
 
 namespace oct {
 
 template <int LOG2N> struct TeamReal2 {
-	static_assert(LOG2N == 12, "real-input team kernel: N = 4096");
+	static_assert(LOG2N == 12 || LOG2N == 13, "real-input team kernel: N = 4096 and 8192");
 	typedef Team<LOG2N> TM;
 	// interleaved rows; the region also takes the SECOND exchange (every lane is past its gather once the first exchange is
 	// written), which saves the two "everyone has read" barriers of a single exchange buffer
@@ -35,12 +36,13 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
 	typedef Team<LOG2N> TM;
 	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3;
-	static_assert(R3 == 16 && TM::NB3 == 1, "one radix-16 butterfly per lane in the last pass");
-	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
+	static_assert(R3 == 16 && TM::NB3 == 1, "one radix-16 butterfly per lane in the third pass");
+	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, FOUR = TM::FOUR;
+	constexpr int KS = FOUR ? T : 256;  // the lane ends with the bins L + KS u, u < 16: kept (u < 8) and upper half
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	f2* rowp = reinterpret_cast<f2*>(smem);  // element n = (row0[n], row1[n])
 	f2* xbuf = reinterpret_cast<f2*>(smem + TeamReal2<LOG2N>::ROWS_BYTES);
-	f2* mb = xbuf;  // mirror buffer: upper bin k at k - N/2
+	f2* mb = FOUR ? rowp : xbuf;  // mirror buffer: upper bin k at k - N/2 (the buffer that does not hold the last exchange)
 	f2* tw2L = reinterpret_cast<f2*>(smem + TeamReal2<LOG2N>::ROWS_BYTES + TM::X_BYTES);
 	const float* termL = reinterpret_cast<const float*>(smem + TeamReal2<LOG2N>::FIXED_BYTES);
 	constexpr bool TW2_LDS = RS == RS_CUBIC;  // 64 tap-weight registers: the pass-2 twiddles (16 distinct per t) are read from LDS
@@ -97,9 +99,14 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 #pragma unroll
 		for (int t = 1; t < 16; t++) tw3[t - 1] = a.twiddle[TM::TW_PASS3 + (t - 1) * 256 + (L & 255)];
 	}
-	f2 mean2[8];  // twice the mean A-line at the lane's kept bins L + 256 u
+	f2 tw4[FOUR ? 8 : 1];  // N = 8192: the radix-2 pass over (b, b + 4096), b = L + T m
+	if constexpr (FOUR) {
 #pragma unroll
-	for (int u = 0; u < 8; u++) mean2[u] = a.subtractMean ? a.meanLine[L + 256 * u] * 2.0f : f2{0.0f, 0.0f};
+		for (int m = 0; m < 8; m++) tw4[m] = a.twiddle[TM::TW_PASS4 + L + T * m];
+	}
+	f2 mean2[8];  // twice the mean A-line at the lane's kept bins L + KS u
+#pragma unroll
+	for (int u = 0; u < 8; u++) mean2[u] = a.subtractMean ? a.meanLine[L + KS * u] * 2.0f : f2{0.0f, 0.0f};
 	// out = sA f(P) + sB with P = |S - 2m|^2 / 4:  log2(P'/4) = log2(P') - 2,  sqrt(P'/4) = sqrt(P') / 2
 	const float sA = LOGSCALE ? a.sA : 0.5f * a.sA, sB = LOGSCALE ? a.sB - 2.0f * a.sA : a.sB;
 	const uint32_t shift = a.bitshift ? 4u : 0u;
@@ -121,7 +128,8 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 	f2* wb1 = xbuf + (16 + TM::PAD) * L;
 	f2* wb2 = rowp + ((256 + 16 * TM::PAD) * (L >> 4) + (L & 15));  // second exchange: in the row region
 	const f2* rb2 = rowp + (L + TM::PAD * (L >> 4));
-	constexpr int S16 = 16 + TM::PAD;
+	constexpr int S16 = 16 + TM::PAD, S256 = 256 + 16 * TM::PAD;
+	f2* wb3 = xbuf + ((4096 + 256 * TM::PAD) * (L >> 8) + (L & 255) + TM::PAD * ((L & 255) >> 4));  // N = 8192: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[S256 u]
 
 	for (; pi < numPairs; pi += gridDim.x) {
 		// ---- stage both rows interleaved as float32
@@ -183,11 +191,26 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 				v[t] = octfft::cmul(v[t], tw3[t - 1]);
 			}
 		}
-		octfft::Dft<16, 1, false>::run(&v[0]);  // v[u] = Z[L + 256 u]
-		// the exchange buffer was last read before the previous barrier: it takes the mirror
+		octfft::Dft<16, 1, false>::run(&v[0]);  // N = 4096: v[u] = Z[L + 256 u]
+		if constexpr (FOUR) {
+			// third exchange, in the exchange buffer again (last read before the previous barrier), then the radix-2 pass:
+			// element L + T q = b + 4096 t with b = L + T m, q = m + 8 t;  Z[b] = s + w d,  Z[b + 4096] = s - w d
 #pragma unroll
-		for (int u = 8; u < 16; u++) mb[L + 256 * (u - 8)] = v[u];  // Z[k], k >= N/2, at k - N/2
-		team_barrier();  // mirror written (and the second exchange read by everyone: the next rows may be staged)
+			for (int u = 0; u < 16; u++) wb3[S256 * u] = v[u];
+			team_barrier();  // third exchange written
+#pragma unroll
+			for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+#pragma unroll
+			for (int m = 0; m < 8; m++) {
+				const f2 d = octfft::cmul(v[m + 8], tw4[m]), s0 = v[m];
+				v[m] = s0 + d;
+				v[m + 8] = s0 - d;
+			}
+		}
+		// v[u] = Z[L + KS u].  The mirror goes to the buffer that was last read before the previous barrier
+#pragma unroll
+		for (int u = 8; u < 16; u++) mb[L + KS * (u - 8)] = v[u];  // Z[k], k >= N/2, at k - N/2
+		team_barrier();  // mirror written (N = 4096: and the second exchange read by everyone, the next rows may be staged)
 		__builtin_amdgcn_s_setprio(1);
 
 		// ---- separate the two A-scans, mean A-line, |.|^2, log / lin, two output rows (flip per row as in the general kernel)
@@ -201,10 +224,10 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 		}
 		const __amdgpu_buffer_rsrc_t outR0 = make_rsrc(a.out + (size_t)orow0 * (N / 2), N * 2u);
 		const __amdgpu_buffer_rsrc_t outR1 = make_rsrc(a.out + (size_t)orow1 * (N / 2), ln1 < a.numLines ? N * 2u : 0u);  // no second row: stores dropped
-		const f2* mr = mb + (N / 2 - L);  // Z[N - k] of bin k = L + 256 u at mr[-256 u]
+		const f2* mr = mb + (N / 2 - L);  // Z[N - k] of bin k = L + KS u at mr[-KS u]
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
-			f2 zm = (u == 0) ? ((L == 0) ? v[0] : mr[0]) : mr[-256 * u];  // bin 0 is its own partner
+			f2 zm = (u == 0) ? ((L == 0) ? v[0] : mr[0]) : mr[-KS * u];  // bin 0 is its own partner
 			if (u == 0 && L == 0) zm = v[0];
 			const f2 z = v[u];
 			// S1 = Z[k] + conj Z[N-k] = 2 X1[k];  S2 = (Z[k] - conj Z[N-k]) / i = 2 X2[k]
@@ -214,10 +237,11 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 			const float p1 = d1.x * d1.x + d1.y * d1.y, p2 = d2.x * d2.x + d2.y * d2.y;
 			const float f1 = LOGSCALE ? __builtin_amdgcn_logf(p1) : __builtin_amdgcn_sqrtf(p1);
 			const float f2v = LOGSCALE ? __builtin_amdgcn_logf(p2) : __builtin_amdgcn_sqrtf(p2);
-			store_image<BG>(sA * f1 + sB, outR0, termL, L * 4, 256 * u * 4);
-			store_image<BG>(sA * f2v + sB, outR1, termL, L * 4, 256 * u * 4);
+			store_image<BG>(sA * f1 + sB, outR0, termL, L * 4, KS * u * 4);
+			store_image<BG>(sA * f2v + sB, outR1, termL, L * 4, KS * u * 4);
 		}
 		__builtin_amdgcn_s_setprio(0);
+		if constexpr (FOUR) team_barrier();  // the mirror (in the row region) read by everyone: the next rows may be staged
 	}
 }
 

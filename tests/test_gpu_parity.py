@@ -259,15 +259,15 @@ def test_real_input_kernel_matches_oracle(case, A, B):
     pipe.close(); o.close()
 
 
-@pytest.mark.parametrize("N", [256, 512, 2048, 1664, 4096])
+@pytest.mark.parametrize("N", [256, 512, 2048, 1664, 4096, 8192])
 @pytest.mark.parametrize("case", list(REAL_INPUT_CASES))
 @pytest.mark.parametrize("A,B", [(24, 3), (7, 3), (1, 1)])
 def test_real_input_kernel_on_the_other_lengths(N, case, A, B):
     """real2n_kernel.h: the same two-A-scans-per-transform scheme on the 4.4.4.4, 8.8.8 and (planar) 16.16.8 plans, and
     mixed1664_real2.h on the 32 x 4 x 13 plan of the reference recording's length, team_real2_kernel.h at N = 4096 (one pair
-    per team of four waves)"""
+    per team of four waves) and N = 8192 (eight waves, 16 x 16 x 16 x 2)"""
     p = v180_benchmark_params(N, A, B)
-    if N == 1664:
+    if N in (1664, 8192):
         p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
     REAL_INPUT_CASES[case](p)
     p.update_all_curves()
@@ -512,7 +512,7 @@ def test_lanczos_on_the_mixed_radix_kernel_of_1664(variant, A, B):
     pipe.close(); blue.close(); o.close()
 
 
-@pytest.mark.parametrize("N", [512, 1024, 2048, 1664, 4096])
+@pytest.mark.parametrize("N", [512, 1024, 2048, 1664, 4096, 8192])
 def test_real_input_route_agrees_with_the_complex_route(N):
     """dispersion compensation off: the two-A-scans-per-transform kernels and the general kernel of the length
     (OCTPIPE_ROUTE_NO_REAL_INPUT) give the same image within the float tolerance, from really different code, and both hold the oracle"""
@@ -787,7 +787,7 @@ def test_team_kernel_of_1664_matches_oracle_and_the_one_wave_kernel(variant, A, 
     pipe.close(); one.close(); o.close()
 
 
-@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096, 1664])
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096, 1664, 8192])
 @pytest.mark.parametrize("variant", ["v180", "no_dispersion", "linear_flip", "lanczos", "lin_scale"])
 def test_background_removal_inside_the_fused_store_equals_the_post_pass(N, variant):
     """cu:757-767 saturate(v - (weight bg + offset)): without the sinusoidal correction the removal rides on the image store of
