@@ -221,3 +221,62 @@ def _settings_sequence(seed, rng, N):
         common.compare_images(pipe.processed_host(), want, p, what, mean_line=o.mean_line())
         o.close()
     pipe.close()
+
+
+# ------------------------------------------------------------------ the same draws in the other sample formats
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_FORMAT_SEEDS", "40"))))
+def test_random_setting_combination_in_other_sample_formats(seed):
+    """A draw whose samples are delivered as packed 12 bit, int16 and int32 instead of uint16 decodes to the same float rows, so
+    it must give the uint16 handle's image (which the draws above hold against the oracle) -- through whatever route the format
+    takes: decode inside the fused / team kernel, prepared rows from the unpack or row kernels, the rolling average in the
+    kernel or in front of it, background removal in the store or as a post pass.  Signed twins: the samples minus 2048 as int16
+    (reference of the group), packed signed 12 bit and int32."""
+    import torch
+    from test_sample_formats import FORMATS, pack12
+    for extra in range(50):  # the first draw at or behind the seed that came out as plain uint16
+        p, raw, what = draw(seed * 50 + extra, LENGTHS + [8192], 9000)
+        if p.bitDepth == 12 and raw.dtype == np.uint16:
+            break
+    else:
+        pytest.skip("no uint16 draw")
+    vals = raw.reshape(-1).astype(np.int64)
+
+    def run(values, fmt, bits, mean=None):
+        q = copy.copy(p)
+        q.bitDepth = bits
+        if fmt in (FORMATS["uint12p"], FORMATS["int12p"]):
+            buf = pack12(values)
+        elif fmt == FORMATS["int16"]:
+            buf = values.astype(np.int16)
+        elif fmt == FORMATS["int32"]:
+            buf = values.astype(np.int32)
+        else:
+            buf = values.astype(np.uint16)
+        pipe = Pipeline(q, device=0, sample_format=fmt)
+        if mean is not None:
+            pipe.set_mean_line(mean, pin=True)
+        d = torch.from_numpy(np.ascontiguousarray(buf).view(np.uint8).reshape(-1)).to("cuda:0")
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        img, ml, path = pipe.processed_host(), pipe.mean_line(), pipe.last_path()
+        pipe.close()
+        return img, ml, path
+
+    def same(got, ref, tag, mean):
+        if p.postProcessBackgroundRemoval:  # behind the clamp: compared directly
+            assert np.abs(got - ref).max() < 1e-3, what + " " + tag
+            return
+        q = copy.copy(p)
+        q.signalMultiplicator, q.signalAddend = 1.0, 0.0
+        unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
+        common.compare_images(unscale(got), unscale(ref), q, what + " " + tag, mean_line=mean)
+
+    ref, ml, _ = run(vals, 0, 12)
+    ml = ml if p.fixedPatternNoiseRemoval else None
+    for name, bits in (("uint12p", 12), ("int16", 16), ("int32", 32)):
+        got, _, path = run(vals, FORMATS[name], bits, ml)
+        same(got, ref, "%s (path %#x) vs uint16" % (name, path), ml)
+    sref, sml, _ = run(vals - 2048, FORMATS["int16"], 16)
+    sml = sml if p.fixedPatternNoiseRemoval else None
+    for name, bits in (("int12p", 12), ("int32", 32)):
+        got, _, path = run(vals - 2048, FORMATS[name], bits, sml)
+        same(got, sref, "%s (path %#x) vs int16, signed samples" % (name, path), sml)
