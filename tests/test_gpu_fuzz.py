@@ -17,7 +17,10 @@ wrong, each fixed in tests/common.py with the reason next to it: a DC bin that t
 amplitude cannot hold 0.065 dB in float32 (CANCEL_FLOOR); at N = 8192 the -60 dB floor of the dB comparison sits under the
 transform's rounding when DC dominates the line (floor x N / 4096); a float32 FFT returns EXACTLY 0 at a bin 150 dB under the
 line maximum where the oracle's rounded float64 DFT keeps a residue, with no subtraction involved (one-sided -inf rule).
-Draws with post-process background removal are checked as chain parity without the removal + the removal stage bit for bit."""
+Draws with post-process background removal are checked as chain parity without the removal + the removal stage bit for bit.
+End of round 3 (real-input and rolling-average team kernels, row kernels, background removal in the store for every container):
+OCT_FUZZ_SEEDS=600 OCT_FUZZ_TEAM_SEEDS=300 OCT_FUZZ_SEQUENCES=60 OCT_FUZZ_TEAM_SEQUENCES=40, 1 000 cases, and
+OCT_FUZZ_FORMAT_SEEDS=120 format twins: all green."""
 import copy
 import os
 
