@@ -103,14 +103,23 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr bool CW = RS == RS_CUBIC && Cfg<LOG2N>::LDS_LUT && Cfg<LOG2N>::WAVES_CW > 0;
 	// N = 2048 with the weights table runs 8 waves of up to 256 VGPRs: room for the lane's 16 mean-line bins (OCT_MEANREG11)
 	static constexpr bool MEAN_REGS = Cfg<LOG2N>::MEAN_REGS || (CW && LOG2N == 11 && OCT_MEANREG11 != 0);
-	static constexpr bool REGTAB = CW && LOG2N == 10 && OCT_REGTAB != 0;
-	static constexpr bool REGLIN = !CW && LOG2N == 10 && OCT_REGLIN != 0 && (RS == RS_LINEAR || RS == RS_NONE) && !ROLL;
+#ifndef OCT_REGTAB9
+#define OCT_REGTAB9 1  // N = 512 with the register tables of N = 1024 (8 samples per lane, 113 VGPRs, 16 waves per CU): +11 %
+#endif
+#ifndef OCT_REGTAB8
+#define OCT_REGTAB8 1  // N = 256 likewise (4 samples per lane): +6.5 %
+#endif
+	static constexpr bool REGTAB = CW && (LOG2N == 10 || (LOG2N == 9 && OCT_REGTAB9 != 0) || (LOG2N == 8 && OCT_REGTAB8 != 0)) && OCT_REGTAB != 0;
+#ifndef OCT_REGLIN_SHORT
+#define OCT_REGLIN_SHORT 1  // the register tables of the linear / no-resampling variants at N = 512 and 256 too: +6 .. +12 %
+#endif
+	static constexpr bool REGLIN = !CW && (LOG2N == 10 || (LOG2N <= 9 && OCT_REGLIN_SHORT != 0)) && OCT_REGLIN != 0 && (RS == RS_LINEAR || RS == RS_NONE) && !ROLL;
 	// Lanczos: the [N][16] tap-weight table (64 B per sample) in LDS where it fits (N <= 1024; at N = 1024 with 8 waves)
 	static constexpr bool LZ_LDS = RS == RS_LANCZOS && LOG2N <= 10 && Cfg<LOG2N>::LDS_LUT && OCT_LANCZOS_LDS != 0;
-	static constexpr int WAVES_PLAIN = REGLIN ? (RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : (LZ_LDS && LOG2N == 10) ? 8 : Cfg<LOG2N>::WAVES;
+	static constexpr int WAVES_PLAIN = REGLIN ? (LOG2N <= 9 ? Cfg<LOG2N>::WAVES : RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : (LZ_LDS && LOG2N == 10) ? 8 : Cfg<LOG2N>::WAVES;
 	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
 	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0 && Cfg<LOG2N>::WAVES_ROLL < WAVES_PLAIN) ? Cfg<LOG2N>::WAVES_ROLL : WAVES_PLAIN;
-	static constexpr int MINW = (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN || (LZ_LDS && LOG2N == 10)) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
+	static constexpr int MINW = ((REGTAB || REGLIN) && LOG2N <= 9) ? 4 : (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN || (LZ_LDS && LOG2N == 10)) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 #ifndef OCT_PADK
@@ -687,8 +696,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 	}
 	// the last pass' twiddles too where the register budget allows (plain uint16 kernel: 249 VGPRs, no spill)
-	constexpr bool TW3 = (REGTAB || REGLIN) && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32;
-	constexpr bool TW2 = (REGTAB || REGLIN) && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
+	constexpr bool TW3 = (REGTAB || REGLIN) && LOG2N == 10 && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32;
+	constexpr bool TW2 = (REGTAB || REGLIN) && LOG2N == 10 && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
 	f32x4 tw2R[TW2 ? (TW3 ? 14 : 8) : 1];
 	if constexpr (REGTAB) {
 #pragma unroll
