@@ -22,8 +22,11 @@ template <int LOG2N> struct Real2Cfg;
 // ILV: the two rows staged interleaved (see above).  Measured against two separate rows on one box (cubic / linear / none):
 // N = 2048 +4.7 % / 0 / 0, N = 512 0 / 0 / 0, N = 256 -2 % throughout (the 32-byte-per-lane staging stores conflict two-way
 // and there is little interpolation work to save): on for N = 2048 only.
-template <> struct Real2Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool ILV = false; };
-template <> struct Real2Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool ILV = false; };
+#ifndef OCT_REAL2N_REGW
+#define OCT_REAL2N_REGW 1  // N = 256 / 512: tap weights (window folded in) and tap addresses of the lane's samples in registers, rows interleaved
+#endif
+template <> struct Real2Cfg<8>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool ILV = OCT_REAL2N_REGW != 0; };
+template <> struct Real2Cfg<9>  { static constexpr int WAVES = 8,  MINW = 4; static constexpr bool ILV = OCT_REAL2N_REGW != 0; };
 template <> struct Real2Cfg<11> { static constexpr int WAVES = 7,  MINW = 2; static constexpr bool ILV = true; };  // LDS-bound: two 8.1 KiB rows per wave
 
 template <int LOG2N> constexpr int real2n_slice_bytes() {
@@ -67,6 +70,36 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 		winL[i] = t.y * t.z;  // phasor = (1, 0): the window alone
 	}
 	__syncthreads();
+
+	// N <= 512 (4 / 8 samples per lane): what the gather needs per sample is A-scan invariant and fits in registers -- the
+	// Catmull-Rom tap weights (cu:258-271 as weights of the four taps, evaluated once per lane in double) times the window, the
+	// LDS address of tap 0 -- as in real2_kernel.h; the interleaved rows make every tap read and every FMA serve both A-scans
+	constexpr bool REGW = LOG2N <= 9 && OCT_REAL2N_REGW != 0;
+	static_assert(!REGW || ILV, "register weights: interleaved rows");
+	typedef __attribute__((address_space(3))) const f2 lds_cf2;
+	f32x4 cwR[REGW && RS == RS_CUBIC ? P : 1];
+	f2 fwR[REGW && RS == RS_LINEAR ? P : 1];  // (fraction, window)
+	float winR[REGW && RS == RS_NONE ? P : 1];
+	uint32_t tapA[REGW && RS != RS_NONE ? P : 1];
+	if constexpr (REGW) {
+		const uint32_t tapBase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) f2*)(rowp + ROW_OFF - 1));
+#pragma unroll
+		for (int q = 0; q < P; q++) {
+			const float4 t = a.lut[lane + 64 * q];
+			const float win = t.y * t.z;
+			const double p = (double)__builtin_amdgcn_fractf(t.x);
+			if constexpr (RS == RS_CUBIC) {
+				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0), wn = (double)win;
+				cwR[q] = f32x4{(float)(wn * w0), (float)(wn * (1.0 - w0 - w2 - w3)), (float)(wn * w2), (float)(wn * w3)};
+				tapA[q] = tapBase + 8u * (uint32_t)(int)t.x;  // tap 0 = element n1 - 1
+			} else if constexpr (RS == RS_LINEAR) {
+				fwR[q] = f2{(float)p, win};
+				tapA[q] = tapBase + 8u * (uint32_t)(int)t.x + 8u;  // element n1
+			} else {
+				winR[q] = win;
+			}
+		}
+	}
 
 	// twice the mean A-line at the lane's kept bins
 	f2 mean2[P / 2];
@@ -129,6 +162,19 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			const int j = lane + 64 * q;
+			if constexpr (REGW) {
+				if constexpr (RS == RS_CUBIC) {
+					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[q]);
+					const f32x4 cw = cwR[q];
+					v[q] = t[3] * cw.w + (t[2] * cw.z + (t[1] * cw.y + t[0] * cw.x));
+				} else if constexpr (RS == RS_LINEAR) {
+					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[q]);
+					v[q] = (t[0] + (t[1] - t[0]) * fwR[q].x) * fwR[q].y;  // cu:225-228, then the window
+				} else {
+					v[q] = rowp[ROW_OFF + j] * winR[q];
+				}
+				continue;
+			}
 			const float w = winL[j];
 			f2 y;  // (row 0, row 1) at the same resampling position
 			if constexpr (RS == RS_NONE) {
