@@ -22,6 +22,12 @@ template <int LOG2N> struct Real2Cfg;
 // ILV: the two rows staged interleaved (see above).  Measured against two separate rows on one box (cubic / linear / none):
 // N = 2048 +4.7 % / 0 / 0, N = 512 0 / 0 / 0, N = 256 -2 % throughout (the 32-byte-per-lane staging stores conflict two-way
 // and there is little interpolation work to save): on for N = 2048 only.
+#ifndef OCT_REAL2N_NREG11_CUBIC
+#define OCT_REAL2N_NREG11_CUBIC 4    // N = 2048: samples per lane whose tap address + four weights live in the spare registers
+#endif
+#ifndef OCT_REAL2N_NREG11_LINEAR
+#define OCT_REAL2N_NREG11_LINEAR 10  // ... tap address + (fraction, window)
+#endif
 #ifndef OCT_REAL2N_REGW
 #define OCT_REAL2N_REGW 1  // N = 256 / 512: tap weights (window folded in) and tap addresses of the lane's samples in registers, rows interleaved
 #endif
@@ -74,17 +80,20 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 	// N <= 512 (4 / 8 samples per lane): what the gather needs per sample is A-scan invariant and fits in registers -- the
 	// Catmull-Rom tap weights (cu:258-271 as weights of the four taps, evaluated once per lane in double) times the window, the
 	// LDS address of tap 0 -- as in real2_kernel.h; the interleaved rows make every tap read and every FMA serve both A-scans
-	constexpr bool REGW = LOG2N <= 9 && OCT_REAL2N_REGW != 0;
+	// N = 2048 (32 samples per lane, 218 of 256 VGPRs): the same for the FIRST NREG samples of the lane, the others keep the
+	// per-A-scan evaluation from the LDS tables
+	constexpr bool REGW = (LOG2N <= 9 || LOG2N == 11) && OCT_REAL2N_REGW != 0;
+	constexpr int NREG = !REGW ? 0 : LOG2N <= 9 ? P : RS == RS_CUBIC ? OCT_REAL2N_NREG11_CUBIC : RS == RS_LINEAR ? OCT_REAL2N_NREG11_LINEAR : 0;
 	static_assert(!REGW || ILV, "register weights: interleaved rows");
 	typedef __attribute__((address_space(3))) const f2 lds_cf2;
-	f32x4 cwR[REGW && RS == RS_CUBIC ? P : 1];
-	f2 fwR[REGW && RS == RS_LINEAR ? P : 1];  // (fraction, window)
-	float winR[REGW && RS == RS_NONE ? P : 1];
-	uint32_t tapA[REGW && RS != RS_NONE ? P : 1];
-	if constexpr (REGW) {
+	f32x4 cwR[NREG > 0 && RS == RS_CUBIC ? NREG : 1];
+	f2 fwR[NREG > 0 && RS == RS_LINEAR ? NREG : 1];  // (fraction, window)
+	float winR[NREG > 0 && RS == RS_NONE ? NREG : 1];
+	uint32_t tapA[NREG > 0 && RS != RS_NONE ? NREG : 1];
+	if constexpr (NREG > 0) {
 		const uint32_t tapBase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) f2*)(rowp + ROW_OFF - 1));
 #pragma unroll
-		for (int q = 0; q < P; q++) {
+		for (int q = 0; q < NREG; q++) {
 			const float4 t = a.lut[lane + 64 * q];
 			const float win = t.y * t.z;
 			const double p = (double)__builtin_amdgcn_fractf(t.x);
@@ -162,16 +171,18 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			const int j = lane + 64 * q;
-			if constexpr (REGW) {
+			if (q < NREG) {  // (a constant after unrolling)
+				constexpr int Z = NREG > 0 ? NREG - 1 : 0;
+				const int qq = q < NREG ? q : Z;
 				if constexpr (RS == RS_CUBIC) {
-					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[q]);
-					const f32x4 cw = cwR[q];
+					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[qq]);
+					const f32x4 cw = cwR[qq];
 					v[q] = t[3] * cw.w + (t[2] * cw.z + (t[1] * cw.y + t[0] * cw.x));
 				} else if constexpr (RS == RS_LINEAR) {
-					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[q]);
-					v[q] = (t[0] + (t[1] - t[0]) * fwR[q].x) * fwR[q].y;  // cu:225-228, then the window
+					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[qq]);
+					v[q] = (t[0] + (t[1] - t[0]) * fwR[qq].x) * fwR[qq].y;  // cu:225-228, then the window
 				} else {
-					v[q] = rowp[ROW_OFF + j] * winR[q];
+					v[q] = rowp[ROW_OFF + j] * winR[qq];
 				}
 				continue;
 			}
