@@ -25,11 +25,27 @@ __device__ constexpr float kSin16[16] = {
 	0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
 	-1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
 
+#ifndef OCT_CMUL_CONST_ASM
+#define OCT_CMUL_CONST_ASM 1
+#endif
 OCT_DEV f2 cmul(f2 a, f2 w) {
 	f2 t, r;
 	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
 	return r;
+}
+// a * (c + i s) for a compile-time constant: the same two packed instructions with the constant in a scalar register pair
+// (written as float expressions, hipcc vectorises the four products with register shuffles: 74 v_mov per A-scan at N = 2048)
+OCT_DEV f2 cmul_const(f2 a, float c, float s) {
+#if OCT_CMUL_CONST_ASM
+	f2 t, r;
+	const f2 w = f2{c, s};
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+	return r;
+#else
+	return f2{a.x * c - a.y * s, a.x * s + a.y * c};
+#endif
 }
 OCT_DEV f2 mul_i(f2 a) { return f2{-a.y, a.x}; }   // a * (+i)
 // a + i*b and a - i*b in one packed add (operand swizzle + sign on the second source)
@@ -57,7 +73,7 @@ OCT_DEV f2 mul_w16(f2 z) {
 	else if constexpr (m == 6) return sub_i(z, z) * (-h);
 	else if constexpr (m == 10) return add_i(z, z) * (-h);
 	else if constexpr (m == 14) return sub_i(z, z) * h;
-	else return f2{z.x * kCos16[m] - z.y * kSin16[m], z.x * kSin16[m] + z.y * kCos16[m]};
+	else return cmul_const(z, kCos16[m], kSin16[m]);
 }
 
 // ---- radix 2 / 4 on named values -------------------------------------------------
@@ -169,7 +185,7 @@ struct Dft<32, ST, false> {
 			f2 t;
 			if (k == 0) t = d;
 			else if (k == 8) t = f2{-d.y, d.x};
-			else t = f2{d.x * c[k] - d.y * s[k], d.x * s[k] + d.y * c[k]};
+			else t = cmul_const(d, c[k], s[k]);
 			o[k] = e + t;
 			o[k + 16] = e - t;
 		}
@@ -199,7 +215,7 @@ struct Dft<64, ST, false> {
 		if (k == 16) return f2{-d.y, d.x};
 		if (k == 32) return f2{-d.x, -d.y};
 		const float cs = c[k], sn = c[(k + 48) % 64];
-		return f2{d.x * cs - d.y * sn, d.x * sn + d.y * cs};
+		return cmul_const(d, cs, sn);
 	}
 	static OCT_DEV void run(f2* v) {
 #pragma unroll

@@ -71,7 +71,7 @@ OCT_DEV void dft32(f2 (&v)[32]) {
 		f2 t;
 		if (k == 0) t = d;
 		else if (k == 8) t = f2{-d.y, d.x};
-		else t = f2{d.x * kCos32[k] - d.y * kSin32[k], d.x * kSin32[k] + d.y * kCos32[k]};
+		else t = octfft::cmul_const(d, kCos32[k], kSin32[k]);
 		o[k] = e + t;
 		o[k + 16] = e - t;
 	}
