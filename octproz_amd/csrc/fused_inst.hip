@@ -44,13 +44,9 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 template <int INTYPE, int RS, int ROLLBIT>
 hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, hipStream_t st, int* bu) {
 	if (spectrum) return launch_one<INTYPE, RS, ROLLBIT | MODE_SPECTRUM>(a, rb, st, bu);
-	// post-process background removal inside the image store (a.bgTerm set): every container, but not together with the
-	// in-kernel rolling average (the caller keeps the post pass there)
-	if constexpr (ROLLBIT == 0) {
-		if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, MODE_LOG | MODE_BG>(a, rb, st, bu) : launch_one<INTYPE, RS, MODE_BG>(a, rb, st, bu);
-	} else if (a.bgTerm) {
-		return hipErrorInvalidValue;
-	}
+	// post-process background removal inside the image store (a.bgTerm set): every container, with or without the in-kernel
+	// rolling average
+	if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_BG>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_BG>(a, rb, st, bu);
 	if (logScale) return launch_one<INTYPE, RS, ROLLBIT | MODE_LOG>(a, rb, st, bu);
 	return launch_one<INTYPE, RS, ROLLBIT>(a, rb, st, bu);
 }

@@ -520,9 +520,9 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	}
 	if (bgApplied) *bgApplied = false;
 	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
-	// and the prepared float32 rows; not with the in-kernel rolling average (`roll` still set here), Bluestein or the library route
+	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
 	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
-	if (wantBg && !spectrum && !roll && (!h->libfft || teamLib) && (useMixed || !h->bluestein)) {
+	if (wantBg && !spectrum && (!h->libfft || teamLib) && (useMixed || !h->bluestein)) {
 		int rc = ensure((void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
 		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {

@@ -21,9 +21,9 @@ hipError_t launch_team1664_one(const FusedArgs& a, hipStream_t stream) {
 }
 template <int INTYPE, int RS>
 hipError_t launch_team1664_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
-	if (roll) {  // rolling average inside the team: uint16 rows, not together with the background removal in the store
+	if (roll) {  // rolling average inside the team: uint16 rows
 		if constexpr (INTYPE == IN_U16) {
-			if (a.bgTerm) return hipErrorInvalidValue;
+			if (a.bgTerm) return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_ROLL | MODE_BG>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_ROLL | MODE_BG>(a, stream);
 			return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_ROLL>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_ROLL>(a, stream);
 		} else return hipErrorInvalidValue;
 	}

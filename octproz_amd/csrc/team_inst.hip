@@ -28,9 +28,9 @@ hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
 }
 template <int LOG2N, int RS>
 hipError_t launch_team_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
-	if (roll) {  // rolling average inside the team: uint16 rows, not together with the background removal in the store
+	if (roll) {  // rolling average inside the team: uint16 rows
 		if constexpr (kIn == IN_U16 && LOG2N >= 12) {
-			if (a.bgTerm) return hipErrorInvalidValue;
+			if (a.bgTerm) return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL | MODE_BG>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL | MODE_BG>(a, stream);
 			return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL>(a, stream);
 		} else return hipErrorInvalidValue;
 	}

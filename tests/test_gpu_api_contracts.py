@@ -185,6 +185,9 @@ _ROUTING = [
     (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 200, "bitDepth": 16}, 0, 0, _P.PATH_PREPARED_ROWS),  # sums not exact
     (1024, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_FUSED_BG),
     (1024, {"postProcessBackgroundRemoval": 1, "sinusoidalScanCorrection": 1}, 0, 0, 0),
+    (1024, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
+    (4096, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
+    (1664, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
     (1024, {"postProcessBackgroundRemoval": 1}, 0, _P.ROUTE_NO_FUSED_BG, 0),
     (1024, {"postProcessBackgroundRemoval": 1}, 1, 0, _P.PATH_FUSED_BG),                      # packed 12 bit, decoded in the kernel
     (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 8}, 1, 0, _P.PATH_PREPARED_ROWS),

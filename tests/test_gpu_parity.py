@@ -788,7 +788,7 @@ def test_team_kernel_of_1664_matches_oracle_and_the_one_wave_kernel(variant, A, 
 
 
 @pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096, 1664, 8192])
-@pytest.mark.parametrize("variant", ["v180", "no_dispersion", "linear_flip", "lanczos", "lin_scale"])
+@pytest.mark.parametrize("variant", ["v180", "no_dispersion", "linear_flip", "lanczos", "lin_scale", "rolling", "rolling_linear"])
 def test_background_removal_inside_the_fused_store_equals_the_post_pass(N, variant):
     """cu:757-767 saturate(v - (weight bg + offset)): without the sinusoidal correction the removal rides on the image store of
     the fused / real-input / mixed-radix kernels (MODE_BG) instead of a second pass over the volume.  Bit for bit the image of
@@ -800,6 +800,8 @@ def test_background_removal_inside_the_fused_store_equals_the_post_pass(N, varia
     {"v180": mutate(), "no_dispersion": mutate(dispersionCompensation=0),
      "linear_flip": mutate(resamplingInterpolation=INTERPOLATION.LINEAR, bscanFlip=1, dispersionCompensation=0),
      "lanczos": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS),
+     "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),  # the rolling average inside the kernel AND the removal in its store
+     "rolling_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=64, resamplingInterpolation=INTERPOLATION.LINEAR),
      "lin_scale": mutate(signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0)}[variant](p)
     p.signalGrayscaleMax, p.signalGrayscaleMin = (110.0, 20.0) if p.signalLogScaling else (900.0, 0.0)
     p.postProcessBackgroundRemoval = 1
