@@ -505,10 +505,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	const bool i16Direct = plainFused && h->sampleFormat == OCTPIPE_FORMAT_INT16;
 	if (u8Direct) intype = oct::IN_U8;
 	if (i16Direct) intype = oct::IN_I16;
-	// lengths on the library route that also have a team kernel (N = 8192): everything but Lanczos and the spectrum output runs
-	// on it, plain uint16 rows directly, other containers and the rolling average through the prepared float32 rows
-	const bool teamLib = h->libfft && h->d_twTeam && rs != oct::RS_LANCZOS && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
-	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && (!roll || rollInKernel);
+	// lengths on the library route that also have a team kernel (N = 8192): everything but the spectrum output runs on it, plain
+	// uint16 rows directly, other containers (and the rolling average in front of Lanczos) through the prepared float32 rows
+	const bool teamLib = h->libfft && h->d_twTeam && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
+	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO &&
+	                        (!roll || (rollInKernel && rs != oct::RS_LANCZOS));  // (rolling average in front of Lanczos: prepared rows)
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect) {
 		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
@@ -569,7 +570,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (teamLib && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && !roll && !p.dispersionCompensation &&
+	if (teamLib && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !p.dispersionCompensation &&
 	    !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
 		// N = 8192, real FFT input (no dispersion compensation): two A-scans per team transform
 		a.twiddle = h->d_twTeam;
@@ -629,7 +630,8 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		a.twiddle = h->d_twTeam;
 		path |= OCTPIPE_PATH_TEAM | OCTPIPE_PATH_REAL_INPUT;
 		HIP_TRY(oct::launch_team_real2(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
-	} else if (h->d_twTeam && intype != oct::IN_U32 && rs != oct::RS_LANCZOS && (!roll || intype == oct::IN_U16) && !spectrum &&
+	} else if (h->d_twTeam && intype != oct::IN_U32 && (rs != oct::RS_LANCZOS || ((intype == oct::IN_U16 || intype == oct::IN_F32) && !roll)) &&
+	           (!roll || intype == oct::IN_U16) && !spectrum &&
 	           !(h->route & OCTPIPE_ROUTE_NO_TEAM) && (p.dispersionCompensation || intype != oct::IN_U16 || !oct::real2n_supported(h->log2n))) {
 		// N = 4096: one A-scan per team of four waves, lane-invariant tables in registers (team_kernel.h); every raw container
 		// the general kernel reads directly (uint16, int16, uint8, packed 12 bit) and the prepared float32 rows (other

@@ -28,8 +28,8 @@ hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
 }
 template <int LOG2N, int RS>
 hipError_t launch_team_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
-	if (roll) {  // rolling average inside the team: uint16 rows
-		if constexpr (kIn == IN_U16 && LOG2N >= 12) {
+	if (roll) {  // rolling average inside the team: uint16 rows (in front of Lanczos the host prepares the rows)
+		if constexpr (kIn == IN_U16 && LOG2N >= 12 && RS != RS_LANCZOS) {
 			if (a.bgTerm) return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL | MODE_BG>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL | MODE_BG>(a, stream);
 			return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL>(a, stream);
 		} else return hipErrorInvalidValue;
@@ -44,6 +44,9 @@ hipError_t launch_team_rs(int rs, bool roll, bool logScale, const FusedArgs& a, 
 	case RS_NONE: return launch_team_mode<LOG2N, RS_NONE>(roll, logScale, a, stream);
 	case RS_LINEAR: return launch_team_mode<LOG2N, RS_LINEAR>(roll, logScale, a, stream);
 	case RS_CUBIC: return launch_team_mode<LOG2N, RS_CUBIC>(roll, logScale, a, stream);
+	case RS_LANCZOS:  // uint16 rows with their halos straight from the buffer, or prepared float32 rows
+		if constexpr ((kIn == IN_U16 || kIn == IN_F32) && LOG2N >= 12) return launch_team_mode<LOG2N, RS_LANCZOS>(roll, logScale, a, stream);
+		else return hipErrorInvalidValue;
 	default: return hipErrorInvalidValue;
 	}
 }

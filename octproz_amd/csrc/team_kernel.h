@@ -142,8 +142,12 @@ OCT_DEV void team_roll_stage(const u32x4 (&pre)[NL], uint32_t shift, int W, uint
 // IN_F32: float32 rows prepared by oct_prepare[_rows]_kernel (other containers, the rolling average)
 template <int LOG2N, int INTYPE, int RS, int MODE>
 __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const FusedArgs a) {
-	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "Lanczos taps cross line borders: general kernel");
+	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC || RS == RS_LANCZOS, "resampling mode");
 	static_assert(INTYPE == IN_U16 || INTYPE == IN_I16 || INTYPE == IN_U8 || INTYPE == IN_P12U || INTYPE == IN_P12S || INTYPE == IN_F32, "raw or prepared rows");
+	// Lanczos (cu:297-326): the row is staged with its 8-sample halos straight from the buffer (the taps cross line borders, and
+	// line 0 reads 8 samples late: cu:313-314); the 16 tap weights of a sample are A-scan invariant and come from the table the
+	// host computed (FusedArgs::lanczosW, [sample][16], L2 resident), summed in the reference's order -- as in the general kernel
+	static_assert(RS != RS_LANCZOS || ((INTYPE == IN_U16 || INTYPE == IN_F32) && (MODE & MODE_ROLL) == 0), "Lanczos: uint16 or prepared rows, no in-team rolling average");
 	typedef Team<LOG2N> TM;
 	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3, NB3 = TM::NB3, NBINS = 8;
 	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, FOUR = TM::FOUR, ROLL = (MODE & MODE_ROLL) != 0;
@@ -181,8 +185,11 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		} else if constexpr (RS == RS_LINEAR) {
 			fracR[q] = __builtin_amdgcn_fractf(t.x);
 			tapA[q] = tapBase + 4u * (uint32_t)(int)t.x + 4u;  // sample n1
+		} else if constexpr (RS == RS_LANCZOS) {
+			tapA[q] = tapBase + 4u * (uint32_t)(int)t.x + 4u - 28u;  // n0 = (int)rho: tap 0 = sample n0 - 7, tap 15 = sample n0 + 8
 		}
 	}
+	const __amdgpu_buffer_rsrc_t lanczosR = make_rsrc(a.lanczosW, N * 64u);
 	f2 tw2[15], tw3[NB3 * (R3 - 1)];
 #pragma unroll
 	for (int t = 1; t < 16; t++) tw2[t - 1] = a.twiddle[(t - 1) * 16 + (L & 15)];
@@ -211,12 +218,30 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	const unsigned rowBytes = (unsigned)(N / SPL) * CB;
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 	unsigned line = blockIdx.x;
-	u32x4 pre[NL];  // the lane's share of a raw row: samples SPL (T i + L) .. + SPL - 1
-	if (line < a.numLines) {
-		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
+	// Lanczos: 16-byte units of the window [off - 8, off + N + 8) of the buffer, off = clamp(line N, 8, S - 9) (cu:313-314), through a
+	// descriptor that ends with the buffer (reads past it return 0; N x element size and 16 are multiples of 16: aligned)
+	constexpr int SPU = INTYPE == IN_U16 ? 8 : 4, UNITS = (N + 16) / SPU, NLZ = (UNITS + T - 1) / T;
+	constexpr int NPRE = RS == RS_LANCZOS ? NLZ : NL;
+	u32x4 pre[NPRE];  // the lane's share of a raw row: samples SPL (T i + L) .. + SPL - 1 (Lanczos: units T i + L of the window)
+	auto prefetch = [&](unsigned ln) {
+		if constexpr (RS == RS_LANCZOS) {
+			constexpr int EB = INTYPE == IN_U16 ? 2 : 4;
+			const long long S = (long long)a.linesInBuffer * N;
+			long long off = (long long)ln * N;
+			if (off < 8) off = 8;
+			if (off > S - 9) off = S - 9;
+			const char* g = reinterpret_cast<const char*>(a.raw) + (off - 8) * EB;
+			const long long left = (S - (off - 8)) * EB, want = (long long)UNITS * 16;
+			const __amdgpu_buffer_rsrc_t haloR = make_rsrc(g, (uint32_t)(left < want ? left : want));
 #pragma unroll
-		for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, L * CB, i * T * CB);
-	}
+			for (int i = 0; i < NLZ; i++) pre[i] = __builtin_bit_cast(u32x4, buf_load128(haloR, L * 16, i * T * 16));  // units past the window: past the descriptor or unused
+		} else {
+			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * rowBytes, rowBytes);
+#pragma unroll
+			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, L * CB, i * T * CB);
+		}
+	};
+	if (line < a.numLines) prefetch(line);
 	const f2* rb = xbuf + (L + TM::PAD * (L >> 4));                       // strided read: element L + T q at rb[PITCH q]
 	f2* wb1 = xbuf + (16 + TM::PAD) * L;                                  // pass 1 output 16 L + u at wb1[u]
 	f2* wb2 = xbuf + ((256 + 16 * TM::PAD) * (L >> 4) + (L & 15));        // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[(16 + PAD) u]
@@ -226,6 +251,19 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		if constexpr (ROLL) {
 			team_roll_stage<T, N, NL>(pre, shift, a.rollingW, reinterpret_cast<uint32_t*>(xbuf),
 			                          reinterpret_cast<uint32_t*>(smem + team_lds_bytes<LOG2N, MODE>() - TEAM_ROLL_BYTES), row, L, RS == RS_CUBIC);
+		} else if constexpr (RS == RS_LANCZOS) {
+#pragma unroll
+			for (int i = 0; i < NLZ; i++) {
+				const int u = L + T * i;
+				if ((i + 1) * T <= UNITS || u < UNITS) {
+					if constexpr (INTYPE == IN_U16) {
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 8 * u]) = chunk_to_float<IN_U16>(pre[i], 0, shift);
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 8 * u + 4]) = chunk_to_float<IN_U16>(pre[i], 1, shift);
+					} else {
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 4 * u]) = chunk_to_float<IN_F32>(pre[i], 0, 0u);
+					}
+				}
+			}
 		} else
 #pragma unroll
 		for (int i = 0; i < NL; i++) {
@@ -238,12 +276,7 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 				}
 			}
 		}
-		const unsigned next = line + gridDim.x;
-		if (next < a.numLines) {
-			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
-#pragma unroll
-			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, L * CB, i * T * CB);
-		}
+		if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
 		team_barrier();  // the row is complete
 
 		// ---- k-linearisation x window x dispersion phasor
@@ -259,6 +292,15 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 			} else if constexpr (RS == RS_LINEAR) {
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
 				y = t[0] + (t[1] - t[0]) * fracR[q];  // cu:225-228
+			} else if constexpr (RS == RS_LANCZOS) {
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);  // t[0] = sample n0 - 7
+				f32x4 w[4];
+#pragma unroll
+				for (int c = 0; c < 4; c++) w[c] = buf_load128(lanczosR, L * 64, q * T * 64 + c * 16);
+				float sum = 0.0f;
+#pragma unroll
+				for (int i = 0; i < 16; i++) sum += t[i] * w[i >> 2][i & 3];  // the order of cu:315-321
+				y = sum;
 			} else {
 				y = row[ROW_OFF + L + T * q];
 			}

@@ -199,12 +199,16 @@ _ROUTING = [
     (4096, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
     (4096, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, _P.ROUTE_NO_TEAM, _P.PATH_ROLL_IN_KERNEL),
     (4096, {"postProcessBackgroundRemoval": 1}, 2, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG),       # signed packed 12 bit
-    (4096, {"resamplingInterpolation": 2}, 0, 0, 0),                                           # Lanczos: one-wave kernel
+    (4096, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_TEAM),                                # Lanczos on the team kernel
+    (4096, {"resamplingInterpolation": 2}, 0, _P.ROUTE_NO_TEAM, 0),
+    (4096, {"resamplingInterpolation": 2, "backgroundRemoval": 1, "rollingAverageWindowSize": 16}, 0, 0, _P.PATH_TEAM | _P.PATH_PREPARED_ROWS),
     (8192, {}, 0, 0, _P.PATH_TEAM),
     (8192, {"dispersionCompensation": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_REAL_INPUT),
     (8192, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
     (8192, {"bitDepth": 16}, 4, 0, _P.PATH_TEAM | _P.PATH_PREPARED_ROWS),                      # int16 comes prepared at this length
-    (8192, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
+    (8192, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_TEAM),
+    (8192, {"resamplingInterpolation": 2}, 0, _P.ROUTE_NO_TEAM, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
+    (8192, {"resamplingInterpolation": 2, "dispersionCompensation": 0}, 0, 0, _P.PATH_TEAM),
     (1664, {}, 0, 0, _P.PATH_TEAM),
     (1664, {"resamplingInterpolation": 0}, 0, 0, _P.PATH_MIXED_RADIX),
     (1664, {"dispersionCompensation": 0}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_REAL_INPUT),

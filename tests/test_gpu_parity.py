@@ -364,7 +364,7 @@ def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
 
 
 @pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (130, 3)])
-@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg", "rolling", "rolling256_linear"])
+@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg", "rolling", "rolling256_linear", "lanczos", "lanczos_rolling_flip"])
 def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B):
     """N = 8192: one A-scan per team of EIGHT waves (team_kernel.h: plan 16 x 16 x 16 x 2, three exchanges fenced with
     s_barrier); OCTPIPE_ROUTE_NO_TEAM keeps the library route (gather -> hipFFT -> epilogue).  Both against the oracle's O(N^2)
@@ -378,6 +378,8 @@ def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B)
      "no_dispersion": mutate(dispersionCompensation=0),
      "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),  # inside the team: team_roll_stage
      "rolling256_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=256, resamplingInterpolation=INTERPOLATION.LINEAR),
+     "lanczos": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS),  # halos straight from the buffer, weights table through L2
+     "lanczos_rolling_flip": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS, backgroundRemoval=1, rollingAverageWindowSize=16, bscanFlip=1),  # prepared rows
      "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
                          signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
     if A * B < 18:
@@ -702,7 +704,7 @@ def test_postprocess_background_record_and_remove():
 
 
 @pytest.mark.parametrize("A,B", [(25, 3), (1, 1), (300, 3)])
-@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg", "rolling", "rolling256_linear"])
+@pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg", "rolling", "rolling256_linear", "lanczos", "lanczos_rolling_flip"])
 def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, B):
     """N = 4096 runs one A-scan per team of four waves (team_kernel.h: 16 x 16 x 16 plan, exchanges fenced with s_barrier,
     lane-invariant tables in registers); OCTPIPE_ROUTE_NO_TEAM keeps the one-wave kernel (64 x 16 x 4 plan, LUT through L2).
@@ -717,6 +719,8 @@ def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, 
      "no_dispersion": mutate(dispersionCompensation=0),
      "rolling": mutate(backgroundRemoval=1, rollingAverageWindowSize=24),  # inside the team: team_roll_stage
      "rolling256_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=256, resamplingInterpolation=INTERPOLATION.LINEAR),
+     "lanczos": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS),  # halos straight from the buffer, weights table through L2
+     "lanczos_rolling_flip": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS, backgroundRemoval=1, rollingAverageWindowSize=16, bscanFlip=1),  # prepared rows
      "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
                          signalGrayscaleMax=110.0, signalGrayscaleMin=20.0)}[variant](p)
     if A * B < 18:
