@@ -125,6 +125,9 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 #ifndef OCT_CVT_PERM
 #define OCT_CVT_PERM 1
 #endif
+#ifndef OCT_LANCZOS_AHEAD
+#define OCT_LANCZOS_AHEAD 2  // samples whose Lanczos weights are requested ahead of the sample being summed
+#endif
 #ifndef OCT_PADK
 #define OCT_PADK 1  // pad elements per 16 of the complex exchange layout (2 keeps a lane's 16 outputs 16-byte aligned)
 #endif
@@ -877,6 +880,18 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(3);
 		f2 v[P];
 		f32x4 wph2;
+		// Lanczos with the weights table behind L2: the four loads of sample q + LZ_AHEAD are issued before the taps of sample q are
+		// summed (left to itself hipcc waits for each sample's weights right after asking for them: one exposed L2 round trip per
+		// sample, 32 per A-scan at N = 2048)
+		constexpr bool LZ_GLOBAL = RS == RS_LANCZOS && !LZ_LDS;
+		constexpr int LZ_AHEAD = (LOG2N == 11 && OCT_LANCZOS_AHEAD > 1) ? 1 : OCT_LANCZOS_AHEAD;  // (N = 2048: 12 waves of 168 VGPRs, room for one sample ahead)
+		f32x4 lzw[LZ_GLOBAL ? LZ_AHEAD + 1 : 1][4];
+		if constexpr (LZ_GLOBAL) {
+#pragma unroll
+			for (int q = 0; q < LZ_AHEAD && q < P; q++)
+#pragma unroll
+				for (int c = 0; c < 4; c++) lzw[q][c] = buf_load128(lanczosR, lane * 64, q * 4096 + c * 16);
+		}
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			// {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
@@ -922,10 +937,16 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				const int n0 = (int)L.x;
 				const float* t = &row[ROW_OFF + n0];
 				f32x4 w[4];
+				if constexpr (LZ_GLOBAL) {
+					if (q + LZ_AHEAD < P) {
 #pragma unroll
-				for (int c = 0; c < 4; c++) {
-					if constexpr (LZ_LDS) w[c] = lzL[(q * 4 + c) * 64 + lane];
-					else w[c] = buf_load128(lanczosR, lane * 64, q * 4096 + c * 16);
+						for (int c = 0; c < 4; c++) lzw[(q + LZ_AHEAD) % (LZ_AHEAD + 1)][c] = buf_load128(lanczosR, lane * 64, (q + LZ_AHEAD) * 4096 + c * 16);
+					}
+#pragma unroll
+					for (int c = 0; c < 4; c++) w[c] = lzw[q % (LZ_AHEAD + 1)][c];
+				} else {
+#pragma unroll
+					for (int c = 0; c < 4; c++) w[c] = lzL[(q * 4 + c) * 64 + lane];
 				}
 				float sum = 0.0f;
 #pragma unroll

@@ -28,6 +28,9 @@
 namespace oct {
 
 constexpr int MR_N = 1664, MR_N1 = 32, MR_N2 = 52, MR_PITCH = 54, MR_WAVES = 8;
+#ifndef OCT_MR_LANCZOS_AHEAD
+#define OCT_MR_LANCZOS_AHEAD 1  // (234 VGPRs: room for one sample's weights ahead)
+#endif
 #ifndef MR_NREG_CUBIC
 #define MR_NREG_CUBIC 14   // samples per lane whose tap address + four tap weights live in registers (5 VGPRs each)
 #endif
@@ -273,6 +276,14 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 		// ---- stage A: gather x[52 n1 + n2] (k-linearisation x window x phasor), 32-point transform over n1
 		__builtin_amdgcn_s_setprio(3);
 		f2 v[32];
+		constexpr int LZ_AHEAD = OCT_MR_LANCZOS_AHEAD;
+		f32x4 lzw[RS == RS_LANCZOS ? LZ_AHEAD + 1 : 1][4];
+		if constexpr (RS == RS_LANCZOS) {
+#pragma unroll
+			for (int q = 0; q < LZ_AHEAD && q < N1; q++)
+#pragma unroll
+				for (int c = 0; c < 4; c++) lzw[q][c] = buf_load128(lanczosR, n2 * 16, mr_lanczos_unit(q, c, 0) * 16);
+		}
 #pragma unroll
 		for (int q = 0; q < N1; q++) {
 			const int j = N2 * q + n2;
@@ -283,8 +294,12 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 				const int n0 = (int)rhoL[j];
 				const float* t = &row[ROW_OFF + n0];
 				f32x4 w[4];
+				if (q + LZ_AHEAD < N1) {  // weights of sample q + LZ_AHEAD requested before sample q is summed (kernels.h)
 #pragma unroll
-				for (int c = 0; c < 4; c++) w[c] = buf_load128(lanczosR, n2 * 16, mr_lanczos_unit(q, c, 0) * 16);
+					for (int c = 0; c < 4; c++) lzw[(q + LZ_AHEAD) % (LZ_AHEAD + 1)][c] = buf_load128(lanczosR, n2 * 16, mr_lanczos_unit(q + LZ_AHEAD, c, 0) * 16);
+				}
+#pragma unroll
+				for (int c = 0; c < 4; c++) w[c] = lzw[q % (LZ_AHEAD + 1)][c];
 				float sum = 0.0f;
 #pragma unroll
 				for (int i = -7; i <= 8; i++) sum += t[i] * w[(i + 7) >> 2][(i + 7) & 3];  // the order of cu:315-321

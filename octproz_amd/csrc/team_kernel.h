@@ -282,6 +282,14 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		// ---- k-linearisation x window x dispersion phasor
 		__builtin_amdgcn_s_setprio(3);
 		f2 v[P];
+		constexpr int LZ_AHEAD = OCT_LANCZOS_AHEAD;  // (kernels.h: weights of sample q + LZ_AHEAD requested before sample q is summed)
+		f32x4 lzw[RS == RS_LANCZOS ? LZ_AHEAD + 1 : 1][4];
+		if constexpr (RS == RS_LANCZOS) {
+#pragma unroll
+			for (int q = 0; q < LZ_AHEAD && q < P; q++)
+#pragma unroll
+				for (int c = 0; c < 4; c++) lzw[q][c] = buf_load128(lanczosR, L * 64, q * T * 64 + c * 16);
+		}
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			float y;
@@ -295,8 +303,12 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 			} else if constexpr (RS == RS_LANCZOS) {
 				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);  // t[0] = sample n0 - 7
 				f32x4 w[4];
+				if (q + LZ_AHEAD < P) {
 #pragma unroll
-				for (int c = 0; c < 4; c++) w[c] = buf_load128(lanczosR, L * 64, q * T * 64 + c * 16);
+					for (int c = 0; c < 4; c++) lzw[(q + LZ_AHEAD) % (LZ_AHEAD + 1)][c] = buf_load128(lanczosR, L * 64, (q + LZ_AHEAD) * T * 64 + c * 16);
+				}
+#pragma unroll
+				for (int c = 0; c < 4; c++) w[c] = lzw[q % (LZ_AHEAD + 1)][c];
 				float sum = 0.0f;
 #pragma unroll
 				for (int i = 0; i < 16; i++) sum += t[i] * w[i >> 2][i & 3];  // the order of cu:315-321
