@@ -218,6 +218,12 @@ OCT_DEV u32x4 load_chunk(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
 }
 
 // cu:119-121 / cu:139-141: uint16 -> float (exact), optional >> 4; samples 4h..4h+3 of the chunk
+// The same chunk (four uint16 samples) of TWO rows as the interleaved floats the real-input kernels stage: lo = (row0[0], row1[0],
+// row0[1], row1[1]), hi = samples 2 and 3.  The packed subtraction of the v_perm_b32 conversion below pairs the two ROWS, so
+// every result lands in its place of the 16-byte LDS write (converted per row first, the pairs have to be shuffled: ~38 v_mov
+// per pair of A-scans at N = 1024)
+OCT_DEV void chunk_pair_to_float_ilv(u32x2 r0, u32x2 r1, uint32_t s, float4& lo, float4& hi);
+
 template <int INTYPE>
 OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 	if constexpr (INTYPE == IN_U16) {
@@ -265,6 +271,22 @@ OCT_DEV float4 chunk_to_float(u32x4 c, int h, uint32_t s) {
 }
 
 // the four integer samples 4h..4h+3 of a uint16 chunk (after the optional >> 4), for the rolling-average prefix sums
+OCT_DEV void chunk_pair_to_float_ilv(u32x2 r0, u32x2 r1, uint32_t s, float4& lo, float4& hi) {
+#if OCT_CVT_PERM
+	if (s == 0) {
+		const uint32_t M = 0x4B000000u;
+		const f2 K = f2{8388608.0f, 8388608.0f};
+		auto pr = [&](uint32_t a, uint32_t b, uint32_t sel) { return f2{__builtin_bit_cast(float, __builtin_amdgcn_perm(M, a, sel)), __builtin_bit_cast(float, __builtin_amdgcn_perm(M, b, sel))} - K; };
+		const f2 p0 = pr(r0.x, r1.x, 0x07060100u), p1 = pr(r0.x, r1.x, 0x07060302u), p2 = pr(r0.y, r1.y, 0x07060100u), p3 = pr(r0.y, r1.y, 0x07060302u);
+		lo = float4{p0.x, p0.y, p1.x, p1.y};
+		hi = float4{p2.x, p2.y, p3.x, p3.y};
+		return;
+	}
+#endif
+	const float4 a = chunk_to_float<IN_U16>(u32x4{r0.x, r0.y, 0u, 0u}, 0, s), b = chunk_to_float<IN_U16>(u32x4{r1.x, r1.y, 0u, 0u}, 0, s);
+	lo = float4{a.x, b.x, a.y, b.y};
+	hi = float4{a.z, b.z, a.w, b.w};
+}
 OCT_DEV uint4 chunk_to_uint(u32x4 c, int h, uint32_t s) {
 	const uint32_t a = h ? c.z : c.x, b = h ? c.w : c.y;
 	return uint4{(a & 0xffffu) >> s, (a >> 16) >> s, (b & 0xffffu) >> s, (b >> 16) >> s};

@@ -124,12 +124,12 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_real2_kernel(c
 		// ---- stage both rows interleaved as float32 (the last chunk covers samples 1536 .. 1663: lanes 0..31 only)
 #pragma unroll
 		for (int c = 0; c < NL; c++) {
-			const float4 r0 = chunk_to_float<IN_U16>(u32x4{pre[c].x, pre[c].y, 0u, 0u}, 0, shift);
-			const float4 r1 = chunk_to_float<IN_U16>(u32x4{pre[NL + c].x, pre[NL + c].y, 0u, 0u}, 0, shift);
+			float4 lo4, hi4;
+			chunk_pair_to_float_ilv(pre[c], pre[NL + c], shift, lo4, hi4);
 			float* dst = reinterpret_cast<float*>(rowp + ROW_OFF + 4 * lane + 256 * c);
 			if (c < NL - 1 || lane < (N - 256 * (NL - 1)) / 4) {
-				*reinterpret_cast<float4*>(dst) = float4{r0.x, r1.x, r0.y, r1.y};
-				*reinterpret_cast<float4*>(dst + 4) = float4{r0.z, r1.z, r0.w, r1.w};
+				*reinterpret_cast<float4*>(dst) = lo4;
+				*reinterpret_cast<float4*>(dst + 4) = hi4;
 			}
 		}
 		if (pi + pairsStride < numPairs) prefetch(pi + pairsStride);

@@ -150,11 +150,11 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 		if constexpr (ILV) {
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
-				const float4 r0 = chunk_to_float<IN_U16>(u32x4{pre[c].x, pre[c].y, 0u, 0u}, 0, a.bitshift ? 4u : 0u);
-				const float4 r1 = chunk_to_float<IN_U16>(u32x4{pre[4 + c].x, pre[4 + c].y, 0u, 0u}, 0, a.bitshift ? 4u : 0u);
+				float4 lo4, hi4;
+				chunk_pair_to_float_ilv(pre[c], pre[4 + c], a.bitshift ? 4u : 0u, lo4, hi4);
 				float* dst = reinterpret_cast<float*>(rowp + ROW_OFF + 4 * lane + 256 * c);
-				*reinterpret_cast<float4*>(dst) = float4{r0.x, r1.x, r0.y, r1.y};
-				*reinterpret_cast<float4*>(dst + 4) = float4{r0.z, r1.z, r0.w, r1.w};
+				*reinterpret_cast<float4*>(dst) = lo4;
+				*reinterpret_cast<float4*>(dst + 4) = hi4;
 			}
 		} else {
 #pragma unroll

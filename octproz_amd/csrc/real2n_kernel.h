@@ -140,11 +140,18 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 		if constexpr (ILV) {
 #pragma unroll
 			for (int c = 0; c < NL; c++) {
-				const float4 r0 = chunk_to_float<IN_U16>(u32x4{pre[c].x, pre[c].y, 0u, 0u}, 0, shift);
-				const float4 r1 = chunk_to_float<IN_U16>(u32x4{pre[NL + c].x, pre[NL + c].y, 0u, 0u}, 0, shift);
+				float4 lo4, hi4;
+				if constexpr (LOG2N >= 11) {
+					chunk_pair_to_float_ilv(pre[c], pre[NL + c], shift, lo4, hi4);
+				} else {  // (N = 512 / 256: measured 2 % slower with the pair conversion)
+					const float4 r0 = chunk_to_float<IN_U16>(u32x4{pre[c].x, pre[c].y, 0u, 0u}, 0, shift);
+					const float4 r1 = chunk_to_float<IN_U16>(u32x4{pre[NL + c].x, pre[NL + c].y, 0u, 0u}, 0, shift);
+					lo4 = float4{r0.x, r1.x, r0.y, r1.y};
+					hi4 = float4{r0.z, r1.z, r0.w, r1.w};
+				}
 				float* dst = reinterpret_cast<float*>(rowp + ROW_OFF + 4 * lane + 256 * c);
-				*reinterpret_cast<float4*>(dst) = float4{r0.x, r1.x, r0.y, r1.y};
-				*reinterpret_cast<float4*>(dst + 4) = float4{r0.z, r1.z, r0.w, r1.w};
+				*reinterpret_cast<float4*>(dst) = lo4;
+				*reinterpret_cast<float4*>(dst + 4) = hi4;
 			}
 		} else {
 #pragma unroll

@@ -135,13 +135,13 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 		// ---- stage both rows interleaved as float32
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
-			const float4 r0 = chunk_to_float<IN_U16>(u32x4{pre[i].x, pre[i].y, 0u, 0u}, 0, shift);
-			const float4 r1 = chunk_to_float<IN_U16>(u32x4{pre[4 + i].x, pre[4 + i].y, 0u, 0u}, 0, shift);
+			float4 lo4, hi4;
+			chunk_pair_to_float_ilv(pre[i], pre[4 + i], shift, lo4, hi4);
 			float* dst = reinterpret_cast<float*>(rowp + ROW_OFF + 4 * (L + T * i));
-			*reinterpret_cast<float4*>(dst) = float4{r0.x, r1.x, r0.y, r1.y};
-			*reinterpret_cast<float4*>(dst + 4) = float4{r0.z, r1.z, r0.w, r1.w};
+			*reinterpret_cast<float4*>(dst) = lo4;
+			*reinterpret_cast<float4*>(dst + 4) = hi4;
 			if constexpr (RS == RS_CUBIC) {
-				if (i == 0 && L == 0) rowp[ROW_OFF - 1] = f2{r0.y, r1.y};  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
+				if (i == 0 && L == 0) rowp[ROW_OFF - 1] = f2{lo4.z, lo4.w};  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
 			}
 		}
 		if (pi + gridDim.x < numPairs) prefetch(pi + gridDim.x);
