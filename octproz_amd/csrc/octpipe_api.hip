@@ -332,6 +332,25 @@ int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, boo
 }
 
 // twiddles of the one-A-scan-per-team kernel (plan 16 x 16 x R3): [t-1][k] = e^{+2 pi i t k / (NS R)} per pass
+// Streams of destroyed handles are kept per device and handed to the next handle created there instead of being destroyed and
+// re-created: a host that opens and closes pipelines repeatedly (the test suite does, ~1 000 times per process) would otherwise
+// churn through the runtime's hardware-queue and signal pools (three streams, two of them with a priority, per handle).
+struct IdleStreams { hipStream_t compute, copy, out; };
+std::mutex g_idleMutex;
+std::map<int, std::vector<IdleStreams>> g_idleStreams;
+bool takeIdleStreams(int device, hipStream_t* compute, hipStream_t* copy, hipStream_t* out) {
+	std::lock_guard<std::mutex> lock(g_idleMutex);
+	auto& v = g_idleStreams[device];
+	if (v.empty()) return false;
+	*compute = v.back().compute; *copy = v.back().copy; *out = v.back().out;
+	v.pop_back();
+	return true;
+}
+void keepIdleStreams(int device, hipStream_t compute, hipStream_t copy, hipStream_t out) {
+	std::lock_guard<std::mutex> lock(g_idleMutex);
+	g_idleStreams[device].push_back(IdleStreams{compute, copy, out});
+}
+
 int uploadTeamTables(octpipe* h) {
 	std::vector<f2> tw((size_t)oct::team_twiddle_count(h->log2n));
 	size_t pos = 0;
@@ -1008,6 +1027,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	*out = h;  // from here on failures leave a handle the caller must destroy
 
 	HIP_TRY(hipSetDevice(device));
+	if (!takeIdleStreams(device, &h->stream, &h->copyStream, &h->outStream)) {
 	HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 	{
 		// The runtime multiplexes the streams of one priority onto a handful of hardware queues, in creation order over the
@@ -1024,6 +1044,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 			HIP_TRY(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
 			HIP_TRY(hipStreamCreateWithFlags(&h->outStream, hipStreamNonBlocking));
 		}
+	}
 	}
 	HIP_TRY(hipEventCreateWithFlags(&h->chainDone, hipEventDisableTiming));
 	h->destRead.assign(acq->buffersPerVolume < 2 ? 2 : acq->buffersPerVolume, nullptr);
@@ -1090,9 +1111,14 @@ int octpipe_destroy(octpipe_t* h) {
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_processedAlt, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
 	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW};
 	for (void* b : bufs) if (b) hipFree(b);
-	if (h->copyStream) hipStreamDestroy(h->copyStream);
-	if (h->outStream) hipStreamDestroy(h->outStream);
-	if (h->stream && h->ownStream) hipStreamDestroy(h->stream);
+	// the (drained) streams of the handle go to the idle list of the device; the next handle created there takes them over
+	if (h->stream && h->ownStream && h->copyStream && h->outStream) {
+		keepIdleStreams(h->device, h->stream, h->copyStream, h->outStream);
+	} else {
+		if (h->copyStream) hipStreamDestroy(h->copyStream);
+		if (h->outStream) hipStreamDestroy(h->outStream);
+		if (h->stream && h->ownStream) hipStreamDestroy(h->stream);
+	}
 	delete h;
 	return OCTPIPE_OK;
 }
