@@ -133,7 +133,15 @@ def test_group_with_one_submitting_thread_per_member(members, B):
     for k, r in enumerate(raws):
         g.octCudaPipeline(r)
         g.synchronize()
-        assert np.array_equal(g.processed_host().view(np.uint32), want[k].view(np.uint32)), "buffer %d" % k
+        got = g.processed_host()
+        if not np.array_equal(got.view(np.uint32), want[k].view(np.uint32)):
+            # (seen once in ~25 runs of the suite, never in isolation: say where and how much before failing)
+            bad = np.flatnonzero(got.view(np.uint32) != want[k].view(np.uint32))
+            per_bscan = N // 2 * A
+            again = g.processed_host()
+            pytest.fail("buffer %d: %d of %d values differ, B-scans %s, max |diff| %.3g, a second read-back %s" % (
+                k, bad.size, got.size, sorted(set((bad // per_bscan).tolist()))[:12], float(np.abs(got - want[k]).max()),
+                "agrees with the oracle run" if np.array_equal(again.view(np.uint32), want[k].view(np.uint32)) else "differs as well"))
     stats = system.run_group(g, max_buffers=8)
     system.stopAcquisition()
     assert stats.buffersProcessed == 8
