@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session", autouse=True)
-def _native_built():
+def _native_built(request):
     """The oracle is compiled on demand (gcc, seconds).  liboctpipe.so is built by
     __graft_entry__.build(); when it is missing we build it here once (hipcc cross-compiles on CPU)."""
     from oracle import octref
@@ -23,6 +23,21 @@ def _native_built():
     lib = os.path.join(ROOT, "octproz_amd", "liboctpipe.so")
     if not os.path.exists(lib):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "octproz_amd", "csrc"), "-j", "8"])
+    # a C call stack in front of faulthandler's Python stack should anything abort() (tests/native/abrt.c; installed here, behind
+    # pytest's own faulthandler set-up, whose handler it chains to)
+    abrt = os.path.join(ROOT, "tests", "native", "libabrt.so")
+    if os.path.exists(abrt):
+        try:
+            import ctypes
+            fd = -1
+            try:  # the duplicate of the real stderr that pytest's faulthandler plug-in writes to (fd 2 is captured during a test)
+                from _pytest.faulthandler import fault_handler_stderr_fd_key
+                fd = int(request.config.stash[fault_handler_stderr_fd_key])
+            except Exception:
+                fd = -1
+            ctypes.CDLL(abrt).abrt_install(fd)
+        except OSError:
+            pass
     yield
 
 
