@@ -164,6 +164,11 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 int octpipe_raw_buffer_bytes(const octpipe_t* h, size_t* bytes);
 /* cleanupCuda + releaseBuffers + destroyStreamsAndEvents, kernels.h:65-67 / cu:1164-1212 */
 int octpipe_destroy(octpipe_t* h);
+/* The three HIP streams of a destroyed handle are kept (at most 4 sets per device) and handed to the next handle created on
+ * that device, so that a host which opens and closes pipelines repeatedly does not churn the runtime's hardware queues.  This
+ * call destroys every idle set now -- e.g. before the host application resets the device.  Sets the runtime no longer
+ * recognises (hipStreamQuery fails) are never handed out. */
+int octpipe_release_idle_streams(void);
 /* parameter snapshot taken per call in the reference (params-> reads in cu:1409-1604) */
 int octpipe_set_params(octpipe_t* h, const OctPipeParams* params);
 int octpipe_get_acquisition_params(const octpipe_t* h, OctPipeAcquisitionParams* out);
@@ -216,51 +221,12 @@ int octpipe_copy_processed_to_host(octpipe_t* h, float* dst, size_t count, size_
 int octpipe_get_stream(octpipe_t* h, void** stream);
 int octpipe_set_stream(octpipe_t* h, void* stream);
 
-/* test / calibration hooks (no reference counterpart; used to pin the ill-conditioned FPN stage) */
+/* calibration hooks (no reference counterpart; the multi-GPU group and the tests pin the ill-conditioned FPN stage with them).
+ * Test-only entry points (stage outputs, route selection, which kernel ran) live in octpipe_debug.h, not here. */
 int octpipe_get_mean_line(octpipe_t* h, float* meanLineComplex /* 2*N floats */);
 int octpipe_set_mean_line(octpipe_t* h, const float* meanLineComplex /* 2*N floats */, int pin);
 /* run only getMinimumVarianceMean (cu:523-565) on a caller-supplied complex buffer [height][width] */
 int octpipe_min_variance_mean(octpipe_t* h, const float* d_or_h_complex, int isDevice, int width, int height, float* meanOutComplex);
-/* complex spectrum after IDFT (before mean subtraction) of the first `lines` A-scans of d_raw */
-int octpipe_debug_spectrum(octpipe_t* h, const void* d_raw, int lines, float* hostComplexOut);
-/* raw unpack (+ bitshift, + rolling average when enabled) of the first `count` samples of d_raw as
- * float32: the stage of cu:109-211 in isolation, for the bit-exactness test */
-int octpipe_debug_unpack(octpipe_t* h, const void* d_raw, size_t count, float* hostOut);
-/* route uint16 input through the float32 "prepared" path as well (normally only uint8/uint32 input
- * and the Lanczos variant take it); lets a test prove fused-unpack == standalone unpack bit-for-bit */
-int octpipe_debug_force_prepared(octpipe_t* h, int enable);
-/* Route selection for tests and A/B measurements: where two independent implementations of a stage exist, these flags keep
- * a configuration on the slower / more general one so that the tests can hold one against the other.  Flags of an existing
- * handle take effect with the next buffer; the FFT-backend flags are read when a handle is created: call with h = NULL to
- * set them for the handles this THREAD creates afterwards (0 restores the default choice).  No environment variable is read
- * anywhere in the library. */
-enum {
-	OCTPIPE_ROUTE_NO_REAL_INPUT = 1,   /* dispersion compensation off: keep the general kernel instead of the two-A-scans-per-transform kernels */
-	OCTPIPE_ROUTE_NO_FUSED_BG   = 2,   /* post-process background removal always as the post pass (cu:1567), never inside the image store */
-	OCTPIPE_ROUTE_FULL_DISPLAY  = 4,   /* display frames re-extracted from the whole volume for every buffer (cu:1571-1578 literally) */
-	OCTPIPE_ROUTE_NO_TEAM       = 8,   /* samplesPerLine = 4096 / 1664: keep the one-wave-per-A-scan kernel instead of the team kernel (8192: the library route) */
-	OCTPIPE_ROUTE_NO_LIBFFT     = 16,  /* creation: Bluestein on the in-register FFT instead of hipFFT for lengths without a fused kernel (<= 2047) */
-	OCTPIPE_ROUTE_FORCE_LIBFFT  = 32,  /* creation: every length through unpack -> gather -> hipFFT -> epilogue (the reference's pass structure) */
-	OCTPIPE_ROUTE_NO_MIXED      = 64   /* creation: samplesPerLine = 1664 without the mixed-radix kernel */
-};
-int octpipe_debug_set_route(octpipe_t* h_or_null, unsigned flags);
-/* persistent-grid size (workgroups) of the last launch of the general fused kernel: each kernel variant has its own
- * occupancy-derived grid, whatever was launched before it in the process */
-int octpipe_debug_last_grid(const octpipe_t* h, int* blocks);
-/* which implementation the image launch of the last processed buffer took (tests pin the routing with it: a silent fall-back
- * to a slower but equally correct path would otherwise go unnoticed) */
-enum {
-	OCTPIPE_PATH_PREPARED_ROWS = 1,   /* a row kernel / unpack kernel wrote float32 rows in front of the transform kernel */
-	OCTPIPE_PATH_FUSED_BG      = 2,   /* post-process background removal inside the image store */
-	OCTPIPE_PATH_TEAM          = 4,   /* one A-scan (or pair) per team of waves: team_kernel.h, team_real2_kernel.h, team1664_kernel.h */
-	OCTPIPE_PATH_REAL_INPUT    = 8,   /* two A-scans per complex transform */
-	OCTPIPE_PATH_LIBRARY_FFT   = 16,  /* gather -> hipFFT -> epilogue */
-	OCTPIPE_PATH_ROLL_IN_KERNEL = 32, /* rolling average inside the transform kernel */
-	OCTPIPE_PATH_MIXED_RADIX   = 64,  /* mixed1664.h / mixed1664_real2.h */
-	OCTPIPE_PATH_BLUESTEIN     = 128
-};
-int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
-
 /* ------------------------------------------------------------------ result delivery
  * cuda_registerStreamingBuffers / cuda_unregisterStreamingBuffers (kernels.h:69-70, cu:659-675)
  * and the float variants (kernels.h:71-72, cu:677-695): two host buffers, filled alternately
@@ -303,17 +269,35 @@ int octpipe_register_gl_buffer_volume_view(unsigned buf); /* always OCTPIPE_ERR_
 typedef struct octpipe_group octpipe_group_t;
 int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acqWholeBuffer,
                          const OctPipeParams* params, void* h_buffer1, void* h_buffer2);          /* initializeCuda */
+/* The same with options.  octpipe_group_create == flags 0: submitting threads exactly when every member has a device of its
+ * own, and NO change to the caller's memory policy.
+ *   OCTPIPE_GROUP_PLACE_RING_SLABS  move the pages of every member's slab of the two ring slots to the NUMA node of that member's
+ *                                   GPU before pinning them (mbind MPOL_PREFERRED | MPOL_MF_MOVE on the caller's buffers, best
+ *                                   effort; octpipe_group_info reports how many slabs could be placed).  A side effect on memory
+ *                                   the caller owns, hence opt-in.
+ *   OCTPIPE_GROUP_NO_SUBMIT_THREADS the caller's thread submits to every member even on distinct devices
+ *   OCTPIPE_GROUP_SUBMIT_THREADS    one submitting thread per member even when members share a device
+ * On failure *out is NULL and everything the call had allocated (member handles, communicators, staging buffers, pinning of
+ * the ring slots) has been released again; octpipe_group_last_error() names the step and the member that failed. */
+enum { OCTPIPE_GROUP_PLACE_RING_SLABS = 1, OCTPIPE_GROUP_NO_SUBMIT_THREADS = 2, OCTPIPE_GROUP_SUBMIT_THREADS = 4 };
+int octpipe_group_create_ex(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acqWholeBuffer,
+                            const OctPipeParams* params, void* h_buffer1, void* h_buffer2, unsigned flags);
 int octpipe_group_destroy(octpipe_group_t* g);                                                     /* cleanupCuda */
 int octpipe_group_size(const octpipe_group_t* g);
 octpipe_t* octpipe_group_member(octpipe_group_t* g, int i);   /* NULL for a member without B-scans */
 int octpipe_group_slab(const octpipe_group_t* g, int i, unsigned* firstBscan, unsigned* bscanCount);
 /* One submitting host thread per member (persistent, asleep between buffers): on by default when the members sit on distinct
  * devices, so that the n enqueue sequences of a call run side by side instead of one after the other; can be switched on
- * for members that share a device (tests on a one-GPU box) and off.  octpipe_group_info reports the thread count (0 = the
- * caller's thread submits) and how many member slabs of the ring slots could be moved to the NUMA node of their GPU
- * (mbind, best effort; 0 on single-node hosts or where the container forbids it). */
+ * for members that share a device (tests on a one-GPU box) and off.  A caller-owned host buffer that is NOT one of the two
+ * registered ring slots (h_buffer1 / h_buffer2 of the creation call, pinned there) is submitted member after member by the
+ * caller's thread instead: the threads only ever start DMA transfers out of pinned memory, never concurrent on-the-fly pinning
+ * or staging of pageable memory (octpipe_group_serial_submit_count counts such calls).
+ * octpipe_group_info reports the thread count (0 = the caller's thread submits) and how many member slabs of the ring slots
+ * were moved to the NUMA node of their GPU (only with OCTPIPE_GROUP_PLACE_RING_SLABS; 0 on single-node hosts or where the
+ * container forbids mbind). */
 int octpipe_group_set_submit_threads(octpipe_group_t* g, int enable);
 int octpipe_group_info(const octpipe_group_t* g, int* submitThreads, int* slabsPlacedOnGpuNode);
+uint64_t octpipe_group_serial_submit_count(const octpipe_group_t* g);
 const char* octpipe_group_backend(const octpipe_group_t* g);   /* "rccl" or "copy" */
 uint64_t octpipe_group_broadcast_count(const octpipe_group_t* g);
 const char* octpipe_group_last_error(void);

@@ -1,0 +1,65 @@
+/*
+ * octpipe_debug.h -- test and measurement hooks of liboctpipe.so.  NOT part of the drop-in boundary (octpipe.h): nothing here has
+ * a counterpart in the reference's kernels.h, and a host application never needs it.  The parity tests use these entry points
+ * to look at single stages (cu:109-211 unpack, the spectrum behind cu:1514-1515), to hold two implementations of a stage
+ * against each other, and to pin which implementation a configuration runs on.
+ */
+#ifndef OCTPIPE_DEBUG_H
+#define OCTPIPE_DEBUG_H
+
+#include "octpipe.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* complex spectrum after IDFT (before mean subtraction) of the first `lines` A-scans of d_raw */
+int octpipe_debug_spectrum(octpipe_t* h, const void* d_raw, int lines, float* hostComplexOut);
+/* raw unpack (+ bitshift, + rolling average when enabled) of the first `count` samples of d_raw as
+ * float32: the stage of cu:109-211 in isolation, for the bit-exactness test */
+int octpipe_debug_unpack(octpipe_t* h, const void* d_raw, size_t count, float* hostOut);
+/* route uint16 input through the float32 "prepared" path as well (normally only uint8/uint32 input
+ * and the Lanczos variant take it); lets a test prove fused-unpack == standalone unpack bit-for-bit */
+int octpipe_debug_force_prepared(octpipe_t* h, int enable);
+/* Route selection for tests and A/B measurements: where two independent implementations of a stage exist, these flags keep
+ * a configuration on the slower / more general one so that the tests can hold one against the other.  Flags of an existing
+ * handle take effect with the next buffer; the FFT-backend flags ("creation" below) are read when a handle is created and are
+ * passed to octpipe_debug_create.  No environment variable is read anywhere in the library, and no per-thread state either. */
+enum {
+	OCTPIPE_ROUTE_NO_REAL_INPUT = 1,   /* dispersion compensation off: keep the general kernel instead of the two-A-scans-per-transform kernels */
+	OCTPIPE_ROUTE_NO_FUSED_BG   = 2,   /* post-process background removal always as the post pass (cu:1567), never inside the image store */
+	OCTPIPE_ROUTE_FULL_DISPLAY  = 4,   /* display frames re-extracted from the whole volume for every buffer (cu:1571-1578 literally) */
+	OCTPIPE_ROUTE_NO_TEAM       = 8,   /* samplesPerLine = 4096 / 1664: keep the one-wave-per-A-scan kernel instead of the team kernel (8192: the library route) */
+	OCTPIPE_ROUTE_NO_LIBFFT     = 16,  /* creation: Bluestein on the in-register FFT instead of hipFFT for lengths without a fused kernel (<= 2047) */
+	OCTPIPE_ROUTE_FORCE_LIBFFT  = 32,  /* creation: every length through unpack -> gather -> hipFFT -> epilogue (the reference's pass structure) */
+	OCTPIPE_ROUTE_NO_MIXED      = 64   /* creation: samplesPerLine = 1664 without the mixed-radix kernel */
+};
+int octpipe_debug_set_route(octpipe_t* h, unsigned flags);
+/* octpipe_create_with_format with OCTPIPE_ROUTE_* flags from the start (the creation-time ones select the FFT backend) */
+int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
+                         void* h_buffer1, void* h_buffer2, int sampleFormat, unsigned routeFlags);
+/* what the device holds in the raw slot of the last octpipe_process[_async] call (slot < 0) or in slot 0 / 1: `bytes` bytes from
+ * its start, copied on the handle's compute stream behind everything enqueued there.  Lets the group stress harness tell a
+ * wrong host-to-device copy from a wrong kernel result. */
+int octpipe_debug_read_raw_slot(octpipe_t* h, int slot, void* dst, size_t bytes);
+/* persistent-grid size (workgroups) of the last launch of the general fused kernel: each kernel variant has its own
+ * occupancy-derived grid, whatever was launched before it in the process */
+int octpipe_debug_last_grid(const octpipe_t* h, int* blocks);
+/* which implementation the image launch of the last processed buffer took (tests pin the routing with it: a silent fall-back
+ * to a slower but equally correct path would otherwise go unnoticed) */
+enum {
+	OCTPIPE_PATH_PREPARED_ROWS = 1,   /* a row kernel / unpack kernel wrote float32 rows in front of the transform kernel */
+	OCTPIPE_PATH_FUSED_BG      = 2,   /* post-process background removal inside the image store */
+	OCTPIPE_PATH_TEAM          = 4,   /* one A-scan (or pair) per team of waves: team_kernel.h, team_real2_kernel.h, team1664_kernel.h */
+	OCTPIPE_PATH_REAL_INPUT    = 8,   /* two A-scans per complex transform */
+	OCTPIPE_PATH_LIBRARY_FFT   = 16,  /* gather -> hipFFT -> epilogue */
+	OCTPIPE_PATH_ROLL_IN_KERNEL = 32, /* rolling average inside the transform kernel */
+	OCTPIPE_PATH_MIXED_RADIX   = 64,  /* mixed1664.h / mixed1664_real2.h */
+	OCTPIPE_PATH_BLUESTEIN     = 128
+};
+int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTPIPE_DEBUG_H */

@@ -1,4 +1,4 @@
-"""ctypes view of liboctpipe.so (include/octpipe.h, include/octhost.h).
+"""ctypes view of liboctpipe.so (include/octpipe.h, include/octhost.h; test hooks: include/octpipe_debug.h).
 
 The library is the product; this module only loads it.  It never falls back to anything:
 if the shared object is missing or a HIP device is absent the corresponding call fails loudly.
@@ -10,9 +10,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")  # override: A/B builds only
 
 OCTPIPE_OK = 0
-# OCTPIPE_ROUTE_* (include/octpipe.h, octpipe_debug_set_route): keep a configuration on the slower / more general of two routes
+# OCTPIPE_ROUTE_* (include/octpipe_debug.h, octpipe_debug_set_route / octpipe_debug_create): keep a configuration on the slower / more general of two routes
 ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED = 1, 2, 4, 8, 16, 32, 64
-# octpipe_debug_last_path (include/octpipe.h OCTPIPE_PATH_*)
+# octpipe_debug_last_path (include/octpipe_debug.h OCTPIPE_PATH_*)
+# octpipe_group_create_ex flags (include/octpipe.h)
+GROUP_PLACE_RING_SLABS, GROUP_NO_SUBMIT_THREADS, GROUP_SUBMIT_THREADS = 1, 2, 4
 PATH_PREPARED_ROWS, PATH_FUSED_BG, PATH_TEAM, PATH_REAL_INPUT, PATH_LIBRARY_FFT, PATH_ROLL_IN_KERNEL, PATH_MIXED_RADIX, PATH_BLUESTEIN = 1, 2, 4, 8, 16, 32, 64, 128
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE"}
 
@@ -95,21 +97,24 @@ OCTPIPE_SYMBOLS = [
     "octpipe_calibration_size", "octpipe_export_calibration", "octpipe_import_calibration",
     "octpipe_process", "octpipe_process_async", "octpipe_wait_input", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
-    "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_debug_spectrum",
-    "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_last_grid", "octpipe_debug_last_path",
+    "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_release_idle_streams",
     "octpipe_register_streaming_buffers", "octpipe_unregister_streaming_buffers",
     "octpipe_register_float_streaming_buffers", "octpipe_unregister_float_streaming_buffers",
     "octpipe_set_callbacks",
     "octpipe_change_displayed_bscan_frame", "octpipe_change_displayed_enface_frame", "octpipe_get_display_buffers",
     "octpipe_get_volume_view_buffer", "octpipe_register_gl_buffer_bscan", "octpipe_register_gl_buffer_enface_view", "octpipe_register_gl_buffer_volume_view",
     "octpipe_enable_kernel_timing", "octpipe_kernel_timing",
-    "octpipe_group_create", "octpipe_group_destroy", "octpipe_group_size", "octpipe_group_member", "octpipe_group_slab",
-    "octpipe_group_set_submit_threads", "octpipe_group_info",
+    "octpipe_group_create", "octpipe_group_create_ex", "octpipe_group_destroy", "octpipe_group_size", "octpipe_group_member", "octpipe_group_slab",
+    "octpipe_group_set_submit_threads", "octpipe_group_info", "octpipe_group_serial_submit_count",
     "octpipe_group_backend", "octpipe_group_broadcast_count", "octpipe_group_last_error", "octpipe_group_set_params",
     "octpipe_group_update_resample_curve", "octpipe_group_update_dispersion_curve", "octpipe_group_update_window_curve",
     "octpipe_group_update_postprocess_background", "octpipe_group_set_mean_line", "octpipe_group_process",
     "octpipe_group_process_device", "octpipe_group_broadcast_calibration", "octpipe_group_synchronize",
     "octpipe_group_copy_processed_to_host",
+]
+OCTPIPE_DEBUG_SYMBOLS = [
+    "octpipe_debug_spectrum", "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_create",
+    "octpipe_debug_read_raw_slot", "octpipe_debug_last_grid", "octpipe_debug_last_path",
 ]
 OCTHOST_SYMBOLS = [
     "octhost_buffer_create", "octhost_buffer_destroy", "octhost_buffer_allocate", "octhost_buffer_release",
@@ -206,6 +211,9 @@ def lib():
         L.octpipe_debug_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.octpipe_debug_force_prepared.argtypes = [C.c_void_p, C.c_int]
         L.octpipe_debug_set_route.argtypes = [C.c_void_p, C.c_uint]
+        L.octpipe_debug_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
+        L.octpipe_debug_read_raw_slot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.octpipe_release_idle_streams.argtypes = []
         L.octpipe_debug_last_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.octpipe_debug_last_path.argtypes = [C.c_void_p, C.c_void_p]
         L.octhost_system_set_copy_threads.argtypes = [C.c_void_p, C.c_uint]
@@ -221,12 +229,15 @@ def lib():
         L.octpipe_process_async.argtypes = [C.c_void_p, C.c_void_p]
         L.octpipe_wait_input.argtypes = [C.c_void_p]
         L.octpipe_group_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.octpipe_group_create_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
         L.octpipe_group_member.restype = C.c_void_p
         L.octpipe_group_member.argtypes = [C.c_void_p, C.c_int]
         L.octpipe_group_backend.restype = C.c_char_p
         L.octpipe_group_backend.argtypes = [C.c_void_p]
         L.octpipe_group_broadcast_count.restype = C.c_uint64
         L.octpipe_group_broadcast_count.argtypes = [C.c_void_p]
+        L.octpipe_group_serial_submit_count.restype = C.c_uint64
+        L.octpipe_group_serial_submit_count.argtypes = [C.c_void_p]
         L.octpipe_group_last_error.restype = C.c_char_p
         L.octpipe_group_slab.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.octpipe_group_set_submit_threads.argtypes = [C.c_void_p, C.c_int]

@@ -64,6 +64,7 @@ hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool
 			return launch_out<IN_U16, RS_LANCZOS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 		}
 		if (roll) {
+			if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
 			switch (rs) {
 			case RS_NONE: return launch_out<IN_U16, RS_NONE, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 			case RS_LINEAR: return launch_out<IN_U16, RS_LINEAR, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);

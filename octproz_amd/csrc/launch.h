@@ -45,6 +45,11 @@ hipError_t kernel_launch_info(K kernel, int threads, size_t ldsBytes, KernelLaun
 	return hipSuccess;
 }
 
+// The in-kernel rolling average (MODE_ROLL of the fused / team kernels) indexes a [ROLL_PAD | N | ROLL_PAD] prefix-sum array in
+// LDS with j +- W and relies on integer window sums that equal the reference's float sums: every launcher refuses a window it
+// does not cover instead of trusting the host's routing (needsPrepared / rollInKernel) to stay in step with the kernels.
+inline bool roll_in_kernel_ok(const FusedArgs& a) { return a.rollingW > 0 && a.rollingW <= ROLL_PAD && a.rollExact != 0; }
+
 #define OCT_DECL_LAUNCH(L)                                                                                                  \
 	hipError_t launch_fused_##L(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,              \
 	                            int requestedBlocks, hipStream_t stream, int* blocksUsed);                                   \

@@ -12,11 +12,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/octpipe.h"
+#include "../../include/octpipe_debug.h"
 #include "host_luts.h"
 #include "launch.h"
 #include "side_kernels.h"
@@ -24,7 +26,6 @@
 namespace {
 
 thread_local std::string g_lastError;
-thread_local unsigned g_createRoute = 0;  // octpipe_debug_set_route(NULL, flags): FFT-backend flags for the handles this thread creates
 
 int fail(int code, const std::string& msg) {
 	g_lastError = msg;
@@ -162,6 +163,23 @@ void hostCallback(void* p) {
 	delete c;
 }
 
+// Every host<->device transfer that feeds (or reads what was produced by) kernels of this handle goes through the handle's own
+// compute stream and is waited for there.  The handle's streams are hipStreamNonBlocking, i.e. they do NOT synchronise with the
+// NULL stream: a plain hipMemcpy / hipMemset (NULL stream) is ordered against them only by the host-side wait inside the call,
+// which holds for a blocking hipMemcpy but not for hipMemset (asynchronous to the host), and several threads that each drive a
+// handle (octpipe_group_* with submitting threads) would meet on the one NULL stream of the device.  The reference uploads its
+// curves on the stream that consumes them, too (cu:636-650).
+int uploadSync(octpipe* h, void* dst, const void* src, size_t bytes) {
+	HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));  // src may be a temporary
+	return OCTPIPE_OK;
+}
+int downloadSync(octpipe* h, void* dst, const void* src, size_t bytes) {
+	HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return OCTPIPE_OK;
+}
+
 int gridFor(size_t n, int block = 256) {
 	size_t g = (n + block - 1) / block;
 	const size_t cap = 256 * 16;
@@ -243,17 +261,16 @@ int uploadTwiddles(octpipe* h) {
 		ns *= R;
 	}
 	HIP_TRY(hipMalloc(&h->d_twiddle, sizeof(f2) * (size_t)count));
-	HIP_TRY(hipMemcpy(h->d_twiddle, tw.data(), sizeof(f2) * (size_t)count, hipMemcpyHostToDevice));
-	return OCTPIPE_OK;
+	return uploadSync(h, h->d_twiddle, tw.data(), sizeof(f2) * (size_t)count);
 }
 
-int ensure(void** p, size_t bytes) {
+// lazily allocated, zero-filled device buffer.  The fill runs on the handle's compute stream and is waited for (a memset is
+// asynchronous to the host): whichever of the handle's streams touches the buffer next does so after this call has returned
+int ensure(octpipe* h, void** p, size_t bytes) {
 	if (*p) return OCTPIPE_OK;
 	HIP_TRY(hipMalloc(p, bytes));
-	// hipMemset runs on the NULL stream and is asynchronous to the host; the handle's streams are
-	// non-blocking, so without this wait the zero-fill could land after the first kernel's writes
-	HIP_TRY(hipMemset(*p, 0, bytes));
-	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemsetAsync(*p, 0, bytes, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
 	return OCTPIPE_OK;
 }
 
@@ -283,9 +300,8 @@ int uploadBluesteinTables(octpipe* h) {
 	for (int k = 0; k < N; ++k) chirp[k] = f2{(float)(cr[k] / M), (float)(ci[k] / M)};
 	HIP_TRY(hipMalloc((void**)&h->d_filter, sizeof(f2) * M));
 	HIP_TRY(hipMalloc((void**)&h->d_outChirp, sizeof(f2) * N));
-	HIP_TRY(hipMemcpy(h->d_filter, filter.data(), sizeof(f2) * M, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(h->d_outChirp, chirp.data(), sizeof(f2) * N, hipMemcpyHostToDevice));
-	return OCTPIPE_OK;
+	int rc = uploadSync(h, h->d_filter, filter.data(), sizeof(f2) * M);
+	return rc ? rc : uploadSync(h, h->d_outChirp, chirp.data(), sizeof(f2) * N);
 }
 
 // hipFFT for the lengths without a fused kernel, bound at run time (no link dependency; a process that already holds the
@@ -306,7 +322,7 @@ int bindFftLibrary(octpipe* h) {
 // gather -> batched inverse C2C -> epilogue for `lines` A-scans of the prepared float32 buffer (cufftExecC2C cu:1514-1515)
 int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, bool logScale) {
 	const size_t lines = a.numLines, N = (size_t)h->N;
-	int rc = ensure((void**)&h->d_cplx, sizeof(f2) * (size_t)h->A * h->B * N);
+	int rc = ensure(h, (void**)&h->d_cplx, sizeof(f2) * (size_t)h->A * h->B * N);
 	if (rc) return rc;
 	f2* work = spectrum ? a.spectrum : h->d_cplx;
 	hipLaunchKernelGGL(oct::oct_lib_gather_kernel, dim3(gridFor(lines * N)), dim3(256), 0, h->stream, reinterpret_cast<const float*>(a.raw), work, a.lut,
@@ -336,19 +352,38 @@ int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, boo
 // re-created: a host that opens and closes pipelines repeatedly (the test suite does, ~1 000 times per process) would otherwise
 // churn through the runtime's hardware-queue and signal pools (three streams, two of them with a priority, per handle).
 struct IdleStreams { hipStream_t compute, copy, out; };
+constexpr size_t kIdleStreamSetsPerDevice = 4;  // what a group of members sharing a device re-creates in a row; the rest is destroyed
 std::mutex g_idleMutex;
 std::map<int, std::vector<IdleStreams>> g_idleStreams;
+void destroyStreams(const IdleStreams& s) {
+	hipStreamDestroy(s.copy);
+	hipStreamDestroy(s.out);
+	hipStreamDestroy(s.compute);
+}
 bool takeIdleStreams(int device, hipStream_t* compute, hipStream_t* copy, hipStream_t* out) {
 	std::lock_guard<std::mutex> lock(g_idleMutex);
 	auto& v = g_idleStreams[device];
-	if (v.empty()) return false;
-	*compute = v.back().compute; *copy = v.back().copy; *out = v.back().out;
-	v.pop_back();
-	return true;
+	while (!v.empty()) {
+		const IdleStreams s = v.back();
+		v.pop_back();
+		// a set is handed out only if the runtime still knows all three streams as idle (a hipDeviceReset by the host
+		// application in between invalidates them: such a set is dropped, not destroyed)
+		if (hipStreamQuery(s.compute) == hipSuccess && hipStreamQuery(s.copy) == hipSuccess && hipStreamQuery(s.out) == hipSuccess) {
+			*compute = s.compute; *copy = s.copy; *out = s.out;
+			return true;
+		}
+		(void)hipGetLastError();
+	}
+	return false;
 }
 void keepIdleStreams(int device, hipStream_t compute, hipStream_t copy, hipStream_t out) {
-	std::lock_guard<std::mutex> lock(g_idleMutex);
-	g_idleStreams[device].push_back(IdleStreams{compute, copy, out});
+	const IdleStreams s{compute, copy, out};
+	{
+		std::lock_guard<std::mutex> lock(g_idleMutex);
+		auto& v = g_idleStreams[device];
+		if (v.size() < kIdleStreamSetsPerDevice) { v.push_back(s); return; }
+	}
+	destroyStreams(s);
 }
 
 int uploadTeamTables(octpipe* h) {
@@ -364,8 +399,7 @@ int uploadTeamTables(octpipe* h) {
 			}
 	if (pos != tw.size()) return fail(OCTPIPE_ERR_DEVICE, "team twiddle table size mismatch");
 	HIP_TRY(hipMalloc((void**)&h->d_twTeam, sizeof(f2) * tw.size()));
-	HIP_TRY(hipMemcpy(h->d_twTeam, tw.data(), sizeof(f2) * tw.size(), hipMemcpyHostToDevice));
-	return OCTPIPE_OK;
+	return uploadSync(h, h->d_twTeam, tw.data(), sizeof(f2) * tw.size());
 }
 
 // twiddles between the 32-point and the 52-point stage of the N = 1664 plan: W^{n2 k1}, W = e^{+2 pi i / 1664}, as [k1][n2]
@@ -378,7 +412,7 @@ int uploadMixedTables(octpipe* h) {
 			tw[(size_t)k1 * N2 + n2] = f2{(float)cos(ang), (float)sin(ang)};
 		}
 	HIP_TRY(hipMalloc((void**)&h->d_twMixed, sizeof(f2) * tw.size()));
-	HIP_TRY(hipMemcpy(h->d_twMixed, tw.data(), sizeof(f2) * tw.size(), hipMemcpyHostToDevice));
+	if (int rcUp = uploadSync(h, h->d_twMixed, tw.data(), sizeof(f2) * tw.size())) return rcUp;
 	HIP_TRY(hipMalloc((void**)&h->d_lutPlain, sizeof(float4) * N));
 	// the two-wave team kernel of the length (team1664_kernel.h, 13 x 16 x 8): [t-1][r] of pass 2, then [t-1][b] of pass 3
 	std::vector<f2> tt((size_t)oct::team1664_twiddle_count());
@@ -392,8 +426,7 @@ int uploadMixedTables(octpipe* h) {
 			}
 	if (pos != tt.size()) return fail(OCTPIPE_ERR_DEVICE, "team twiddle table size mismatch");
 	HIP_TRY(hipMalloc((void**)&h->d_twTeam, sizeof(f2) * tt.size()));
-	HIP_TRY(hipMemcpy(h->d_twTeam, tt.data(), sizeof(f2) * tt.size(), hipMemcpyHostToDevice));
-	return OCTPIPE_OK;
+	return uploadSync(h, h->d_twTeam, tt.data(), sizeof(f2) * tt.size());
 }
 
 // bytes of one raw buffer: S * bytesPerSample, 1.5 B/sample for the packed formats
@@ -446,14 +479,12 @@ int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int
 	// element-wise kernel with the ordered loop
 	const size_t rowsLds = rowsKernelLds(h);
 	if (rowsKernelApplies(h, rollingW, count)) {
-		static std::once_flag ldsOptIn[64];
 		const size_t lines = count / (size_t)h->N;
-		hipError_t e = hipSuccess;
-		std::call_once(ldsOptIn[h->device & 63], [&] {
-			e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-			if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-		});
-		HIP_TRY(e);
+		// > 64 KiB of dynamic LDS is an opt-in per kernel and device: the launch cache of launch.h remembers it per (kernel,
+		// device) and marks an entry ready only once the runtime has accepted it (a failure is reported by every call)
+		oct::KernelLaunchInfo li;
+		if (rowsKernelPerWave(h)) HIP_TRY(oct::kernel_launch_info(oct::oct_prepare_rows_wave_kernel, oct::PREP_WAVES * 64, 150 * 1024, &li));
+		else HIP_TRY(oct::kernel_launch_info(oct::oct_prepare_rows_kernel<512>, 512, 150 * 1024, &li));
 		if (rowsKernelPerWave(h)) {
 			const size_t blocks = (lines + oct::PREP_WAVES - 1) / oct::PREP_WAVES;
 			hipLaunchKernelGGL(oct::oct_prepare_rows_wave_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(oct::PREP_WAVES * 64), rowsLds, h->stream, d_raw, d_out,
@@ -464,11 +495,9 @@ int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int
 		}
 	} else if (rollingW >= 2 && count % (size_t)h->N == 0 && sizeof(float) * ((size_t)h->N + 2 * (size_t)rollingW + 3) <= 150 * 1024) {
 		// window sums that are not exact in float32: the reference's ordered loop, over a row staged in LDS
-		static std::once_flag ldsOptIn[64];
 		const size_t lines = count / (size_t)h->N, lds = sizeof(float) * ((size_t)h->N + 2 * (size_t)rollingW + 3);
-		hipError_t e = hipSuccess;
-		std::call_once(ldsOptIn[h->device & 63], [&] { e = hipFuncSetAttribute(reinterpret_cast<const void*>(oct::oct_prepare_rows_ordered_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
-		HIP_TRY(e);
+		oct::KernelLaunchInfo li;
+		HIP_TRY(oct::kernel_launch_info(oct::oct_prepare_rows_ordered_kernel<256>, 256, 150 * 1024, &li));
 		hipLaunchKernelGGL(oct::oct_prepare_rows_ordered_kernel<256>, dim3((unsigned)(lines < 8192 ? lines : 8192)), dim3(256), lds, h->stream, d_raw, d_out,
 		                   (int)h->acq.bitDepth, p.bitshift, rollingW, h->N, lines, h->sampleFormat);
 	} else {
@@ -530,7 +559,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO &&
 	                        (!roll || (rollInKernel && rs != oct::RS_LANCZOS));  // (rolling average in front of Lanczos: prepared rows)
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect) {
-		int rc = ensure((void**)&h->d_prepared, sizeof(float) * h->S);
+		int rc = ensure(h, (void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
 		if ((rc = launchPrepare(h, d_raw, h->d_prepared, h->S, roll ? p.rollingAverageWindowSize : 0))) return rc;
 		a.raw = h->d_prepared;
@@ -543,7 +572,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
 	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
 	if (wantBg && !spectrum && (!h->libfft || teamLib) && (useMixed || !h->bluestein)) {
-		int rc = ensure((void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
+		int rc = ensure(h, (void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
 		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {
 			hipLaunchKernelGGL(oct::oct_bg_term_kernel, dim3((h->N / 2 + 255) / 256), dim3(256), 0, h->stream, h->d_bgTerm, h->d_postBg,
@@ -709,7 +738,7 @@ int foldTimings(octpipe* h) {
 int minVarianceMean(octpipe* h, const f2* d_in, int width, int height, f2* d_meanOut) {
 	const int segs = 9;  // FIXED_PATTERN_NOISE_REMOVAL_SEGMENTS, octalgorithmparameters.h:35
 	const int segWidth = height / segs;
-	int rc = ensure((void**)&h->d_segs, sizeof(float4) * (size_t)segs * (size_t)std::max(width, h->N));
+	int rc = ensure(h, (void**)&h->d_segs, sizeof(float4) * (size_t)segs * (size_t)std::max(width, h->N));
 	if (rc) return rc;
 	hipLaunchKernelGGL(oct::oct_minvar_segments_kernel, dim3((width * segs + 255) / 256), dim3(256), 0, h->stream, d_in, width, segWidth, segs, h->d_segs);
 	HIP_TRY(hipGetLastError());
@@ -824,7 +853,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	unsigned dest = h->bufferNumberInVolume;
 	h->d_processedCur = h->d_processed;
 	if (h->acq.buffersPerVolume == 1 && floatStreaming) {
-		int rcAlt = ensure((void**)&h->d_processedAlt, sizeof(float) * (S / 2));
+		int rcAlt = ensure(h, (void**)&h->d_processedAlt, sizeof(float) * (S / 2));
 		if (rcAlt) return rcAlt;
 		h->altCur ^= 1;
 		dest = (unsigned)h->altCur;
@@ -843,7 +872,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	float* d_fusedOut = d_curr;
 	int rc;
 	if (p.sinusoidalScanCorrection) {
-		if ((rc = ensure((void**)&h->d_sinusTmp, sizeof(float) * (S / 2)))) return rc;
+		if ((rc = ensure(h, (void**)&h->d_sinusTmp, sizeof(float) * (S / 2)))) return rc;
 		d_fusedOut = h->d_sinusTmp;
 	}
 	const bool sinus = p.sinusoidalScanCorrection != 0;
@@ -878,7 +907,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	}
 	if (p.volumeViewEnabled) {  // cu:1579-1582
 		const unsigned W = (unsigned)(N / 2), BV = (unsigned)B * h->acq.buffersPerVolume;
-		if ((rc = ensure((void**)&h->d_volumeView, (size_t)W * BV * (size_t)A))) return rc;
+		if ((rc = ensure(h, (void**)&h->d_volumeView, (size_t)W * BV * (size_t)A))) return rc;
 		const unsigned tilesY = ((unsigned)A + 63) / 64, tilesR = (W + 63) / 64;
 		hipLaunchKernelGGL(oct::oct_volume_to_u8_kernel, dim3((unsigned)B * tilesY * tilesR), dim3(256), 0, h->stream, h->d_volumeView, d_curr,
 		                   W, (unsigned)A, (unsigned)B, BV, h->bufferNumberInVolume, tilesY, tilesR);
@@ -901,7 +930,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 		if (quantise) {  // the (fast) kernel first: the volume slot is released after the float copy below
 			h->streamingBufferNumber = (h->streamingBufferNumber + 1) % 2;
 			qdst = h->streamingBufferNumber == 0 ? h->h_stream[0] : h->h_stream[1];
-			rc = ensure(&h->d_output, (S / 2) * (size_t)h->bytesPerSample);
+			rc = ensure(h, &h->d_output, (S / 2) * (size_t)h->bytesPerSample);
 			if (rc) return rc;
 			const int qgrid = gridFor((S / 2) * (size_t)h->bytesPerSample / 16);
 			if (h->bytesPerSample == 1) hipLaunchKernelGGL(oct::oct_float_to_output_kernel<uint8_t>, dim3(qgrid), dim3(256), 0, h->outStream, (uint8_t*)h->d_output, d_curr, (int)h->acq.bitDepth, S / 2);
@@ -971,6 +1000,11 @@ int octpipe_raw_buffer_bytes(const octpipe_t* h, size_t* bytes) {
 
 int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
                                void* h_buffer1, void* h_buffer2, int sampleFormat) {
+	return octpipe_debug_create(out, device, acq, params, h_buffer1, h_buffer2, sampleFormat, 0u);
+}
+
+int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
+                         void* h_buffer1, void* h_buffer2, int sampleFormat, unsigned createRoute) {
 	if (!out || !acq || !params) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	*out = nullptr;
 	if (sampleFormat < OCTPIPE_FORMAT_AUTO || sampleFormat > OCTPIPE_FORMAT_INT32) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "unknown sample format");
@@ -983,7 +1017,6 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	// Lengths that are neither a power of two nor 1664: Bluestein on the in-register FFT (bluestein.h, up to 2047) or the library
 	// route; measured on MI355X the library route is 1.4-3x faster (N = 600: 160 vs 91 M A-scans/s, N = 2000: 48 vs 16 M), so it
 	// is the default where hipFFT can be loaded and Bluestein the fallback (OCTPIPE_ROUTE_NO_LIBFFT forces it).
-	const unsigned createRoute = g_createRoute;
 	const bool forceLib = (createRoute & OCTPIPE_ROUTE_FORCE_LIBFFT) != 0, noLib = (createRoute & OCTPIPE_ROUTE_NO_LIBFFT) != 0;
 	const bool noFused = !oct::fused_supported(acq->samplesPerLine) && acq->samplesPerLine != oct::kMixedLength;
 	const bool bluesteinOk = oct::bluestein_log2m(acq->samplesPerLine) >= 0;
@@ -1055,14 +1088,14 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 		HIP_TRY(hipEventCreateWithFlags(&h->slotFree[i], hipEventDisableTiming));
 	}
 	const size_t S = h->S;
-	if ((rc = ensure((void**)&h->d_processed, sizeof(float) * (S / 2) * acq->buffersPerVolume))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_processed, sizeof(float) * (S / 2) * acq->buffersPerVolume))) return rc;
 	h->d_processedCur = h->d_processed;
-	if ((rc = ensure((void**)&h->d_lut, sizeof(float4) * h->N))) return rc;
-	if ((rc = ensure((void**)&h->d_meanLine, sizeof(f2) * h->N))) return rc;
-	if ((rc = ensure((void**)&h->d_postBg, sizeof(float) * (h->N / 2)))) return rc;
-	if ((rc = ensure((void**)&h->d_sinusCurve, sizeof(float) * h->A))) return rc;
-	if ((rc = ensure((void**)&h->d_dispBscan, sizeof(float) * ((size_t)h->N * h->A / 2)))) return rc;
-	if ((rc = ensure((void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_lut, sizeof(float4) * h->N))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_meanLine, sizeof(f2) * h->N))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_postBg, sizeof(float) * (h->N / 2)))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_sinusCurve, sizeof(float) * h->A))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_dispBscan, sizeof(float) * ((size_t)h->N * h->A / 2)))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
 	if (h->libfft) { if ((rc = bindFftLibrary(h))) return rc; }
 	else if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
@@ -1074,7 +1107,7 @@ int octpipe_create_with_format(octpipe_t** out, int device, const OctPipeAcquisi
 	{  // cu:1093
 		std::vector<float> sc((size_t)h->A);
 		octhost::sinusoidal_curve((unsigned)h->A, sc.data());
-		HIP_TRY(hipMemcpy(h->d_sinusCurve, sc.data(), sizeof(float) * sc.size(), hipMemcpyHostToDevice));
+		if ((rc = uploadSync(h, h->d_sinusCurve, sc.data(), sizeof(float) * sc.size()))) return rc;
 	}
 	// ring slots: pinned here, unpinned in octpipe_destroy (cu:1135-1136, 1200-1207)
 	void* hb[2] = {h_buffer1, h_buffer2};
@@ -1209,10 +1242,9 @@ int octpipe_export_calibration(octpipe_t* h, void* blob, size_t size) {
 	std::memcpy(p, h->resample.data(), sizeof(float) * N); p += sizeof(float) * N;
 	std::memcpy(p, h->dispersion.data(), sizeof(float) * N); p += sizeof(float) * N;
 	std::memcpy(p, h->window.data(), sizeof(float) * N); p += sizeof(float) * N;
-	HIP_TRY(hipStreamSynchronize(h->stream));
-	HIP_TRY(hipMemcpy(p, h->d_meanLine, sizeof(float) * 2 * N, hipMemcpyDeviceToHost)); p += sizeof(float) * 2 * N;
-	HIP_TRY(hipMemcpy(p, h->d_postBg, sizeof(float) * (N / 2), hipMemcpyDeviceToHost));
-	return OCTPIPE_OK;
+	// behind everything the compute stream still has to do to them (the mean-line estimate of the buffer just enqueued)
+	HIP_TRY(hipMemcpyAsync(p, h->d_meanLine, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, h->stream)); p += sizeof(float) * 2 * N;
+	return downloadSync(h, p, h->d_postBg, sizeof(float) * (N / 2));
 }
 int octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size) {
 	if (!h || !blob || size < octpipe_calibration_size(h)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "calibration blob too small");
@@ -1226,9 +1258,9 @@ int octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size) {
 	std::memcpy(h->dispersion.data(), p, sizeof(float) * N); p += sizeof(float) * N;
 	std::memcpy(h->window.data(), p, sizeof(float) * N); p += sizeof(float) * N;
 	octhost::dispersive_phase(h->dispersion.data(), (unsigned)h->N, h->phase.data());
-	HIP_TRY(hipStreamSynchronize(h->stream));
-	HIP_TRY(hipMemcpy(h->d_meanLine, p, sizeof(float) * 2 * N, hipMemcpyHostToDevice)); p += sizeof(float) * 2 * N;
-	HIP_TRY(hipMemcpy(h->d_postBg, p, sizeof(float) * (N / 2), hipMemcpyHostToDevice));
+	// on the compute stream, i.e. behind the kernels already enqueued there and in front of those of the next buffer
+	HIP_TRY(hipMemcpyAsync(h->d_meanLine, p, sizeof(float) * 2 * N, hipMemcpyHostToDevice, h->stream)); p += sizeof(float) * 2 * N;
+	if ((rc = uploadSync(h, h->d_postBg, p, sizeof(float) * (N / 2)))) return rc;
 	h->bgVersion++;
 	std::memcpy(h->h_postBg.data(), p, sizeof(float) * (N / 2));
 	h->fpnDetermined = hd.fixedPatternNoiseDetermined != 0;
@@ -1243,7 +1275,7 @@ int octpipe_process_async(octpipe_t* h, const void* h_inputSignal) {
 	const size_t bytes = rawBytes(h);
 	const int s = h->slot;
 	h->slot ^= 1;
-	if ((rc = ensure(&h->d_raw[s], bytes))) return rc;
+	if ((rc = ensure(h, &h->d_raw[s], bytes))) return rc;
 	// the copy may not overwrite a raw slot the previous fused kernel is still reading
 	if (h->slotUsed[s]) HIP_TRY(hipStreamWaitEvent(h->copyStream, h->slotFree[s], 0));
 	HIP_TRY(hipMemcpyAsync(h->d_raw[s], h_inputSignal, bytes, hipMemcpyHostToDevice, h->copyStream));  // cu:1404
@@ -1345,11 +1377,11 @@ int octpipe_min_variance_mean(octpipe_t* h, const float* data, int isDevice, int
 	const size_t bytes = sizeof(f2) * (size_t)width * height;
 	if (!isDevice) {
 		HIP_TRY(hipMalloc((void**)&d_in, bytes));
-		HIP_TRY(hipMemcpy(d_in, data, bytes, hipMemcpyHostToDevice));
+		if ((rc = uploadSync(h, d_in, data, bytes))) { hipFree(d_in); return rc; }
 	}
 	HIP_TRY(hipMalloc((void**)&d_out, sizeof(f2) * width));
 	if (h->d_segs) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->d_segs)); h->d_segs = nullptr; }
-	rc = ensure((void**)&h->d_segs, sizeof(float4) * 9 * (size_t)std::max(width, h->N));
+	rc = ensure(h, (void**)&h->d_segs, sizeof(float4) * 9 * (size_t)std::max(width, h->N));
 	if (!rc) rc = minVarianceMean(h, isDevice ? reinterpret_cast<const f2*>(data) : d_in, width, height, d_out);
 	if (!rc) {
 		hipError_t e = hipMemcpyAsync(meanOut, d_out, sizeof(f2) * width, hipMemcpyDeviceToHost, h->stream);
@@ -1398,8 +1430,32 @@ int octpipe_debug_force_prepared(octpipe_t* h, int enable) {
 }
 
 int octpipe_debug_set_route(octpipe_t* h, unsigned flags) {
-	if (h) h->route = flags;
-	else g_createRoute = flags;
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	h->route = flags;
+	return OCTPIPE_OK;
+}
+int octpipe_debug_read_raw_slot(octpipe_t* h, int slot, void* dst, size_t bytes) {
+	if (!h || !dst) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	if (slot < 0) slot = h->lastInputSlot;
+	if (slot < 0 || slot > 1 || !h->d_raw[slot] || bytes > rawBytes(h)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "no such raw slot");
+	int rc = setDevice(h); if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->copyStream));
+	return downloadSync(h, dst, h->d_raw[slot], bytes);
+}
+int octpipe_release_idle_streams(void) {
+	std::map<int, std::vector<IdleStreams>> byDevice;
+	{
+		std::lock_guard<std::mutex> lock(g_idleMutex);
+		byDevice.swap(g_idleStreams);
+	}
+	int previous = 0;
+	const bool havePrevious = hipGetDevice(&previous) == hipSuccess;
+	for (auto& kv : byDevice) {
+		if (hipSetDevice(kv.first) != hipSuccess) continue;
+		for (const IdleStreams& s : kv.second) destroyStreams(s);
+	}
+	if (havePrevious) hipSetDevice(previous);
+	(void)hipGetLastError();
 	return OCTPIPE_OK;
 }
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path) {
@@ -1481,7 +1537,7 @@ int octpipe_get_volume_view_buffer(octpipe_t* h, void** d_voxels, size_t* bytes)
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	int rc = setDevice(h); if (rc) return rc;
 	const size_t n = (size_t)(h->N / 2) * (size_t)h->B * h->acq.buffersPerVolume * (size_t)h->A;
-	if ((rc = ensure((void**)&h->d_volumeView, n))) return rc;
+	if ((rc = ensure(h, (void**)&h->d_volumeView, n))) return rc;
 	if (d_voxels) *d_voxels = h->d_volumeView;
 	if (bytes) *bytes = n;
 	return OCTPIPE_OK;

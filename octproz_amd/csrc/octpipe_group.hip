@@ -172,6 +172,8 @@ struct octpipe_group {
 	std::vector<hipStream_t> commStreams;
 	std::vector<unsigned char> blob;
 	void* pinned[2] = {nullptr, nullptr};
+	size_t pinnedBytes = 0;              // size of each registered ring slot
+	uint64_t serialSubmits = 0;          // calls whose host buffer was not a registered ring slot: submitted by the caller's thread
 	uint64_t broadcasts = 0;
 };
 
@@ -198,7 +200,9 @@ int broadcastCalibration(octpipe_group* g) {
 	if (rc) return gfail(rc, octpipe_last_error());
 	if (g->useRccl) {
 		// device-to-device over xGMI: root stages the blob in HBM, one grouped ncclBroadcast, every member reads it back
-		if (hipSetDevice(g->devices[0]) != hipSuccess || hipMemcpy(g->d_blob[0], g->blob.data(), n, hipMemcpyHostToDevice) != hipSuccess)
+		// (on the communication stream of member 0, the stream its ncclBroadcast is enqueued on: in order without a NULL-stream copy)
+		if (hipSetDevice(g->devices[0]) != hipSuccess || hipMemcpyAsync(g->d_blob[0], g->blob.data(), n, hipMemcpyHostToDevice, g->commStreams[0]) != hipSuccess ||
+		    hipStreamSynchronize(g->commStreams[0]) != hipSuccess)
 			return gfail(OCTPIPE_ERR_DEVICE, "staging the calibration blob failed");
 		int e = g->rccl.GroupStart();
 		for (size_t i = 0; i < g->members.size() && e == 0; ++i)
@@ -209,8 +213,8 @@ int broadcastCalibration(octpipe_group* g) {
 		for (size_t i = 1; i < g->members.size(); ++i) {
 			if (!g->members[i]) continue;
 			std::vector<unsigned char> got(n);
-			if (hipSetDevice(g->devices[i]) != hipSuccess || hipStreamSynchronize(g->commStreams[i]) != hipSuccess ||
-			    hipMemcpy(got.data(), g->d_blob[i], n, hipMemcpyDeviceToHost) != hipSuccess)
+			if (hipSetDevice(g->devices[i]) != hipSuccess || hipMemcpyAsync(got.data(), g->d_blob[i], n, hipMemcpyDeviceToHost, g->commStreams[i]) != hipSuccess ||
+			    hipStreamSynchronize(g->commStreams[i]) != hipSuccess)
 				return gfail(OCTPIPE_ERR_DEVICE, "reading the broadcast calibration blob failed");
 			if ((rc = octpipe_import_calibration(g->members[i], got.data(), n))) return gfail(rc, octpipe_last_error());
 		}
@@ -253,11 +257,46 @@ int forMembersParallel(octpipe_group* g, size_t first, F f) {
 	return rc ? gfail(rc, err) : OCTPIPE_OK;
 }
 
+// whether [p, p + bytes) lies inside one of the two ring slots this group has registered with the runtime
+bool insideRingSlot(const octpipe_group* g, const void* p, size_t bytes) {
+	for (int k = 0; k < 2; ++k) {
+		const char* lo = static_cast<const char*>(g->pinned[k]);
+		if (lo && static_cast<const char*>(p) >= lo && static_cast<const char*>(p) + bytes <= lo + g->pinnedBytes) return true;
+	}
+	return false;
+}
+
+// ... or in memory the caller has pinned itself (hipHostRegister / hipHostMalloc): first and last byte known to the runtime as host memory
+bool pinnedByCaller(const void* p, size_t bytes) {
+	const char* ends[2] = {static_cast<const char*>(p), static_cast<const char*>(p) + bytes - 1};
+	for (const char* q : ends) {
+		hipPointerAttribute_t attr{};
+		if (hipPointerGetAttributes(&attr, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+		if (attr.type != hipMemoryTypeHost) return false;
+	}
+	return true;
+}
+
 int processCommon(octpipe_group* g, const void* h_buffer, const void* const* d_slabs) {
 	auto enqueue = [&](size_t i, octpipe_t* m) -> int {
 		if (h_buffer) return octpipe_process_async(m, static_cast<const char*>(h_buffer) + (size_t)g->first[i] * g->bytesPerBscan);
 		return octpipe_process_device(m, d_slabs[i]);
 	};
+	// The submitting threads copy their slabs straight out of the caller's buffer.  For a registered ring slot (the reference's
+	// only input, cu:1135-1136) that is n DMA transfers from pinned memory.  For any other host buffer the runtime would pin or
+	// stage pageable memory on the fly, from n threads at once, over ranges that share pages at the slab boundaries -- a path
+	// this library gains nothing from (a pageable hipMemcpyAsync blocks its caller for the staging copy anyway) and does not
+	// want to depend on: such a buffer is submitted member after member by the caller's thread.
+	MemberWorkers* const workers = g->workers;
+	struct WorkersOff {  // (restored on every return path)
+		octpipe_group* g; MemberWorkers* w;
+		~WorkersOff() { g->workers = w; }
+	} restore{g, workers};
+	const size_t wholeBuffer = g->bytesPerBscan * g->acq.bscansPerBuffer;
+	if (workers && h_buffer && !insideRingSlot(g, h_buffer, wholeBuffer) && !pinnedByCaller(h_buffer, wholeBuffer)) {
+		g->workers = nullptr;
+		g->serialSubmits++;
+	}
 	if (rootWillCalibrate(g)) {
 		// member 0 first: its slab starts with the buffer's first B-scans, which is where the reference takes the estimate from
 		int rc = enqueue(0, g->members[0]);
@@ -279,21 +318,11 @@ int processCommon(octpipe_group* g, const void* h_buffer, const void* const* d_s
 
 }  // namespace
 
-extern "C" {
+extern "C" const char* octpipe_group_last_error(void) { return g_groupError.c_str(); }
 
-const char* octpipe_group_last_error(void) { return g_groupError.c_str(); }
-
-int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
-                         void* h_buffer1, void* h_buffer2) {
-	if (!out || !devices || n <= 0 || !acq || !params) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
-	*out = nullptr;
-	octpipe_group* g = new octpipe_group();
-	g->devices.assign(devices, devices + n);
-	g->acq = *acq;
-	g->params = *params;
-	slabBounds(acq->bscansPerBuffer, (unsigned)n, &g->first, &g->count);
-	g->members.assign((size_t)n, nullptr);
-	*out = g;
+namespace {
+int buildGroup(octpipe_group* g, const int* devices, int n, const OctPipeAcquisitionParams* acq, const OctPipeParams* params, void* h_buffer1,
+               void* h_buffer2, unsigned flags) {
 	if (g->count[0] == 0) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "no B-scans for member 0");
 	for (int i = 0; i < n; ++i) {
 		if (g->count[i] == 0) continue;  // fewer B-scan pairs than members: the surplus members stay empty
@@ -306,30 +335,34 @@ int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const
 			p.postProcessBackgroundRecordingRequested = 0;
 		}
 		const int rc = octpipe_create(&g->members[i], devices[i], &a, &p, nullptr, nullptr);
-		if (rc) return gfail(rc, octpipe_last_error());
+		if (rc) return gfail(rc, "member " + std::to_string(i) + " on device " + std::to_string(devices[i]) + ": " + octpipe_last_error());
 	}
 	size_t raw0 = 0;
 	octpipe_raw_buffer_bytes(g->members[0], &raw0);
 	g->bytesPerBscan = raw0 / g->count[0];
 	g->outPerBscan = (size_t)(acq->samplesPerLine / 2) * acq->ascansPerBscan;
-	// ring slots: every member's slab is moved next to its GPU (the pages of a slab are only ever read by that GPU's DMA
-	// engine; on a two-socket node half of the GPUs hang off the other socket), then pinned once, portable across the
-	// members' devices (cu:1135-1136)
+	// ring slots: pinned once, portable across the members' devices (cu:1135-1136).  With OCTPIPE_GROUP_PLACE_RING_SLABS every
+	// member's slab is first moved next to its GPU: the pages of a slab are only ever read by that GPU's DMA engine, and on a
+	// two-socket node half of the GPUs hang off the other socket.  That changes the memory policy of buffers the caller owns,
+	// so it happens only when asked for.
 	void* hb[2] = {h_buffer1, h_buffer2};
 	for (int k = 0; k < 2; ++k)
 		if (hb[k]) {
-			for (int i = 0; i < n; ++i)
-				if (g->members[i] && placeOnNode(static_cast<char*>(hb[k]) + (size_t)g->first[i] * g->bytesPerBscan, (size_t)g->count[i] * g->bytesPerBscan, deviceNumaNode(devices[i])))
-					g->numaPlaced++;
+			if (flags & OCTPIPE_GROUP_PLACE_RING_SLABS)
+				for (int i = 0; i < n; ++i)
+					if (g->members[i] && placeOnNode(static_cast<char*>(hb[k]) + (size_t)g->first[i] * g->bytesPerBscan, (size_t)g->count[i] * g->bytesPerBscan, deviceNumaNode(devices[i])))
+						g->numaPlaced++;
 			if (hipSetDevice(devices[0]) != hipSuccess || hipHostRegister(hb[k], g->bytesPerBscan * acq->bscansPerBuffer, hipHostRegisterPortable) != hipSuccess)
-				return gfail(OCTPIPE_ERR_DEVICE, "pinning the ring slots failed");
+				return gfail(OCTPIPE_ERR_DEVICE, "pinning ring slot " + std::to_string(k) + " failed");
 			g->pinned[k] = hb[k];
+			g->pinnedBytes = g->bytesPerBscan * acq->bscansPerBuffer;
 		}
 	// RCCL communicator when every member has its own device
 	bool distinct = n > 0;
 	for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (devices[i] == devices[j]) distinct = false;
 	for (int i = 0; i < n; ++i) if (!g->members[i]) distinct = false;
-	if (distinct && n > 1) g->workers = new MemberWorkers((size_t)n);
+	const bool threads = (flags & OCTPIPE_GROUP_SUBMIT_THREADS) || (distinct && n > 1 && !(flags & OCTPIPE_GROUP_NO_SUBMIT_THREADS));
+	if (threads) g->workers = new MemberWorkers((size_t)n);
 	if (distinct && loadRccl(&g->rccl)) {
 		g->comms.assign((size_t)n, nullptr);
 		const int e = g->rccl.CommInitAll(g->comms.data(), n, devices);
@@ -341,25 +374,53 @@ int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const
 			for (int i = 0; i < n; ++i) {
 				if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc(&g->d_blob[i], nb) != hipSuccess ||
 				    hipStreamCreateWithFlags(&g->commStreams[i], hipStreamNonBlocking) != hipSuccess)
-					return gfail(OCTPIPE_ERR_DEVICE, "allocating the calibration staging buffers failed");
+					return gfail(OCTPIPE_ERR_DEVICE, "allocating the calibration staging buffer of member " + std::to_string(i) + " failed");
 			}
 		} else {
-			g->comms.clear();
+			g->comms.clear();  // no communicator: the blob travels through the host (copy backend), which works on any topology
 		}
 	}
 	return OCTPIPE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int octpipe_group_create_ex(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
+                            void* h_buffer1, void* h_buffer2, unsigned flags) {
+	if (!out) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*out = nullptr;
+	if (!devices || n <= 0 || !acq || !params) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	if ((flags & OCTPIPE_GROUP_NO_SUBMIT_THREADS) && (flags & OCTPIPE_GROUP_SUBMIT_THREADS)) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "contradicting thread flags");
+	octpipe_group* g = new octpipe_group();
+	g->devices.assign(devices, devices + n);
+	g->acq = *acq;
+	g->params = *params;
+	slabBounds(acq->bscansPerBuffer, (unsigned)n, &g->first, &g->count);
+	g->members.assign((size_t)n, nullptr);
+	const int rc = buildGroup(g, devices, n, acq, params, h_buffer1, h_buffer2, flags);
+	if (rc) {  // nothing half-built reaches the caller: release what exists (the message of the failing step survives)
+		const std::string why = g_groupError;
+		octpipe_group_destroy(g);
+		return gfail(rc, why);
+	}
+	*out = g;
+	return OCTPIPE_OK;
+}
+
+int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acq, const OctPipeParams* params,
+                         void* h_buffer1, void* h_buffer2) {
+	return octpipe_group_create_ex(out, devices, n, acq, params, h_buffer1, h_buffer2, 0u);
 }
 
 int octpipe_group_destroy(octpipe_group_t* g) {
 	if (!g) return OCTPIPE_OK;
 	for (size_t i = 0; i < g->members.size(); ++i) if (g->members[i]) octpipe_synchronize(g->members[i]);
-	if (g->useRccl) {
-		for (size_t i = 0; i < g->comms.size(); ++i) {
-			hipSetDevice(g->devices[i]);
-			if (g->commStreams[i]) { hipStreamSynchronize(g->commStreams[i]); hipStreamDestroy(g->commStreams[i]); }
-			if (g->d_blob[i]) hipFree(g->d_blob[i]);
-			if (g->comms[i]) g->rccl.CommDestroy(g->comms[i]);
-		}
+	for (size_t i = 0; i < g->comms.size(); ++i) {  // (also what a creation that failed half-way has built so far)
+		hipSetDevice(g->devices[i]);
+		if (i < g->commStreams.size() && g->commStreams[i]) { hipStreamSynchronize(g->commStreams[i]); hipStreamDestroy(g->commStreams[i]); }
+		if (i < g->d_blob.size() && g->d_blob[i]) hipFree(g->d_blob[i]);
+		if (g->comms[i] && g->rccl.CommDestroy) g->rccl.CommDestroy(g->comms[i]);
 	}
 	delete g->workers;
 	g->workers = nullptr;
@@ -382,6 +443,7 @@ int octpipe_group_set_submit_threads(octpipe_group_t* g, int enable) {
 	if (!enable && g->workers) { delete g->workers; g->workers = nullptr; }
 	return OCTPIPE_OK;
 }
+uint64_t octpipe_group_serial_submit_count(const octpipe_group_t* g) { return g ? g->serialSubmits : 0; }
 int octpipe_group_info(const octpipe_group_t* g, int* submitThreads, int* slabsPlacedOnGpuNode) {
 	if (!g) return gfail(OCTPIPE_ERR_INVALID_ARGUMENT, "null group");
 	if (submitThreads) *submitThreads = g->workers ? (int)g->members.size() : 0;

@@ -22,6 +22,7 @@ hipError_t launch_team1664_one(const FusedArgs& a, hipStream_t stream) {
 template <int INTYPE, int RS>
 hipError_t launch_team1664_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	if (roll) {  // rolling average inside the team: uint16 rows
+		if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
 		if constexpr (INTYPE == IN_U16) {
 			if (a.bgTerm) return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_ROLL | MODE_BG>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_ROLL | MODE_BG>(a, stream);
 			return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_ROLL>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_ROLL>(a, stream);

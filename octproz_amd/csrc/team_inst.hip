@@ -29,6 +29,7 @@ hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
 template <int LOG2N, int RS>
 hipError_t launch_team_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	if (roll) {  // rolling average inside the team: uint16 rows (in front of Lanczos the host prepares the rows)
+		if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
 		if constexpr (kIn == IN_U16 && LOG2N >= 12 && RS != RS_LANCZOS) {
 			if (a.bgTerm) return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL | MODE_BG>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL | MODE_BG>(a, stream);
 			return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL>(a, stream);

@@ -27,12 +27,11 @@ class Pipeline:
         b1 = h_buffer1.ctypes.data if h_buffer1 is not None else None
         b2 = h_buffer2.ctypes.data if h_buffer2 is not None else None
         # sample_format: OCTPIPE_FORMAT_* (0 = the reference's rule, 1/2 packed 12 bit, 3/4/5 int8/int16/int32)
-        # route: OCTPIPE_ROUTE_* flags (tests / A-B measurements); the FFT-backend flags are read at creation (thread-local default)
-        self._lib.octpipe_debug_set_route(None, int(route))
-        try:
+        # route: OCTPIPE_ROUTE_* flags (tests / A-B measurements; include/octpipe_debug.h); the FFT-backend flags are read at creation
+        if route:
+            rc = self._lib.octpipe_debug_create(C.byref(self._h), device, C.byref(acq), C.byref(pod), b1, b2, int(sample_format), int(route))
+        else:
             rc = self._lib.octpipe_create_with_format(C.byref(self._h), device, C.byref(acq), C.byref(pod), b1, b2, int(sample_format))
-        finally:
-            self._lib.octpipe_debug_set_route(None, 0)
         if rc != 0:
             msg = self._lib.octpipe_last_error()
             if self._h:
@@ -251,7 +250,7 @@ class Pipeline:
 class PipelineGroup:
     """octpipe_group_* (include/octpipe.h): one buffer per call, B-scan slabs over several GPUs of the node from one process."""
 
-    def __init__(self, params: OctAlgorithmParameters, devices, h_buffer1=None, h_buffer2=None):
+    def __init__(self, params: OctAlgorithmParameters, devices, h_buffer1=None, h_buffer2=None, flags=0):
         self.params = params
         self._lib = _lib.lib()
         self._g = C.c_void_p()
@@ -260,12 +259,14 @@ class PipelineGroup:
         self._keep = (h_buffer1, h_buffer2)
         b1 = h_buffer1.ctypes.data if h_buffer1 is not None else None
         b2 = h_buffer2.ctypes.data if h_buffer2 is not None else None
-        rc = self._lib.octpipe_group_create(C.byref(self._g), devs, len(devices), C.byref(acq), C.byref(pod), b1, b2)
+        # flags: _lib.GROUP_* (octpipe_group_create_ex); on failure the library has released everything and *out is NULL
+        if flags:
+            rc = self._lib.octpipe_group_create_ex(C.byref(self._g), devs, len(devices), C.byref(acq), C.byref(pod), b1, b2, int(flags))
+        else:
+            rc = self._lib.octpipe_group_create(C.byref(self._g), devs, len(devices), C.byref(acq), C.byref(pod), b1, b2)
         if rc != 0:
             msg = self._lib.octpipe_group_last_error()
-            if self._g:
-                self._lib.octpipe_group_destroy(self._g)
-                self._g = C.c_void_p()
+            assert not self._g
             raise _lib.OctPipeError(rc, msg.decode() if msg else "")
         self.N, self.S = int(params.samplesPerLine), params.samplesPerBuffer
         self._sync_params(force_curves=True)
@@ -313,7 +314,8 @@ class PipelineGroup:
     def info(self):
         t, n = C.c_int(), C.c_int()
         self._check(self._lib.octpipe_group_info(self._g, C.byref(t), C.byref(n)))
-        return {"submit_threads": t.value, "slabs_placed_on_gpu_node": n.value}
+        return {"submit_threads": t.value, "slabs_placed_on_gpu_node": n.value,
+                "serial_submits": int(self._lib.octpipe_group_serial_submit_count(self._g))}
 
     def slab(self, i):
         f, n = C.c_uint(), C.c_uint()

@@ -25,6 +25,12 @@ SPECTRUM_RTOL = 1e-5
 POWER_RTOL = 1e-4
 DB_ATOL = 5e-4
 DB_FLOOR = 1e-6
+# Amplitude bound on EVERY bin (round 4): | |Z_got| - |Z_want| | <= AMP_RTOL x (largest amplitude of the A-scan; with a mean line
+# given also: the largest |mean line| entry -- the subtracted term sets the rounding floor of a float32 transform).  This is the
+# metric a transform's rounding error is uniform in (SPECTRUM_RTOL, applied to what the image still shows of the spectrum), and
+# it is what holds the weak bins, which the linear-power bound (relative to the line MAXIMUM) leaves almost free and the dB
+# comparison does not resolve: a bin at 1e-6 of the line maximum in power may be off by 1 % in amplitude, not by 1000 %.
+AMP_RTOL = 1e-5
 # Mean-line subtraction cancels: a bin whose residual power is below CANCEL_FLOOR x |mean line|^2 at that bin lost more than
 # 3.5 digits to the subtraction.  A float32 transform carries ~1e-6 relative error on the UNSUBTRACTED value, so below that
 # ratio the residual's dB value is not resolved to DB_ATOL (0.065 dB = 0.75 % in amplitude needs |residual| / |mean| >= 1.3e-4,
@@ -65,20 +71,62 @@ def image_to_power(v, p):
     return (t * half) ** 2
 
 
-def compare_images(got, want, p, what="", mean_line=None):
-    """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima.
+# Accountability of the three exemptions below: every call counts the bins each rule takes out of a
+# comparison, asserts the count against a stated bound, and adds it to a session-wide ledger that the test run prints at its end
+# (tests/conftest.py: "tolerance ledger").  `strict=True` allows none of them.
+EXEMPT_FRAC = 1e-3          # one-sided -inf, cancelled bins: at most this fraction of the buffer's bins per call (strict: none)
+DB_FLOOR_FRAC = 0.75        # bins under the dB floor: counted and reported; measured 2 % (N = 1024) to 41 % (N = 2048) on the synthetic
+                            # fringes with the v1.8.0 settings, whose noise floor sits at ~1e-6 of the line maximum -- these bins are
+                            # held by the amplitude bound, which is the same statement as a dB bound that widens with 1 / amplitude
+LEDGER = {"calls": 0, "strict_calls": 0, "bins": 0, "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "db_checked": 0,
+          "max_rel": 0.0, "max_amp": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0, "worst_fraction": {"one_sided_inf": (0.0, ""), "below_db_floor": (0.0, ""), "cancelled": (0.0, "")}}
+LAST_STATS = {}
 
-    Non-finite values: log scaling maps a power of exactly 0 to -inf (cu:718, no guard).  -inf therefore IS the value
-    "P = 0".  The two sides can legitimately disagree about it where float32 cancels exactly and float64 keeps a residue:
-    in the mean-line subtraction (~1e-14 of the line maximum in power), and in the transform's own butterflies at bins 150 dB
-    under the line maximum (found by the randomised tests: N = 4096, Lanczos, bin 2035 at 4e-16 of the line maximum -- the
-    oracle rounds a float64 DFT, a float32 FFT returns exactly 0 there).  So a -inf on one side only is accepted when the
-    other side's power is below DB_FLOOR x line maximum (the bound under which the dB comparison does not look anyway); a
-    kernel that zeroes a bin the other side sees above that bound fails.  NaN and +inf: identical pattern always."""
+
+def _ledger(stats, what):
+    LEDGER["calls"] += 1
+    LEDGER["strict_calls"] += 1 if stats["strict"] else 0
+    for k in ("bins", "one_sided_inf", "below_db_floor", "cancelled", "db_checked"):
+        LEDGER[k] += stats[k]
+    for k in ("max_rel", "max_amp", "max_db", "max_one_sided_residue"):
+        LEDGER[k] = max(LEDGER[k], stats[k])
+    for k in ("one_sided_inf", "below_db_floor", "cancelled"):
+        f = stats[k] / max(1, stats["bins"])
+        if f > LEDGER["worst_fraction"][k][0]:
+            LEDGER["worst_fraction"][k] = (f, what)
+
+
+def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_frac=None):
+    """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima (linear power relative to the line
+    maximum, normalised dB); the per-call exemption counts are left in common.LAST_STATS and added to common.LEDGER.
+
+    EVERY bin is held to two bounds: linear power (POWER_RTOL x the line's maximum power) and amplitude (AMP_RTOL x the line's
+    largest amplitude, x N / 4096 beyond N = 4096; a -inf counts as amplitude 0).  The normalised-dB comparison is a third
+    metric where a float32 transform resolves it.  Three rules take bins out of the dB comparison or accept a one-sided -inf,
+    and each is counted:
+      one_sided_inf   log scaling maps a power of exactly 0 to -inf (cu:718, no guard).  -inf therefore IS the value "P = 0".
+                      The two sides can legitimately disagree about it where float32 cancels exactly and float64 keeps a
+                      residue: in the mean-line subtraction (~1e-14 of the line maximum in power), and in the transform's own
+                      butterflies at bins 150 dB under the line maximum (found by the randomised tests).  A -inf on one side
+                      only is accepted when the other side's amplitude is inside the amplitude bound (power below
+                      AMP_RTOL^2 = 1e-10 of the line maximum; until round 3 the bound was DB_FLOOR = 1e-6).
+      below_db_floor  bins finite on both sides whose power is below DB_FLOOR x line maximum (x N / 4096 beyond N = 4096) are
+                      not compared in dB (a float32 transform does not resolve them: their error is bounded by the
+                      linear-power check, which is relative to the line maximum).
+      cancelled       (only where the caller passes the mean line: the randomised tests with large DC terms) bins the mean-line
+                      subtraction cancelled below CANCEL_FLOOR x |mean line|^2 are not compared in dB.
+    one_sided_inf and cancelled must each stay within `exempt_frac` (default EXEMPT_FRAC) of the buffer's bins, and with
+    strict=True both must be ZERO (identical -inf pattern, no bin excused by cancellation); below_db_floor is bounded by
+    DB_FLOOR_FRAC and reported -- those bins are not unchecked, the amplitude bound holds them.  NaN and +inf: identical
+    pattern always."""
     half = int(p.samplesPerLine) // 2
     g = got.reshape(-1, half)
     w = want.reshape(-1, half)
     assert g.shape == w.shape
+    frac = 0.0 if strict else (EXEMPT_FRAC if exempt_frac is None else exempt_frac)
+    stats = {"strict": bool(strict), "bins": int(g.size), "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "db_checked": 0,
+             "max_rel": 0.0, "max_amp": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0}
+    LAST_STATS.clear(); LAST_STATS.update(stats)
     bad_g = np.isnan(g) | np.isposinf(g)
     bad_w = np.isnan(w) | np.isposinf(w)
     assert np.array_equal(bad_g, bad_w), what + ": NaN / +inf pattern differs"
@@ -90,26 +138,53 @@ def compare_images(got, want, p, what="", mean_line=None):
     pw = np.where(ok & ~zero_w, image_to_power(np.where(np.isfinite(w), w, 0), p), 0.0)
     line_max = pw.max(axis=1, keepdims=True)
     line_max[line_max == 0] = 1.0
+    allowed = int(frac * g.size)
     one_sided = zero_g != zero_w
     if one_sided.any():
         residue = np.where(zero_g, pw, pg)[one_sided] / np.broadcast_to(line_max, pw.shape)[one_sided]
-        assert residue.max() <= DB_FLOOR, "%s: %d bins are -inf on one side only with up to %.2e of the line maximum on the other (cancellation bound %.0e)" % (
-            what, int(one_sided.sum()), float(residue.max()), DB_FLOOR)
+        stats["one_sided_inf"] = int(one_sided.sum())
+        stats["max_one_sided_residue"] = float(residue.max())
+        # (the size of the residue is judged by the amplitude bound below, which treats the -inf side as amplitude 0)
+        assert stats["one_sided_inf"] <= allowed, "%s: %d of %d bins are -inf on one side only (allowed: %d%s)" % (
+            what, stats["one_sided_inf"], g.size, allowed, ", strict" if strict else "")
     rel = np.abs(pg - pw) / line_max
     max_rel = float(rel.max())
+    stats["max_rel"] = max_rel
     assert max_rel <= POWER_RTOL, "%s: linear-power error %.3e > %.1e" % (what, max_rel, POWER_RTOL)
+    amp_scale = np.sqrt(line_max)
+    if mean_line is not None and p.fixedPatternNoiseRemoval:
+        amp_scale = np.maximum(amp_scale, float(np.abs(np.asarray(mean_line).astype(np.complex128)[:half]).max()))
+    amp_tol = AMP_RTOL * max(1.0, int(p.samplesPerLine) / 4096.0)
+    amp = np.abs(np.sqrt(pg) - np.sqrt(pw)) / amp_scale
+    max_amp = float(amp.max())
+    stats["max_amp"] = max_amp
+    if max_amp > amp_tol:
+        i = np.unravel_index(int(amp.argmax()), amp.shape)
+        raise AssertionError("%s: amplitude error %.3e > %.1e of the line's largest amplitude at line %d bin %d (powers %.4g vs %.4g, line maximum %.4g)" % (
+            what, max_amp, amp_tol, i[0], i[1], pg[i], pw[i], float(line_max[i[0], 0])))
     max_db = 0.0
     if p.signalLogScaling:
         # float32 rounding of the transform grows with its length: beyond N = 4096 the floor moves up with N (at N = 8192 a
         # bin at 1e-6 of a DC-dominated line maximum carries 0.9 % amplitude error = 0.075 dB, found by the randomised tests)
         floor = DB_FLOOR * max(1.0, int(p.samplesPerLine) / 4096.0)
-        strong = np.isfinite(g) & np.isfinite(w) & (pw > floor * line_max)
+        finite = np.isfinite(g) & np.isfinite(w)
+        strong = finite & (pw > floor * line_max)
+        stats["below_db_floor"] = int((finite & ~strong).sum())
         if mean_line is not None and p.fixedPatternNoiseRemoval:
             m2 = np.abs(np.asarray(mean_line).astype(np.complex128)[:half]) ** 2
-            strong &= pw >= CANCEL_FLOOR * m2[None, :]
+            kept = strong & (pw >= CANCEL_FLOOR * m2[None, :])
+            stats["cancelled"] = int((strong & ~kept).sum())
+            strong = kept
+        assert stats["cancelled"] <= allowed, "%s: %d of %d bins left out of the dB comparison by the 'cancelled' rule (allowed: %d%s)" % (
+            what, stats["cancelled"], g.size, allowed, ", strict" if strict else "")
+        assert stats["below_db_floor"] <= DB_FLOOR_FRAC * g.size, "%s: %d of %d bins lie under the dB floor" % (what, stats["below_db_floor"], g.size)
+        stats["db_checked"] = int(strong.sum())
         if strong.any():
             max_db = float(np.abs(g[strong].astype(np.float64) - w[strong]).max())
+            stats["max_db"] = max_db
             assert max_db <= DB_ATOL, "%s: normalised-dB error %.3e > %.1e" % (what, max_db, DB_ATOL)
+    LAST_STATS.update(stats)
+    _ledger(stats, what)
     return max_rel, max_db
 
 

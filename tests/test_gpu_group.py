@@ -5,7 +5,7 @@ is identical, bit for bit, to one handle processing the whole buffer."""
 import numpy as np
 import pytest
 
-from octproz_amd import Pipeline, PipelineGroup, VirtualOCTSystem, synthetic_raw, v180_benchmark_params
+from octproz_amd import Pipeline, PipelineGroup, VirtualOCTSystem, _lib, synthetic_raw, v180_benchmark_params
 
 pytestmark = pytest.mark.gpu
 
@@ -112,11 +112,19 @@ def test_processing_loop_over_a_group():
     g.close(); system.close()
 
 
+def _report(got, want, N, A, k, extra=""):
+    bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+    per_bscan = N // 2 * A
+    return "buffer %d: %d of %d values differ, B-scans %s, max |diff| %.3g%s" % (
+        k, bad.size, got.size, sorted(set((bad // per_bscan).tolist()))[:12], float(np.nanmax(np.abs(got - want))), extra)
+
+
 @pytest.mark.parametrize("members,B", [(2, 8), (4, 12), (8, 32)])
 def test_group_with_one_submitting_thread_per_member(members, B):
     """the per-member submit threads (default on distinct devices) forced on for members that share device 0: same output bit
-    for bit, through the host-buffer entry point (H2D per member) and the host loop, with ring slots handed to the group
-    (pinned, slabs placed next to their GPU where the host allows it)"""
+    for bit.  Three ways in: (1) a caller-owned UNPINNED buffer -- submitted by the caller's thread, member after member (the
+    threads never pin / stage pageable memory concurrently; counted by serial_submits); (2) the group's registered ring slots --
+    every member's thread copies its slab out of pinned memory; (3) the host loop over those ring slots."""
     N, A = 1024, 64
     p = v180_benchmark_params(N, A, B)
     p.bscanFlip = 1
@@ -128,25 +136,89 @@ def test_group_with_one_submitting_thread_per_member(members, B):
     ring = system.buffer
     g = PipelineGroup(p, [0] * members, ring.slot(0, np.uint16), ring.slot(1, np.uint16))
     assert g.info["submit_threads"] == 0  # members share a device: the caller's thread submits unless asked otherwise
+    assert g.info["slabs_placed_on_gpu_node"] == 0  # no change to the caller's memory policy unless asked for (GROUP_PLACE_RING_SLABS)
     g.set_submit_threads(True)
     assert g.info["submit_threads"] == members
-    for k, r in enumerate(raws):
+    for k, r in enumerate(raws):  # (1)
         g.octCudaPipeline(r)
         g.synchronize()
         got = g.processed_host()
-        if not np.array_equal(got.view(np.uint32), want[k].view(np.uint32)):
-            # (seen once in ~25 runs of the suite, never in isolation: say where and how much before failing)
-            bad = np.flatnonzero(got.view(np.uint32) != want[k].view(np.uint32))
-            per_bscan = N // 2 * A
-            again = g.processed_host()
-            pytest.fail("buffer %d: %d of %d values differ, B-scans %s, max |diff| %.3g, a second read-back %s" % (
-                k, bad.size, got.size, sorted(set((bad // per_bscan).tolist()))[:12], float(np.abs(got - want[k]).max()),
-                "agrees with the oracle run" if np.array_equal(again.view(np.uint32), want[k].view(np.uint32)) else "differs as well"))
-    stats = system.run_group(g, max_buffers=8)
+        assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), _report(got, want[k], N, A, k, " (unpinned buffer)")
+    assert g.info["serial_submits"] == len(raws)
+    stats = system.run_group(g, max_buffers=8)  # (3)
     system.stopAcquisition()
     assert stats.buffersProcessed == 8
+    assert g.info["serial_submits"] == len(raws)  # ring slots: the threads submitted
     assert any(np.array_equal(g.processed_host().view(np.uint32), w.view(np.uint32)) for w in want)
     g.set_submit_threads(False)
     g.octCudaPipeline(raws[0]); g.synchronize()
     assert np.array_equal(g.processed_host().view(np.uint32), want[0].view(np.uint32))
     g.close(); system.close()
+    # (2) own ring slots (page-aligned numpy memory), threads from the start (GROUP_SUBMIT_THREADS), first buffer = calibrating one
+    n = raws[0].size
+    keep = [np.empty(n + 2048, dtype=np.uint16) for _ in range(2)]
+    slots = [b[(-b.ctypes.data % 4096) // 2:][:n] for b in keep]
+    g = PipelineGroup(p, [0] * members, slots[0], slots[1], flags=_lib.GROUP_SUBMIT_THREADS)
+    assert g.info["submit_threads"] == members
+    for k, r in enumerate(raws):
+        slots[k % 2][:] = r.reshape(-1)
+        g.octCudaPipeline(slots[k % 2])
+        g.synchronize()
+        got = g.processed_host()
+        if not np.array_equal(got.view(np.uint32), want[k].view(np.uint32)):
+            again = g.processed_host()
+            pytest.fail(_report(got, want[k], N, A, k, ", a second read-back %s" % (
+                "agrees with the single-handle run" if np.array_equal(again.view(np.uint32), want[k].view(np.uint32)) else "differs as well")))
+    assert g.info["serial_submits"] == 0
+    g.close()
+
+
+def test_threaded_group_first_buffer_stress():
+    """VERDICT r3 item 1 in short form (tools/group_stress.py is the long one): 60 x { create a threaded group of 2 / 4 / 8 members,
+    first (calibrating) buffer + one more out of its pinned ring slots, compare bit for bit, destroy }"""
+    N, A = 1024, 64
+    for members, B in ((2, 8), (4, 12), (8, 32)):
+        p = v180_benchmark_params(N, A, B)
+        p.bscanFlip = 1
+        raws = [synthetic_raw(N, A, B, seed=280 + i) for i in range(2)]
+        want, _ = _single(p, raws)
+        n = raws[0].size
+        keep = [np.empty(n + 2048, dtype=np.uint16) for _ in range(2)]
+        slots = [b[(-b.ctypes.data % 4096) // 2:][:n] for b in keep]
+        for k in range(2):
+            slots[k][:] = raws[k].reshape(-1)
+        for it in range(20):
+            g = PipelineGroup(p, [0] * members, slots[0], slots[1], flags=_lib.GROUP_SUBMIT_THREADS)
+            for k in range(2):
+                g.octCudaPipeline(slots[k]); g.synchronize()
+                got = g.processed_host()
+                assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), "%d members, iteration %d, %s" % (members, it, _report(got, want[k], N, A, k))
+            g.close()
+
+
+def test_group_creation_failure_leaves_nothing_behind():
+    """a member that cannot be created (device index out of range) fails the whole creation: status code, a message naming the
+    member, *out == NULL, and the handles of the members created before it are released (their streams are back in the idle pool)"""
+    import ctypes as C
+    L = _lib.lib()
+    N, A, B = 1024, 32, 8
+    p = v180_benchmark_params(N, A, B)
+    acq, pod = p.acquisition(), p.pod()
+    devs = (C.c_int * 3)(0, 0, 99)
+    g = C.c_void_p(0x1)
+    rc = L.octpipe_group_create(C.byref(g), devs, 3, C.byref(acq), C.byref(pod), None, None)
+    assert rc == 1 and not g.value  # OCTPIPE_ERR_INVALID_ARGUMENT from member 2
+    msg = L.octpipe_group_last_error().decode()
+    assert "member 2" in msg and "device 99" in msg, msg
+    with pytest.raises(_lib.OctPipeError):
+        PipelineGroup(p, [0, 99])
+    rc = L.octpipe_group_create_ex(C.byref(g), devs, 2, C.byref(acq), C.byref(pod), None, None, _lib.GROUP_SUBMIT_THREADS | _lib.GROUP_NO_SUBMIT_THREADS)
+    assert rc == 1 and not g.value
+    # the library still works, and idle stream sets can be dropped at any time
+    assert L.octpipe_release_idle_streams() == 0
+    raw = synthetic_raw(N, A, B, seed=5)
+    want, _ = _single(p, [raw])
+    gg = PipelineGroup(p, [0, 0], flags=_lib.GROUP_NO_SUBMIT_THREADS)
+    gg.octCudaPipeline(raw); gg.synchronize()
+    assert np.array_equal(gg.processed_host().view(np.uint32), want[0].view(np.uint32))
+    gg.close()

@@ -214,7 +214,9 @@ def test_chain_matches_oracle(case):
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=31)
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, case)
+    # strict: identical -inf pattern, no bin excused (every chain case on the benchmark data; the exemptions exist for the
+    # randomised settings of test_gpu_fuzz.py)
+    common.compare_images(got, want, p, case, strict=True)
     if not p.bscanFlip and not p.sinusoidalScanCorrection:
         spec = pipe.debug_spectrum(d.data_ptr(), A * B)
         # oracle spectrum = after mean subtraction; add the mean back on the half it touched
@@ -590,7 +592,7 @@ def test_committed_golden_vectors(tag):
     d = to_device(raw)
     pipe.process_device(d.data_ptr())
     pipe.synchronize()
-    common.compare_images(pipe.processed_host(), GOLD["img_" + tag], p, tag)
+    common.compare_images(pipe.processed_host(), GOLD["img_" + tag], p, tag, strict=True)
     pipe.close()
 
 
@@ -981,7 +983,7 @@ def test_calibration_blob_round_trip():
 
 
 # ------------------------------------------------------------------ full size (BASELINE configs 2 and 3)
-def _full_size(N, A, B, sample_lines=192, **settings):
+def _full_size(N, A, B, sample_lines=192, strict=True, **settings):
     """size-independent properties at full size + the oracle on a sample of whole B-scans"""
     import torch
     from octproz_amd.virtual_oct import synthetic_raw_torch
@@ -1041,7 +1043,7 @@ def _full_size(N, A, B, sample_lines=192, **settings):
         o = common.make_oracle(ps)
         o.set_mean_line(mean)
         want = o.process(raw[b0:b0 + nb])
-        common.compare_images(full[b0:b0 + nb].reshape(-1), want, ps, "B-scan %d" % b0)
+        common.compare_images(full[b0:b0 + nb].reshape(-1), want, ps, "B-scan %d" % b0, strict=strict)
         o.close()
     pipe.close()
 
@@ -1056,12 +1058,12 @@ def test_full_size_real_input_kernel_1024x512x256():
     FPN removal stays ON: with a real-valued DC bin, X[0] - mean[0] cancels exactly on a few dozen of the 131 072 lines and
     log(0) = -inf appears there on one side or the other depending on the last bit; compare_images treats -inf as the
     power 0 it stands for, so such a bin is held to the same linear-power tolerance as every other one."""
-    _full_size(1024, 512, 256, dispersionCompensation=0)
+    _full_size(1024, 512, 256, strict=False, dispersionCompensation=0)
 
 
 def test_full_size_real_input_kernel_config3_slab():
     """config 3's length on the default-style settings: real-input kernel of N = 2048 on a 2048 x 1024 x 64 slab"""
-    _full_size(2048, 1024, 64, sample_lines=1024, dispersionCompensation=0)
+    _full_size(2048, 1024, 64, sample_lines=1024, strict=False, dispersionCompensation=0)
 
 
 def test_full_size_n1664_mixed_radix_512x128():
@@ -1072,7 +1074,7 @@ def test_full_size_n1664_mixed_radix_512x128():
 
 def test_full_size_n1664_real_input_512x128():
     """the recording's length on its default-style settings (no dispersion compensation): mixed-radix real-input kernel"""
-    _full_size(1664, 512, 128, sample_lines=64, dispersionCompensation=0)
+    _full_size(1664, 512, 128, sample_lines=64, strict=False, dispersionCompensation=0)
 
 
 def test_full_size_config3_2048x1024x512():
