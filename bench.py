@@ -29,6 +29,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide: FP32 vector (VALU) peak, 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
+# VALU-only skeleton of the headline kernel's instruction mix (every LDS / memory / scalar instruction deleted, tools/mk_skeleton.py):
+# 0.118 ms per 1024x512x256 buffer = 0.57 of the HBM roofline -- the ceiling of this algorithm on this ALU
+VALU_FLOOR = {1024: {"frac": 0.57, "kernel_ms": 0.118, "source": "profiles/r2a_ceiling_skeletons_ab.txt, profiles/r2b_pmc_base_vs_regtab_vs_valu_skeleton.txt"}}
 
 
 def parse_args(argv=None):
@@ -42,6 +46,11 @@ def parse_args(argv=None):
     ap.add_argument("--samples", type=int, default=1024)
     ap.add_argument("--ascans", type=int, default=512)
     ap.add_argument("--bscans", type=int, default=256)
+    ap.add_argument("--total-bscans", type=int, default=int(os.environ.get("OCT_BENCH_TOTAL_BSCANS", "0")),
+                    help="STRONG scaling: a fixed volume of this many B-scans, cut into even-sized slabs over the ranks (BASELINE config 4: "
+                         "--total-bscans 2048 at --gpus 1/2/4/8; at N = 1 that is one 2 GiB buffer on one GPU).  Default 0 = weak scaling, "
+                         "--bscans per rank")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the HBM traffic of the dominant kernel")
     ap.add_argument("--volumes", type=int, default=4, help="distinct raw buffers rotated (1 GiB > the 256 MiB Infinity Cache)")
     ap.add_argument("--out-slots", type=int, default=4, help="processed-buffer slots rotated (buffersPerVolume; 1 GiB of output > Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,13 +202,89 @@ def dry_run(args, world, rank):
     cal = odist.unpack_calibration(blob)
     t = torch.tensor([float(cal["mean_line"].real.sum()), float(rank)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.barrier()
     ranks = dist.get_world_size()
+    # the slab every rank would process: --bscans each (weak scaling) or its part of the fixed --total-bscans volume (strong)
+    mine = list(odist.slab_for_rank(args.total_bscans, ranks, rank)) if args.total_bscans > 0 else [rank * args.bscans, args.bscans]
+    slabs = [None] * ranks
+    dist.all_gather_object(slabs, mine)
+    dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "backend": args.backend,
-                          "blob_bytes": int(blob.size), "blob_checksum": float(t[0].item()), "max_rank": int(t[1].item())}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "backend": args.backend, "scaling": "strong" if args.total_bscans > 0 else "weak",
+                          "slabs": slabs, "blob_bytes": int(blob.size), "blob_checksum": float(t[0].item()), "max_rank": int(t[1].item())}), flush=True)
     return 0
+
+
+# ------------------------------------------------------------------------------------------------ HBM traffic (PMC passes)
+def measure_traffic(args, kernel_name, timeout=170.0):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under `rocprofv3 --pmc FETCH_SIZE`
+    and `--pmc WRITE_SIZE` (separate passes with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; values in
+    KB; gfx950 correction: FETCH_SIZE counts 64 B per 128 B request on coalesced streams -> doubled).  Returns (bytes, source);
+    (None, reason) when rocprofv3 is missing or a pass fails -- never a constant from an earlier run."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return None, "rocprofv3 not on PATH: not measured in this run"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="octbench_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "4", "--warmup", "1", "--warmup-seconds", "0", "--no-cpu-baseline", "--no-extras", "--no-traffic",
+               "--samples", str(args.samples), "--ascans", str(args.ascans), "--bscans", str(args.bscans), "--volumes", "2", "--out-slots", "2"]
+        if args.total_bscans:
+            cmd += ["--total-bscans", str(args.total_bscans)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s pass timed out after %.0f s" % (counter, timeout)
+        got = []
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_name in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    got.append(float(row["Counter_Value"]))
+        shutil.rmtree(tmp, ignore_errors=True)
+        if r.returncode != 0 or not got:
+            return None, "rocprofv3 --pmc %s pass gave no rows for %s (exit code %d)" % (counter, kernel_name, r.returncode)
+        vals[counter] = (sum(got) / len(got), len(got))
+    f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return (2.0 * f + w) * 1024.0, ("measured by this run: rocprofv3 --pmc FETCH_SIZE (%.0f KB avg over %d dispatches, doubled: gfx950 counts 64 B per 128 B "
+                                    "request) and --pmc WRITE_SIZE (%.0f KB, %d dispatches) in separate child passes" % (f, vals["FETCH_SIZE"][1], w, vals["WRITE_SIZE"][1]))
+
+
+def preflight(rank, local_rank, dev_index):
+    """one line per rank on stderr (and, gathered, in rank 0's JSON): which physical GPU this rank drives -- a wrong LOCAL_RANK ->
+    device mapping or two ranks on one GPU is visible in the driver's log tail instead of in a strange scaling number"""
+    import torch
+    rec = {"rank": rank, "local_rank": local_rank, "device": dev_index, "host": socket.gethostname(), "pid": os.getpid()}
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        rec["name"] = pr.name
+        rec["gcn_arch"] = getattr(pr, "gcnArchName", "")
+        rec["cus"] = pr.multi_processor_count
+        rec["hbm_GiB"] = round(pr.total_memory / 2.0 ** 30, 1)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        rec["pci"] = bdf
+        try:
+            rec["numa_node"] = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        except Exception:
+            rec["numa_node"] = None
+    except Exception as e:
+        rec["error"] = str(e)
+    try:
+        rec["rccl"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        rec["rccl"] = None
+    rec["hip"] = getattr(torch.version, "hip", None)
+    rec["visible"] = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))
+    sys.stderr.write("bench.py preflight: " + json.dumps(rec) + "\n")
+    sys.stderr.flush()
+    return rec
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -346,12 +431,32 @@ def main():
     ranks = dist.get_world_size() if distributed else 1
 
     N, A, B = args.samples, args.ascans, args.bscans
+    strong = args.total_bscans > 0
+    first_bscan = 0
+    if strong:
+        # BASELINE config 4 as stated: ONE volume of --total-bscans B-scans, rank r owns the even-sized slab slab_bounds gives it
+        # (flip parity preserved, the rule of octpipe_group / octproz_amd.dist); per-rank work shrinks as N grows
+        from octproz_amd import dist as odist
+        first_bscan, B = odist.slab_for_rank(args.total_bscans, ranks, rank)
+        assert B > 0, "rank %d has no B-scans: --total-bscans %d over %d ranks" % (rank, args.total_bscans, ranks)
     slots = max(1, args.out_slots)
+    n_vols = max(1, args.volumes)
+    if strong:  # a slab is >= 256 MiB (> the Infinity Cache) on its own from 256 B-scans up: two of each are enough
+        n_vols, slots = min(n_vols, 2), min(slots, 2)
     p = v180_benchmark_params(N, A, B, buffers_per_volume=slots)
     pipe = Pipeline(p, device=local_rank)
+    pre = preflight(rank, local_rank, local_rank)
+    pre["slab"] = [first_bscan, B]
 
-    # synthetic raw slab(s) of this rank, resident in HBM before the timed region
-    vols = [synthetic_raw_torch(N, A, B, dev, seed=1000 * rank + 7 + i) for i in range(max(1, args.volumes))]
+    # synthetic raw slab(s) of this rank, resident in HBM before the timed region (generated in chunks of <= 256 B-scans: the
+    # generator's float32 temporaries stay small next to a 2 GiB slab)
+    def make_volume(seed):
+        t = torch.empty((B, A, N), dtype=torch.int16, device=dev)
+        for b0 in range(0, B, 256):
+            nb = min(256, B - b0)
+            t[b0:b0 + nb] = synthetic_raw_torch(N, A, nb, dev, seed=seed + 17 * (first_bscan + b0))
+        return t
+    vols = [make_volume(1000 * rank + 7 + i) if B > 256 else synthetic_raw_torch(N, A, B, dev, seed=1000 * rank + 7 + i) for i in range(n_vols)]
     torch.cuda.synchronize()
 
     # calibration: rank 0 determines the FPN mean line on its first buffer ("once", cu:1521), all ranks import it
@@ -365,7 +470,11 @@ def main():
     dt, kernel_ms, launches = timed_run(pipe, vols, args.steps, args.warmup, args.warmup_seconds,
                                         barrier=dist.barrier if distributed else None)
     kernel_ms_ranks = [kernel_ms]
+    pre_all, bscans_all = [pre], [B]
     if distributed:
+        pre_all = [None] * ranks
+        dist.all_gather_object(pre_all, pre)
+        bscans_all = [int(x["slab"][1]) for x in pre_all]
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -375,42 +484,59 @@ def main():
 
     out = None
     if rank == 0:
-        ascans_total = ranks * A * B * args.steps
+        import math
+        ascans_total = A * sum(bscans_all) * args.steps  # every rank's slab, every step
         value = ascans_total / dt
-        alg_bytes = 4.0 * N * A * B  # 2N B in (uint16) + 4*(N/2) B out (float32) per A-scan
+        alg_bytes = 4.0 * N * A * B  # 2N B in (uint16) + 4*(N/2) B out (float32) per A-scan; rank 0's launch
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        # HBM bytes per launch: NOT measured in this run -- copied from the PMC passes of the last profiling run
-        # (profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE with the guide's gfx950 correction)
-        traffic, traffic_src, rec = None, None, {}
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if rec.get("workload") == "%dx%dx%d" % (N, A, B):
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/hbm_traffic.json (rocprofv3 PMC passes of an earlier run, not this one)"
-        except Exception:
-            traffic = None
+        kernel_name = {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_fused_kernel<10, 1, 2, 4>",
+                       2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_team_kernel<12, 1, 2, 4>", 8192: "oct_team_kernel<13, 1, 2, 4>",
+                       1664: "oct_team1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)")
+        # second axis (SURVEY 8(d) "ridge warning"): the path sits at ~20 flop/B = the machine balance, so the record carries the
+        # FP32 rate too.  Convention: 5 N log2 N for the transform + ~30 N for unpack, 4-tap cubic, window x phasor, |z|^2, log
+        flops_fft, flops_other = 5.0 * N * math.log2(N), 30.0 * N
+        flops_launch = (flops_fft + flops_other) * A * B
+        tflops = flops_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        floor = VALU_FLOOR.get(N)
         out = {
             "metric": "A-scans/s", "value": value, "unit": "A-scans/s", "n_gpus": ranks, "rccl_ranks": ranks if distributed else 0,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "volumes_per_s": value / (A * B),
-            "config": {"workload": "%dx%dx%d 12-bit-in-uint16 raw buffer per GPU, full chain (cubic k-linearisation, Hann "
-                                   "window, dispersion, IFFT, FPN removal, log scaling), reference v1.8.0 settings" % (N, A, B),
-                       "samples_per_ascan": N, "ascans_per_bscan": A, "bscans_per_buffer": B,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "volumes_per_s": value / (A * (args.total_bscans if strong else B)),
+            "config": {"workload": ("%dx%dx%d 12-bit-in-uint16 volume cut into %d B-scan slab(s) (BASELINE config 4 form: fixed volume), "
+                                    % (N, A, args.total_bscans, ranks) if strong else "%dx%dx%d 12-bit-in-uint16 raw buffer per GPU, " % (N, A, B)) +
+                                   "full chain (cubic k-linearisation, Hann window, dispersion, IFFT, FPN removal, log scaling), reference v1.8.0 settings",
+                       "samples_per_ascan": N, "ascans_per_bscan": A, "bscans_per_buffer": B, "bscans_per_rank": bscans_all,
                        "distinct_input_buffers": len(vols), "output_slots_rotated": slots,
                        "warmup_seconds": args.warmup_seconds, "parallelism": "bscan-slab x%d" % ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_fused_kernel<10, 1, 2, 4>",
-                                    2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_team_kernel<12, 1, 2, 4>", 8192: "oct_team_kernel<13, 1, 2, 4>",
-                                    1664: "oct_team1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "kernel": kernel_name,
                          "kernel_ms": kernel_ms,
                          "kernel_ms_per_rank": {"min": min(kernel_ms_ranks), "max": max(kernel_ms_ranks), "ranks": kernel_ms_ranks},
-                         "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
+                         "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
+                         # the honest second axis of a kernel on the ridge: FP32 rate against the vector peak, and the measured
+                         # VALU-only floor of this instruction mix where one exists
+                         "flops_per_ascan": flops_fft + flops_other, "flops_convention": "5 N log2 N (transform) + 30 N (unpack, cubic taps, window x phasor, |z|^2, log)",
+                         "achieved_tflops": tflops, "fp32_vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "frac_fp32_vector": tflops / FP32_VECTOR_PEAK_TFLOPS,
+                         "valu_floor_frac": floor["frac"] if floor else None,
+                         "valu_floor_source": (floor["source"] + ": VALU-only skeleton %.3f ms per 1024x512x256 launch" % floor["kernel_ms"]) if floor else
+                                              "no skeleton study for this length"},
+            "preflight": pre_all,
         }
-        if traffic is not None and rec.get("kernel") and rec.get("kernel") != out["roofline"]["kernel"]:
-            # a traffic figure of another kernel says nothing about this one: drop it rather than report it
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = None, "profiles/hbm_traffic.json is for %s, not this kernel" % rec.get("kernel")
     pipe.close()
+    if rank == 0:
+        # HBM traffic of the dominant kernel: measured now (child passes under rocprofv3 --pmc), or null with the reason
+        if ranks > 1:
+            out["roofline"]["traffic_source"] = "measured in the N = 1 run only"
+        elif args.no_traffic:
+            out["roofline"]["traffic_source"] = "skipped (--no-traffic)"
+        elif N not in (256, 512, 1024, 2048, 4096, 8192, 1664):
+            out["roofline"]["traffic_source"] = "library route: several kernels, no single dominant one"
+        else:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measure_traffic(args, kernel_name)
+            if out["roofline"]["traffic"]:
+                out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / alg_bytes
 
     if rank == 0 and ranks == 1 and not args.no_extras:
         # (i) the reference's default-style settings (no dispersion compensation, octalgorithmparameters.cpp:72): real FFT input

@@ -204,7 +204,9 @@ int octpipe_process(octpipe_t* h, const void* h_inputSignal);
 int octpipe_process_async(octpipe_t* h, const void* h_inputSignal);
 int octpipe_wait_input(octpipe_t* h);
 /* Same chain with the raw buffer already resident in HBM (d_raw: device pointer, S*bytesPerSample
- * bytes).  No reference counterpart: it is what the roofline measurement times. */
+ * bytes).  No reference counterpart: it is what the roofline measurement times.  A plain pointer carries no stream ordering:
+ * the buffer must be COMPLETE when this is called (or have been written on the stream octpipe_get_stream returns) -- the
+ * handle's streams are hipStreamNonBlocking and do not wait for the NULL stream or for another library's streams. */
 int octpipe_process_device(octpipe_t* h, const void* d_raw);
 int octpipe_synchronize(octpipe_t* h);
 

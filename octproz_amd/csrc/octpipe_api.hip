@@ -969,6 +969,10 @@ bool fftLibraryAvailable() {
 
 int setDevice(const octpipe* h) {
 	HIP_TRY(hipSetDevice(h->device));
+	// hipLaunchKernelGGL reports through the thread's last-error slot, and the launchers return hipGetLastError(): a status a host
+	// application left there on this thread (PyTorch probes host pointers with calls that fail by design) must not be taken for a
+	// failed launch of ours.  Every HIP call of this library is checked where it is made, so nothing of ours is lost here.
+	(void)hipGetLastError();
 	return OCTPIPE_OK;
 }
 

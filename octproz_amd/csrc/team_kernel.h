@@ -12,10 +12,21 @@
 // A-scan: row staged / first exchange written / first exchange read by everyone / second exchange written).  Two teams per CU
 // at N = 4096 (two waves per SIMD), persistent.
 //
-//   Stockham, strided mapping with T = N / 16 butterflies per pass, element e of the exchange buffer at e + (e >> 4):
+//   Stockham, strided mapping with T = N / 16 butterflies per pass:
 //     pass 1  butterfly b = L:                 inputs L + T t (the gather's order), outputs 16 L + u
 //     pass 2  butterfly b = L:                 inputs L + T t, twiddle e^{+2 pi i t (L & 15) / 256}, outputs 256 (L >> 4) + (L & 15) + 16 u
 //     pass 3  butterflies b = L + T m < 256:   inputs b + 256 t, twiddle e^{+2 pi i t b / N}, bins b + 256 u, u < R3 / 2 kept (R3 = N / 256)
+//   Exchange layouts (round 4; until then element e sat at e + (e >> 4), and every strided ds_read_b64 paid a 2-way bank
+//   conflict: 32 consecutive lanes read elements L + (L >> 4) = 0..15, 17..32, and 32 wraps onto bank 0 -- 7 % of the N = 4096
+//   kernel in SQ_LDS_BANK_CONFLICT).  The DS unit serves 8-byte reads in groups of 32 lanes over 64 banks (32 elements) and
+//   8-byte writes in groups of 16 lanes over 32 banks (16 elements):
+//     exchange 1   TRANSPOSED with pitch C1 = T + 2: pass-1 output 16 L + u at u C1 + L (16 lanes write 16 consecutive elements);
+//                  lane L reads its input L + T q = 16 ((L >> 4) + (T / 16) q) + (L & 15) from (L & 15) C1 + (L >> 4) + (T / 16) q:
+//                  over 32 lanes (L & 15) C1 mod 32 runs through the even residues and (L >> 4) adds 0 or 1 -- 32 different banks
+//     exchanges 2, 3   NATURAL order, no padding: the outputs of passes 2 and 3 are consecutive elements over consecutive lanes
+//                  (256 (L >> 4) + (L & 15) + 16 u resp. 4096 (L >> 8) + (L & 255) + 256 u), and so are the strided reads L + T q
+//   All addresses stay "lane base + immediate".  The reads are issued as plain ds_read_b64 (inline assembly): hipcc would pair them
+//   into ds_read2[st64]_b64, which is served in groups of 16 lanes at half the rate.
 // Arithmetic per stage is the general kernel's (same gather expressions, same butterflies, same epilogue).
 //
 // N = 8192 (no one-wave kernel exists: 128 points per lane; the library route gather -> hipFFT -> epilogue ran it at 12 M
@@ -33,22 +44,60 @@
 
 namespace oct {
 
-#ifndef OCT_TEAM_PAD
-#define OCT_TEAM_PAD 1  // pad elements per 16 of the exchange buffer: element e at e + PAD (e >> 4)
+#ifndef OCT_TEAM_C1PAD
+#define OCT_TEAM_C1PAD 2  // pitch of the transposed first exchange = T + this (even: conflict-free for the 32-lane groups of ds_read_b64)
+#endif
+#ifndef OCT_TEAM_ASM_READS
+#define OCT_TEAM_ASM_READS 1  // exchange reads as plain ds_read_b64 (0: left to hipcc, which pairs them into ds_read2[st64]_b64)
 #endif
 template <int LOG2N> struct Team {
-	static constexpr int PAD = OCT_TEAM_PAD;
 	static_assert(LOG2N >= 11 && LOG2N <= 13, "N / 16 lanes per A-scan: two, four or eight waves");
 	static constexpr bool FOUR = LOG2N == 13;  // four passes: 16 x 16 x 16 x 2
 	static constexpr int N = 1 << LOG2N, P = 16, LANES = N / 16, R3 = FOUR ? 16 : N / 256, NB3 = 16 / R3;
 	static constexpr int ROW_BYTES = ((N + 2 * ROW_OFF) * 4 + 15) & ~15;
-	static constexpr int X_BYTES = (N + PAD * N / 16) * 8;
+	static constexpr int C1 = LANES + OCT_TEAM_C1PAD;  // pitch of the transposed first exchange
+	static constexpr int X_ELEMS = 16 * C1 > N ? 16 * C1 : N;
+	static constexpr int X_BYTES = X_ELEMS * 8;
 	static constexpr int MEAN_BYTES = FOUR ? N * 4 : 0;  // N / 2 complex bins in LDS instead of registers
-	static constexpr int PITCH = LANES + PAD * LANES / 16;  // strided read: element L + LANES q at rb[PITCH q]
 	// twiddle table of this plan in FusedArgs::twiddle: [t-1][k] for pass 2 (15 x 16), then [t-1][k] for pass 3 ((R3 - 1) x 256,
 	// angle 2 pi t k / (256 R3)), then (FOUR) [k] for pass 4 (4096, angle 2 pi k / N)
 	static constexpr int TW_PASS3 = 15 * 16, TW_PASS4 = TW_PASS3 + (R3 - 1) * 256, TW_COUNT = TW_PASS4 + (FOUR ? 4096 : 0);
 };
+// the 16 inputs of a lane's next butterfly: elements base[STRIDE q], q < 16, as sixteen plain ds_read_b64 at lane address +
+// immediate.  ONE assembly block that ends with the wait: the values do not exist for the compiler before the block is over (with
+// a read per asm statement and the s_waitcnt in another, hipcc scheduled the first twiddle products in front of the wait -- their
+// asm is not volatile -- and was free to copy or spill a result register before its data had arrived)
+template <int STRIDE> OCT_DEV void team_read16(f2 (&v)[16], const f2* base) {
+#if OCT_TEAM_ASM_READS
+	static_assert(STRIDE * 8 * 15 < 65536, "16-bit offset field");
+	const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const f2*)base;
+	asm volatile(
+	    "ds_read_b64 %0, %16\n\t"
+	    "ds_read_b64 %1, %16 offset:%17*1\n\t"
+	    "ds_read_b64 %2, %16 offset:%17*2\n\t"
+	    "ds_read_b64 %3, %16 offset:%17*3\n\t"
+	    "ds_read_b64 %4, %16 offset:%17*4\n\t"
+	    "ds_read_b64 %5, %16 offset:%17*5\n\t"
+	    "ds_read_b64 %6, %16 offset:%17*6\n\t"
+	    "ds_read_b64 %7, %16 offset:%17*7\n\t"
+	    "ds_read_b64 %8, %16 offset:%17*8\n\t"
+	    "ds_read_b64 %9, %16 offset:%17*9\n\t"
+	    "ds_read_b64 %10, %16 offset:%17*10\n\t"
+	    "ds_read_b64 %11, %16 offset:%17*11\n\t"
+	    "ds_read_b64 %12, %16 offset:%17*12\n\t"
+	    "ds_read_b64 %13, %16 offset:%17*13\n\t"
+	    "ds_read_b64 %14, %16 offset:%17*14\n\t"
+	    "ds_read_b64 %15, %16 offset:%17*15\n\t"
+	    "s_waitcnt lgkmcnt(0)"
+	    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]),
+	      "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+	    : "v"(addr), "n"(STRIDE * 8)
+	    : "memory");
+#else
+#pragma unroll
+	for (int q = 0; q < 16; q++) v[q] = base[STRIDE * q];
+#endif
+}
 constexpr int TEAM_ROLL_BYTES = 256;  // wave totals of the in-team rolling average: [chunk][wave], at most 4 x 16
 template <int LOG2N, int MODE> constexpr int team_lds_bytes() {
 	return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + Team<LOG2N>::MEAN_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>() + ((MODE & 1 /* MODE_ROLL */) ? TEAM_ROLL_BYTES : 0);
@@ -209,8 +258,7 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 #pragma unroll
 			for (int m = 0; m < NB3; m++) mreg[m + NB3 * u] = a.subtractMean ? a.meanLine[L + T * m + 256 * u] : f2{0.0f, 0.0f};
 	}
-	constexpr int PD = TM::PAD, S16 = 16 + PD, S256 = 256 + 16 * PD;
-	f2* wb3 = xbuf + ((4096 + 256 * PD) * (L >> 8) + (L & 255) + PD * ((L & 255) >> 4));  // FOUR: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[S256 u]
+	f2* wb3 = xbuf + (4096 * (L >> 8) + (L & 255));  // FOUR: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[256 u] (natural order)
 
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (T * SPL);  // chunk = SPL consecutive samples in CB bytes; NL chunks per lane and row
@@ -242,9 +290,10 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		}
 	};
 	if (line < a.numLines) prefetch(line);
-	const f2* rb = xbuf + (L + TM::PAD * (L >> 4));                       // strided read: element L + T q at rb[PITCH q]
-	f2* wb1 = xbuf + (16 + TM::PAD) * L;                                  // pass 1 output 16 L + u at wb1[u]
-	f2* wb2 = xbuf + ((256 + 16 * TM::PAD) * (L >> 4) + (L & 15));        // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[(16 + PAD) u]
+	const f2* rb1 = xbuf + ((L & 15) * TM::C1 + (L >> 4));   // first exchange, transposed: element L + T q at rb1[(T / 16) q]
+	const f2* rb = xbuf + L;                                 // later exchanges, natural order: element L + T q at rb[T q]
+	f2* wb1 = xbuf + L;                                      // pass 1 output 16 L + u at wb1[C1 u]
+	f2* wb2 = xbuf + (256 * (L >> 4) + (L & 15));            // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[16 u]
 
 	for (; line < a.numLines; line += gridDim.x) {
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141), minus the rolling average (cu:165-211)
@@ -324,22 +373,20 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 		octfft::Dft<16, 1, false>::run(&v[0]);
 #ifndef TEAM_SKIP_W1
 #pragma unroll
-		for (int u = 0; u < 16; u++) wb1[u] = v[u];
+		for (int u = 0; u < 16; u++) wb1[TM::C1 * u] = v[u];
 #endif
 		team_barrier();  // first exchange written (and every lane is past its gather: the row may be overwritten)
-#pragma unroll
-		for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+		team_read16<T / 16>(v, rb1);
 #pragma unroll
 		for (int t = 1; t < 16; t++) v[t] = octfft::cmul(v[t], tw2[t - 1]);
 		octfft::Dft<16, 1, false>::run(&v[0]);
 		team_barrier();  // everyone has read the first exchange
 #ifndef TEAM_SKIP_W2
 #pragma unroll
-		for (int u = 0; u < 16; u++) wb2[S16 * u] = v[u];
+		for (int u = 0; u < 16; u++) wb2[16 * u] = v[u];
 #endif
 		team_barrier();  // second exchange written
-#pragma unroll
-		for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+		team_read16<T>(v, rb);
 		// element L + T q = b + 256 t with b = L + T m: q = m + NB3 t
 #pragma unroll
 		for (int m = 0; m < NB3; m++)
@@ -349,10 +396,9 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 			octfft::Dft<16, 1, false>::run(&v[0]);
 			team_barrier();  // everyone has read the second exchange
 #pragma unroll
-			for (int u = 0; u < 16; u++) wb3[S256 * u] = v[u];
+			for (int u = 0; u < 16; u++) wb3[256 * u] = v[u];
 			team_barrier();  // third exchange written
-#pragma unroll
-			for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+			team_read16<T>(v, rb);
 			// radix 2 over (b, b + 4096), b = L + T m: element L + T q with q = m + 8 t; only the sum (bin b) is kept
 #pragma unroll
 			for (int m = 0; m < 8; m++) v[m] = v[m] + octfft::cmul(v[m + 8], tw4[m]);

@@ -124,12 +124,13 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 		}
 	};
 	if (pi < numPairs) prefetch(pi);
-	const f2* rb = xbuf + (L + TM::PAD * (L >> 4));
-	f2* wb1 = xbuf + (16 + TM::PAD) * L;
-	f2* wb2 = rowp + ((256 + 16 * TM::PAD) * (L >> 4) + (L & 15));  // second exchange: in the row region
-	const f2* rb2 = rowp + (L + TM::PAD * (L >> 4));
-	constexpr int S16 = 16 + TM::PAD, S256 = 256 + 16 * TM::PAD;
-	f2* wb3 = xbuf + ((4096 + 256 * TM::PAD) * (L >> 8) + (L & 255) + TM::PAD * ((L & 255) >> 4));  // N = 8192: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[S256 u]
+	// exchange layouts of team_kernel.h: the first transposed with pitch C1, the later ones in natural order
+	const f2* rb1 = xbuf + ((L & 15) * TM::C1 + (L >> 4));
+	const f2* rb = xbuf + L;
+	f2* wb1 = xbuf + L;
+	f2* wb2 = rowp + (256 * (L >> 4) + (L & 15));  // second exchange: in the row region
+	const f2* rb2 = rowp + L;
+	f2* wb3 = xbuf + (4096 * (L >> 8) + (L & 255));  // N = 8192: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[256 u]
 
 	for (; pi < numPairs; pi += gridDim.x) {
 		// ---- stage both rows interleaved as float32
@@ -170,18 +171,16 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 		__builtin_amdgcn_s_setprio(2);
 		octfft::Dft<16, 1, false>::run(&v[0]);
 #pragma unroll
-		for (int u = 0; u < 16; u++) wb1[u] = v[u];
+		for (int u = 0; u < 16; u++) wb1[TM::C1 * u] = v[u];
 		team_barrier();  // first exchange written
-#pragma unroll
-		for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+		team_read16<T / 16>(v, rb1);
 #pragma unroll
 		for (int t = 1; t < 16; t++) v[t] = octfft::cmul(v[t], TW2_LDS ? tw2p[16 * (t - 1)] : tw2[t - 1]);
 		octfft::Dft<16, 1, false>::run(&v[0]);
 #pragma unroll
-		for (int u = 0; u < 16; u++) wb2[S16 * u] = v[u];  // the rows are no longer needed: every lane gathered before the last barrier
+		for (int u = 0; u < 16; u++) wb2[16 * u] = v[u];  // the rows are no longer needed: every lane gathered before the last barrier
 		team_barrier();  // second exchange written
-#pragma unroll
-		for (int q = 0; q < P; q++) v[q] = rb2[TM::PITCH * q];
+		team_read16<T>(v, rb2);
 #pragma unroll
 		for (int t = 1; t < 16; t++) {
 			if constexpr (SQUEEZE) {
@@ -196,10 +195,9 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 			// third exchange, in the exchange buffer again (last read before the previous barrier), then the radix-2 pass:
 			// element L + T q = b + 4096 t with b = L + T m, q = m + 8 t;  Z[b] = s + w d,  Z[b + 4096] = s - w d
 #pragma unroll
-			for (int u = 0; u < 16; u++) wb3[S256 * u] = v[u];
+			for (int u = 0; u < 16; u++) wb3[256 * u] = v[u];
 			team_barrier();  // third exchange written
-#pragma unroll
-			for (int q = 0; q < P; q++) v[q] = rb[TM::PITCH * q];
+			team_read16<T>(v, rb);
 #pragma unroll
 			for (int m = 0; m < 8; m++) {
 				const f2 d = octfft::cmul(v[m + 8], tw4[m]), s0 = v[m];

@@ -68,6 +68,9 @@ def synthetic_raw_torch(samples_per_line, ascans_per_bscan, bscans, device, seed
             acc += amp[:, r:r + 1] * torch.cos((2 * torch.pi) * z[:, r:r + 1] * k[None, :])
         acc += torch.randn((m, N), device=device, generator=g) * 5.0
         out[s:s + m] = torch.clamp(torch.round(acc), 0, 4095).to(torch.int16)
+    # torch enqueued all of this on ITS current stream; the pipeline's streams are non-blocking and do not wait for it -- hand
+    # the caller a finished buffer (a plain device pointer carries no stream ordering)
+    torch.cuda.synchronize(device)
     return out.view(B, A, N)  # int16 storage, values 0..4095: same bytes as little-endian uint16
 
 

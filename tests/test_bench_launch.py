@@ -37,6 +37,17 @@ def test_gpus_8_launches_eight_ranks():
     assert d["blob_checksum"] == sum(range(1024))
 
 
+def test_total_bscans_is_the_strong_scaling_form_of_config_4():
+    """BASELINE config 4 as stated: the FIXED 1024 x 512 x 2048 volume at 1 / 2 / 4 / 8 ranks (`--total-bscans 2048`), eight
+    256-B-scan slabs at N = 8; the default stays weak scaling (--bscans per rank)"""
+    d = _run(["--gpus", "8", "--backend", "gloo", "--dry-run", "--total-bscans", "2048"])
+    assert d["scaling"] == "strong" and d["slabs"] == [[256 * r, 256] for r in range(8)]
+    d = _run(["--gpus", "2", "--backend", "gloo", "--dry-run", "--total-bscans", "2048"])
+    assert d["slabs"] == [[0, 1024], [1024, 1024]]
+    d = _run(["--gpus", "2", "--backend", "gloo", "--dry-run"])
+    assert d["scaling"] == "weak" and d["slabs"] == [[0, 256], [256, 256]]
+
+
 def test_one_dying_rank_stops_the_launcher_quickly():
     """rank 1 exits after the rendezvous while rank 0 waits in the broadcast: the launcher must notice that rank (not only
     rank 0), stop the others it started and report the failing rank's code -- within seconds, not a collective timeout"""
@@ -74,6 +85,11 @@ def test_force_dist_single_rank_rccl():
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1
     assert d["value"] > 1e6 and 0.0 < d["roofline"]["frac"] < 1.0
     assert d["roofline"]["launches"] == 10
+    # the second axis and the per-rank preflight record
+    r = d["roofline"]
+    assert r["flops_per_ascan"] == 5 * 1024 * 10 + 30 * 1024 and 0.0 < r["frac_fp32_vector"] < 1.0 and r["valu_floor_frac"] == 0.57
+    assert abs(r["achieved_tflops"] - r["flops_per_ascan"] * 512 * 32 / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved_tflops"]
+    assert len(d["preflight"]) == 1 and d["preflight"][0]["device"] == 0 and d["preflight"][0]["slab"] == [0, 32]
 
 
 @pytest.mark.gpu
@@ -85,6 +101,30 @@ def test_gpus_flag_launches_rank_processes_on_the_gpu_box():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2
     assert d["config"]["parallelism"] == "bscan-slab x2"
     assert d["value"] > 1e6
+    assert [x["rank"] for x in d["preflight"]] == [0, 1] and d["roofline"]["traffic"] is None
+
+
+@pytest.mark.gpu
+def test_strong_scaling_mode_on_the_gpu_box():
+    """`--total-bscans 64 --gpus 2`: the fixed volume cut into two 32-B-scan slabs, value = the whole volume's A-scans per second"""
+    d = _run(["--gpus", "2", "--backend", "gloo", "--total-bscans", "64", "--steps", "6", "--warmup", "2", "--warmup-seconds", "0.2",
+              "--no-cpu-baseline", "--no-extras"], timeout=900)
+    assert d["scaling"] == "strong" and d["config"]["bscans_per_rank"] == [32, 32]
+    assert abs(d["value"] - 512 * 64 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_traffic_is_measured_by_the_run_itself_or_null():
+    """roofline.traffic comes from rocprofv3 --pmc passes of THIS invocation (child processes), never from a file"""
+    d = _run(["--steps", "10", "--warmup", "2", "--warmup-seconds", "0.2", "--bscans", "64", "--no-cpu-baseline", "--no-extras"], timeout=900)
+    r = d["roofline"]
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert r["traffic"] is not None, r["traffic_source"]
+        assert 0.95 < r["traffic_over_algorithmic"] < 1.2, r  # 4 N bytes per A-scan, nothing re-read
+        assert "measured by this run" in r["traffic_source"]
+    else:
+        assert r["traffic"] is None and "not on PATH" in r["traffic_source"]
 
 
 @pytest.mark.gpu

@@ -21,7 +21,10 @@ reproduce it without this library: tools/pcie_pattern.hip, 7.2-9.7 ms per 256 Mi
 profiles/r3e_pcie_pattern.txt), which puts the preloaded + float leg at ~15.6 M instead of ~24 M.  The test prints the
 runtime it ran on; the floor holds for both.
 
-OCT_STREAM_SECONDS (default 10) sets the duration; 60 is the BASELINE form."""
+Durations: the preloaded + float leg runs BASELINE's 60 s by default (OCT_STREAM_SECONDS_LONG), the two copy-to-RAM legs 10 s
+(OCT_STREAM_SECONDS).  Besides the bit-for-bit comparison of every delivered buffer with the HIP path's own image of that
+buffer (plumbing integrity: no torn, stale or swapped buffer), the expected images themselves and ONE B-SCAN PER SECOND taken out
+of the delivered stream are held against the ORACLE (strict tolerance mode)."""
 import ctypes as C
 import os
 import subprocess
@@ -36,6 +39,7 @@ from octproz_amd import Pipeline, Recorder, VirtualOCTSystem, synthetic_raw, v18
 
 pytestmark = pytest.mark.gpu
 SECONDS = float(os.environ.get("OCT_STREAM_SECONDS", "10"))
+SECONDS_LONG = float(os.environ.get("OCT_STREAM_SECONDS_LONG", "60"))  # BASELINE config 5: "sustained A-scans/s over 60 s"
 
 
 def _pcmp_lib():
@@ -60,8 +64,11 @@ class ParallelChecker:
     waits until the check of buffer k-1 has finished (normally long done) -- at most one check is ever outstanding, and a
     buffer is never overwritten before it has been compared."""
 
-    def __init__(self, expected, threads):
+    def __init__(self, expected, threads, sample_bscan_floats=0, bscans=0):
         import queue
+        import time
+        self.clock = time.monotonic
+        self.sample_floats, self.bscans, self.samples, self.next_sample = sample_bscan_floats, bscans, [], 0.0
         self.lib = _pcmp_lib()
         self.threads = threads
         # expected images re-homed by the comparing threads themselves (first touch spreads the pages over the NUMA nodes)
@@ -86,6 +93,12 @@ class ParallelChecker:
             k, buf = item
             if self.lib.pcmp(buf, self.expected[k % len(self.expected)].ctypes.data, self.nbytes, self.threads) != 0:
                 self.bad.append(k)
+            if self.sample_floats and self.clock() >= self.next_sample:
+                # one B-scan per second out of the delivered stream, kept for the comparison with the ORACLE after the run
+                b = (7 * k + 3) % self.bscans
+                src = (C.c_float * self.sample_floats).from_address(buf + 4 * b * self.sample_floats)
+                self.samples.append((k, b, np.ctypeslib.as_array(src).copy()))
+                self.next_sample = self.clock() + 1.0
             self.checked += 1
             self.idle.set()
 
@@ -130,12 +143,28 @@ def test_config5_full_size_streaming_every_buffer_bit_exact(mode, streams):
     n_buf = 2 if mode == "preloaded" else 4
     dev = torch.device("cuda", 0)
     raws_dev = [synthetic_raw_torch(N, A, B, dev, seed=5000 + i) for i in range(n_buf)]
+    torch.cuda.synchronize()  # torch's stream: the pipeline's own streams do not wait for it
     p = v180_benchmark_params(N, A, B)
     expected, mean = _expected_images(p, raws_dev)
     assert not np.array_equal(expected[0], expected[1])
     data = np.concatenate([d.cpu().numpy().view(np.uint16).reshape(-1) for d in raws_dev])
     del raws_dev
     torch.cuda.empty_cache()
+    seconds = SECONDS_LONG if mode == "preloaded" else SECONDS
+    # the oracle's image of single B-scans (v1.8.0 settings: nothing couples neighbouring B-scans)
+    p1 = v180_benchmark_params(N, A, 1)
+    half = N // 2 * A
+
+    def oracle_bscan(buffer_index, b):
+        o = common.make_oracle(p1)
+        o.set_mean_line(mean)
+        raw = data.reshape(n_buf, B, A, N)[buffer_index, b]
+        img = o.process(raw)
+        o.close()
+        return img
+    for i in range(n_buf):  # what every delivered buffer is compared with bit for bit: first and last B-scan against the oracle
+        for b in (0, B - 1):
+            common.compare_images(expected[i][b * half:(b + 1) * half], oracle_bscan(i, b), p1, "expected image %d, B-scan %d" % (i, b), strict=True, mean_line=mean)
     quant = streams == "float+u16"
     expected_q = [octref.float_to_output(e, 12) for e in expected] if quant else None
 
@@ -153,7 +182,7 @@ def test_config5_full_size_streaming_every_buffer_bit_exact(mode, streams):
     # comparing threads: a quarter of the CPUs the container may use (16 on the pool's boxes, whatever nproc says): more would
     # take the CPU time the DMA submission and the ring threads need
     workers = int(os.environ.get("OCT_CHECK_THREADS", max(2, min(8, int(_lib.lib().octhost_usable_cpus()) // 4))))
-    cf = ParallelChecker(expected, workers)
+    cf = ParallelChecker(expected, workers, sample_bscan_floats=half, bscans=B)
     cq = None
     if quant:
         qb = [np.zeros(S2, np.uint16), np.zeros(S2, np.uint16)]
@@ -162,7 +191,7 @@ def test_config5_full_size_streaming_every_buffer_bit_exact(mode, streams):
     pipe.set_callbacks(on_streaming=cq, on_float_streaming=cf)
     pipe._sync_params()
     system.run_pipeline(pipe, max_buffers=4)  # page-fault / clock warm-up, checked like the rest
-    stats = system.run_pipeline(pipe, max_seconds=SECONDS)  # returns after octpipe_synchronize: every callback has fired
+    stats = system.run_pipeline(pipe, max_seconds=seconds)  # returns after octpipe_synchronize: every callback has fired
     system.stopAcquisition()
     total = int(stats.buffersProcessed) + 4
     cf.idle.wait()
@@ -176,8 +205,16 @@ def test_config5_full_size_streaming_every_buffer_bit_exact(mode, streams):
     assert cf.checked == total and (cq is None or cq.checked == total)
     assert cf.bad == [] and (cq is None or cq.bad == []), "corrupted buffers: float %r quantised %r" % (cf.bad[:8], cq.bad[:8] if cq else None)
     assert np.array_equal(pipe.processed_host().view(np.uint32), expected[(total - 1) % n_buf].view(np.uint32))
-    assert stats.elapsedSeconds >= SECONDS
-    assert stats.ascansPerSecond >= FLOORS[(mode, streams)], "%.2f M A-scans/s" % (stats.ascansPerSecond / 1e6)
+    assert stats.elapsedSeconds >= seconds
+    assert stats.ascansPerSecond >= FLOORS[(mode, streams)], "%.2f M A-scans/s on HIP runtime %d" % (stats.ascansPerSecond / 1e6, ver.value)
+    # the B-scans sampled out of the stream (one per second) against the oracle; buffer k of the run is input buffer k % n_buf
+    assert len(cf.samples) >= int(0.8 * seconds), "%d samples in %.0f s" % (len(cf.samples), seconds)
+    worst = (0.0, 0.0)
+    for k, b, img in cf.samples:
+        r = common.compare_images(img, oracle_bscan(k % n_buf, b), p1, "delivered buffer %d, B-scan %d" % (k, b), strict=True, mean_line=mean)
+        worst = (max(worst[0], r[0]), max(worst[1], r[1]))
+    print("config5 %s %s: %d B-scans sampled from the stream vs the oracle: max linear-power error %.2e, max normalised-dB error %.2e" % (
+        mode, streams, len(cf.samples), worst[0], worst[1]))
     pipe.unregister_float_streaming_buffers()
     if quant:
         pipe.unregister_streaming_buffers()

@@ -135,7 +135,7 @@ def _check_draw(p, raw, what):
         q = copy.copy(p0)
         q.signalMultiplicator, q.signalAddend = 1.0, 0.0
         unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
-        common.compare_images(unscale(got0), unscale(want0), q, what + " (without the background removal)", mean_line=o0.mean_line())
+        common.compare_images(unscale(got0), unscale(want0), q, what + " (without the background removal)", mean_line=o0.mean_line(), cancel=True)
         half = int(p.samplesPerLine) // 2
         expect = octref.postproc_background_removal(got0, np.asarray(p.postProcessBackground, np.float32)[:half], p.postProcessBackgroundWeight,
                                                     p.postProcessBackgroundOffset, half)
@@ -146,7 +146,7 @@ def _check_draw(p, raw, what):
     q = copy.copy(p)
     q.signalMultiplicator, q.signalAddend = 1.0, 0.0
     unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
-    common.compare_images(unscale(got), unscale(want), q, what, mean_line=o.mean_line())
+    common.compare_images(unscale(got), unscale(want), q, what, mean_line=o.mean_line(), cancel=True)
     # the second buffer through the same handle (tables resident, slot logic) gives the same image
     pipe.process_device(d.data_ptr())
     pipe.synchronize()
@@ -221,7 +221,7 @@ def _settings_sequence(seed, rng, N):
         what = "seed %d step %d: N=%d rs=%d/%d win=%d/%d disp=%d roll=%d/%d fpn=%d log=%d flip=%d bpv=%d" % (
             seed, step, N, p.resampling, int(p.resamplingInterpolation), p.windowing, int(p.window), p.dispersionCompensation, p.backgroundRemoval,
             p.rollingAverageWindowSize, p.fixedPatternNoiseRemoval, p.signalLogScaling, p.bscanFlip, p.buffersPerVolume)
-        common.compare_images(pipe.processed_host(), want, p, what, mean_line=o.mean_line())
+        common.compare_images(pipe.processed_host(), want, p, what, mean_line=o.mean_line(), cancel=True)
         o.close()
     pipe.close()
 
@@ -271,7 +271,7 @@ def test_random_setting_combination_in_other_sample_formats(seed):
         q = copy.copy(p)
         q.signalMultiplicator, q.signalAddend = 1.0, 0.0
         unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
-        common.compare_images(unscale(got), unscale(ref), q, what + " " + tag, mean_line=mean)
+        common.compare_images(unscale(got), unscale(ref), q, what + " " + tag, mean_line=mean, cancel=True)
 
     ref, ml, _ = run(vals, 0, 12)
     ml = ml if p.fixedPatternNoiseRemoval else None

@@ -74,7 +74,7 @@ def test_fused_unpack_equals_standalone_unpack_bitwise():
     pipe.synchronize()
     got2 = pipe.processed_host()
     assert np.array_equal(got.view(np.uint32), got2.view(np.uint32))
-    common.compare_images(got, want, p, "u16 full range")
+    common.compare_images(got, want, p, "u16 full range", mean_line=o.mean_line())
     pipe.close(); o.close()
 
 
@@ -94,7 +94,7 @@ def test_lanczos_on_raw_rows_equals_the_prepared_route_bitwise(N, A, B, bitshift
         raw = (raw.astype(np.uint32) * 16).astype(np.uint16)
     p.update_all_curves()
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "lanczos raw rows N=%d %dx%d" % (N, A, B))
+    common.compare_images(got, want, p, "lanczos raw rows N=%d %dx%d" % (N, A, B), mean_line=o.mean_line())
     pipe.debug_force_prepared(True)
     pipe.process_device(d.data_ptr())
     pipe.synchronize()
@@ -216,7 +216,7 @@ def test_chain_matches_oracle(case):
     o, pipe, d, want, got = run_both(p, raw)
     # strict: identical -inf pattern, no bin excused (every chain case on the benchmark data; the exemptions exist for the
     # randomised settings of test_gpu_fuzz.py)
-    common.compare_images(got, want, p, case, strict=True)
+    common.compare_images(got, want, p, case, strict=True, mean_line=o.mean_line())
     if not p.bscanFlip and not p.sinusoidalScanCorrection:
         spec = pipe.debug_spectrum(d.data_ptr(), A * B)
         # oracle spectrum = after mean subtraction; add the mean back on the half it touched
@@ -257,7 +257,7 @@ def test_real_input_kernel_matches_oracle(case, A, B):
     if A * B < 18:
         p.fixedPatternNoiseRemoval = 0  # fewer than 18 lines cannot give a mean line (see the FPN tests)
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "real input %s %dx%d" % (case, A, B))
+    common.compare_images(got, want, p, "real input %s %dx%d" % (case, A, B), mean_line=o.mean_line())
     pipe.close(); o.close()
 
 
@@ -279,7 +279,7 @@ def test_real_input_kernel_on_the_other_lengths(N, case, A, B):
     if A * B < 18:
         p.fixedPatternNoiseRemoval = 0
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "real input %s N=%d %dx%d" % (case, N, A, B))
+    common.compare_images(got, want, p, "real input %s N=%d %dx%d" % (case, N, A, B), mean_line=o.mean_line())
     pipe.close(); o.close()
 
 
@@ -294,7 +294,7 @@ def test_chain_variants_on_the_other_lengths(N, case):
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=N + len(case))
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "%s N=%d" % (case, N))
+    common.compare_images(got, want, p, "%s N=%d" % (case, N), mean_line=o.mean_line())
     if not p.bscanFlip:
         spec = pipe.debug_spectrum(d.data_ptr(), A * B)
         ospec = o.last_spectrum().reshape(-1, N).copy()
@@ -310,7 +310,7 @@ def test_every_supported_length(N):
     p = v180_benchmark_params(N, A, B)
     raw = synthetic_raw(N, A, B, seed=N)
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "N=%d" % N)
+    common.compare_images(got, want, p, "N=%d" % N, mean_line=o.mean_line())
     pipe.close(); o.close()
 
 
@@ -331,7 +331,7 @@ def test_non_power_of_two_lengths_bluestein(N, interp, route):
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=N)
     o, pipe, d, want, got = run_both(p, raw, route=flags)
-    common.compare_images(got, want, p, "N=%d" % N)
+    common.compare_images(got, want, p, "N=%d" % N, mean_line=o.mean_line())
     spec = pipe.debug_spectrum(d.data_ptr(), A * B)
     ospec = o.last_spectrum().reshape(-1, N).copy()
     ospec[:, :N // 2] += o.mean_line()[:N // 2]
@@ -355,7 +355,7 @@ def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=N + len(case))
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "N=%d %s" % (N, case))
+    common.compare_images(got, want, p, "N=%d %s" % (N, case), mean_line=o.mean_line())
     if not p.bscanFlip:
         spec = pipe.debug_spectrum(d.data_ptr(), A * B)
         ospec = o.last_spectrum().reshape(-1, N).copy()
@@ -401,9 +401,9 @@ def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B)
         assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3
         assert got.min() >= 0.0 and got.max() <= 1.0
     else:
-        common.compare_images(ref, want, p, "library route %s" % variant)
-        common.compare_images(got, want, p, "team kernel %s" % variant)
-        common.compare_images(got, ref, p, "team vs library route %s" % variant)
+        common.compare_images(ref, want, p, "library route %s" % variant, mean_line=o.mean_line())
+        common.compare_images(got, want, p, "team kernel %s" % variant, mean_line=o.mean_line())
+        common.compare_images(got, ref, p, "team vs library route %s" % variant, mean_line=o.mean_line())
     assert not np.array_equal(got, ref)
     pipe.close(); lib.close(); o.close()
 
@@ -441,7 +441,7 @@ def test_mixed_radix_1664_chain_matches_oracle(case, A, B):
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=1664 + len(case))
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "N=1664 %s" % case)
+    common.compare_images(got, want, p, "N=1664 %s" % case, mean_line=o.mean_line())
     if not p.bscanFlip:
         spec = pipe.debug_spectrum(d.data_ptr(), A * B)
         ospec = o.last_spectrum().reshape(-1, N).copy()
@@ -462,8 +462,8 @@ def test_mixed_radix_1664_agrees_with_the_bluestein_route():
     blue = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXED | _lib.ROUTE_NO_LIBFFT)
     blue.set_mean_line(o.mean_line(), pin=True)
     blue.process_device(d.data_ptr()); blue.synchronize()
-    common.compare_images(blue.processed_host(), want, p, "bluestein")
-    common.compare_images(got, blue.processed_host(), p, "mixed vs bluestein")
+    common.compare_images(blue.processed_host(), want, p, "bluestein", mean_line=o.mean_line())
+    common.compare_images(got, blue.processed_host(), p, "mixed vs bluestein", mean_line=o.mean_line())
     assert not np.array_equal(got, blue.processed_host())  # two different transforms really ran
     pipe.debug_force_prepared(True)
     pipe.process_device(d.data_ptr()); pipe.synchronize()
@@ -503,9 +503,9 @@ def test_lanczos_on_the_mixed_radix_kernel_of_1664(variant, A, B):
     if p.postProcessBackgroundRemoval:
         assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3 and 0.0 <= got.min() and got.max() <= 1.0
     else:
-        common.compare_images(got, want, p, "mixed-radix Lanczos %s" % variant)
-        common.compare_images(ref, want, p, "Bluestein Lanczos %s" % variant)
-        common.compare_images(got, ref, p, "mixed-radix vs Bluestein %s" % variant)
+        common.compare_images(got, want, p, "mixed-radix Lanczos %s" % variant, mean_line=o.mean_line())
+        common.compare_images(ref, want, p, "Bluestein Lanczos %s" % variant, mean_line=o.mean_line())
+        common.compare_images(got, ref, p, "mixed-radix vs Bluestein %s" % variant, mean_line=o.mean_line())
         if not p.bscanFlip:
             spec = pipe.debug_spectrum(d.data_ptr(), A * B)
             ospec = o.last_spectrum().reshape(-1, N).copy()
@@ -531,9 +531,9 @@ def test_real_input_route_agrees_with_the_complex_route(N):
     general.set_mean_line(o.mean_line(), pin=True)
     general.process_device(d.data_ptr()); general.synchronize()
     ref = general.processed_host()
-    common.compare_images(ref, want, p, "general kernel N=%d" % N)
-    common.compare_images(got, want, p, "real-input kernel N=%d" % N)
-    common.compare_images(got, ref, p, "real-input vs general N=%d" % N)
+    common.compare_images(ref, want, p, "general kernel N=%d" % N, mean_line=o.mean_line())
+    common.compare_images(got, want, p, "real-input kernel N=%d" % N, mean_line=o.mean_line())
+    common.compare_images(got, ref, p, "real-input vs general N=%d" % N, mean_line=o.mean_line())
     assert not np.array_equal(got, ref)
     pipe.close(); general.close(); o.close()
 
@@ -566,7 +566,7 @@ def test_other_container_types(bits, dtype):
     p = v180_benchmark_params(N, A, B)
     p.bitDepth = bits
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "bits=%d" % bits)
+    common.compare_images(got, want, p, "bits=%d" % bits, mean_line=o.mean_line())
     pipe.close(); o.close()
 
 
@@ -592,7 +592,7 @@ def test_committed_golden_vectors(tag):
     d = to_device(raw)
     pipe.process_device(d.data_ptr())
     pipe.synchronize()
-    common.compare_images(pipe.processed_host(), GOLD["img_" + tag], p, tag, strict=True)
+    common.compare_images(pipe.processed_host(), GOLD["img_" + tag], p, tag, strict=True, mean_line=GOLD["mean_" + tag])
     pipe.close()
 
 
@@ -742,9 +742,9 @@ def test_team_kernel_of_4096_matches_oracle_and_the_one_wave_kernel(variant, A, 
         assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3
         assert got.min() >= 0.0 and got.max() <= 1.0
     else:
-        common.compare_images(ref, want, p, "one-wave kernel %s" % variant)
-        common.compare_images(got, want, p, "team kernel %s" % variant)
-        common.compare_images(got, ref, p, "team vs one-wave %s" % variant)
+        common.compare_images(ref, want, p, "one-wave kernel %s" % variant, mean_line=o.mean_line())
+        common.compare_images(got, want, p, "team kernel %s" % variant, mean_line=o.mean_line())
+        common.compare_images(got, ref, p, "team vs one-wave %s" % variant, mean_line=o.mean_line())
     assert not np.array_equal(got, ref)  # two different transforms really ran
     pipe.close(); one.close(); o.close()
 
@@ -786,9 +786,9 @@ def test_team_kernel_of_1664_matches_oracle_and_the_one_wave_kernel(variant, A, 
         assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3
         assert got.min() >= 0.0 and got.max() <= 1.0
     else:
-        common.compare_images(ref, want, p, "one-wave kernel %s" % variant)
-        common.compare_images(got, want, p, "team kernel %s" % variant)
-        common.compare_images(got, ref, p, "team vs one-wave %s" % variant)
+        common.compare_images(ref, want, p, "one-wave kernel %s" % variant, mean_line=o.mean_line())
+        common.compare_images(got, want, p, "team kernel %s" % variant, mean_line=o.mean_line())
+        common.compare_images(got, ref, p, "team vs one-wave %s" % variant, mean_line=o.mean_line())
     assert not np.array_equal(got, ref)  # two different transforms really ran
     pipe.close(); one.close(); o.close()
 
@@ -996,6 +996,7 @@ def _full_size(N, A, B, sample_lines=192, strict=True, **settings):
         return q
     p = params(B)
     d = synthetic_raw_torch(N, A, B, torch.device("cuda:0"), seed=99)
+    torch.cuda.synchronize()  # the generator ran on torch's stream; the pipeline's streams do not wait for it
     pipe = Pipeline(p, device=0)
     pipe.process_device(d.data_ptr()); pipe.synchronize()
     mean = pipe.mean_line()
@@ -1043,7 +1044,7 @@ def _full_size(N, A, B, sample_lines=192, strict=True, **settings):
         o = common.make_oracle(ps)
         o.set_mean_line(mean)
         want = o.process(raw[b0:b0 + nb])
-        common.compare_images(full[b0:b0 + nb].reshape(-1), want, ps, "B-scan %d" % b0, strict=strict)
+        common.compare_images(full[b0:b0 + nb].reshape(-1), want, ps, "B-scan %d" % b0, strict=strict, mean_line=mean)
         o.close()
     pipe.close()
 
@@ -1098,7 +1099,7 @@ def test_tiny_and_single_line_buffers(A, B):
     p.fixedPatternNoiseRemoval = 0  # fewer than 9 lines: the FPN estimate is degenerate (segWidth = 0)
     raw = synthetic_raw(N, A, B, seed=A * 10 + B)
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "A=%d B=%d" % (A, B))
+    common.compare_images(got, want, p, "A=%d B=%d" % (A, B), mean_line=o.mean_line())
     pipe.close(); o.close()
 
 
@@ -1138,7 +1139,7 @@ def test_parameter_change_between_buffers_takes_effect():
     p = v180_benchmark_params(N, A, B)
     raw = synthetic_raw(N, A, B, seed=3)
     o, pipe, d, want, got = run_both(p, raw)
-    common.compare_images(got, want, p, "before")
+    common.compare_images(got, want, p, "before", mean_line=o.mean_line())
     p.c1 = 860.0                       # new resampling curve
     p.window = WindowType.Gauss        # new window
     p.signalGrayscaleMax = 90.0
@@ -1146,6 +1147,6 @@ def test_parameter_change_between_buffers_takes_effect():
     o2 = common.make_oracle(p); o2.set_mean_line(o.mean_line())
     want2 = o2.process(raw)
     pipe.process_device(d.data_ptr()); pipe.synchronize()
-    common.compare_images(pipe.processed_host(), want2, p, "after")
+    common.compare_images(pipe.processed_host(), want2, p, "after", mean_line=o.mean_line())
     assert not np.array_equal(want, want2)
     pipe.close(); o.close(); o2.close()
