@@ -39,7 +39,8 @@ enum {
 	OCTPIPE_ERR_DEVICE = 4,            /* any HIP runtime error (reference: checkCudaErrors -> exit) */
 	OCTPIPE_ERR_UNSUPPORTED = 5,       /* e.g. samplesPerLine outside 8..65536 (fused kernels: 256..4096 and 1664; Bluestein: other lengths
 	                                      up to 2047; everything else through hipFFT, loaded at run time) */
-	OCTPIPE_ERR_NO_DEVICE = 6          /* no HIP device: the product path never falls back to a CPU */
+	OCTPIPE_ERR_NO_DEVICE = 6,         /* no HIP device: the product path never falls back to a CPU */
+	OCTPIPE_ERR_IN_CALLBACK = 7        /* a device-touching entry point was called from inside a data / event callback (see below) */
 };
 
 /* OctAlgorithmParameters::INTERPOLATION, octalgorithmparameters.h:55-59 */
@@ -114,7 +115,11 @@ typedef void (*octpipe_event_callback)(void* user); /* backgroundRecorded, gpu2h
 /* Callbacks run inside hipLaunchHostFunc on the pipeline's result stream (the background callback on the compute stream):
  * while a data callback runs, the next device-to-host copy waits, the kernels of the following buffers do not.  They MUST NOT call any octpipe_* function that
  * touches the device (everything except octpipe_last_error, octpipe_get_acquisition_params and
- * octpipe_get_postprocess_background_host) -- HIP calls are not allowed there and a stream wait would deadlock. */
+ * octpipe_get_postprocess_background_host) -- HIP calls are not allowed there and a stream wait would deadlock.  The library
+ * enforces it: on a thread that is inside one of its callbacks those entry points (octpipe_destroy and octpipe_group_destroy
+ * included) return OCTPIPE_ERR_IN_CALLBACK without touching anything -- a host whose garbage collector finalises a pipeline
+ * object on the callback thread gets an error code, not a hang.  octpipe_callback_active() tells a binding which case it is in. */
+int octpipe_callback_active(void);
 
 /* ------------------------------------------------------------------ library */
 int         octpipe_abi_version(void);

@@ -32,7 +32,8 @@ enum {
 	OCTPIPE_ROUTE_NO_TEAM       = 8,   /* samplesPerLine = 4096 / 1664: keep the one-wave-per-A-scan kernel instead of the team kernel (8192: the library route) */
 	OCTPIPE_ROUTE_NO_LIBFFT     = 16,  /* creation: Bluestein on the in-register FFT instead of hipFFT for lengths without a fused kernel (<= 2047) */
 	OCTPIPE_ROUTE_FORCE_LIBFFT  = 32,  /* creation: every length through unpack -> gather -> hipFFT -> epilogue (the reference's pass structure) */
-	OCTPIPE_ROUTE_NO_MIXED      = 64   /* creation: samplesPerLine = 1664 without the mixed-radix kernel */
+	OCTPIPE_ROUTE_NO_MIXED      = 64,  /* creation: samplesPerLine = 1664 without the mixed-radix kernel */
+	OCTPIPE_ROUTE_NO_MIXEDN     = 128  /* lengths with a generic mixed-radix plan (1000, 1536, 2000 ...): keep the library route / Bluestein */
 };
 int octpipe_debug_set_route(octpipe_t* h, unsigned flags);
 /* octpipe_create_with_format with OCTPIPE_ROUTE_* flags from the start (the creation-time ones select the FFT backend) */

@@ -11,12 +11,34 @@ LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")
 
 OCTPIPE_OK = 0
 # OCTPIPE_ROUTE_* (include/octpipe_debug.h, octpipe_debug_set_route / octpipe_debug_create): keep a configuration on the slower / more general of two routes
-ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED = 1, 2, 4, 8, 16, 32, 64
+ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED, ROUTE_NO_MIXEDN = 1, 2, 4, 8, 16, 32, 64, 128
 # octpipe_debug_last_path (include/octpipe_debug.h OCTPIPE_PATH_*)
 # octpipe_group_create_ex flags (include/octpipe.h)
 GROUP_PLACE_RING_SLABS, GROUP_NO_SUBMIT_THREADS, GROUP_SUBMIT_THREADS = 1, 2, 4
 PATH_PREPARED_ROWS, PATH_FUSED_BG, PATH_TEAM, PATH_REAL_INPUT, PATH_LIBRARY_FFT, PATH_ROLL_IN_KERNEL, PATH_MIXED_RADIX, PATH_BLUESTEIN = 1, 2, 4, 8, 16, 32, 64, 128
-ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE"}
+ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE", 7: "IN_CALLBACK"}
+# handles whose Python object was finalised on a pipeline callback thread (the garbage collector runs wherever an allocation
+# happens): destroying them there is refused by the library (OCTPIPE_ERR_IN_CALLBACK); they are destroyed by the next call of
+# drain_deferred() from an ordinary thread (every Pipeline / PipelineGroup construction and interpreter exit)
+_deferred = []
+
+
+def destroy_or_defer(kind, handle):
+    """octpipe_destroy / octpipe_group_destroy, or -- on a callback thread -- remember the handle for drain_deferred()"""
+    L = lib()
+    if L.octpipe_callback_active():
+        _deferred.append((kind, handle))
+        return
+    (L.octpipe_group_destroy if kind == "group" else L.octpipe_destroy)(handle)
+
+
+def drain_deferred():
+    L = lib()
+    if L.octpipe_callback_active():
+        return
+    while _deferred:
+        kind, handle = _deferred.pop()
+        (L.octpipe_group_destroy if kind == "group" else L.octpipe_destroy)(handle)
 
 
 class OctPipeError(RuntimeError):
@@ -87,7 +109,7 @@ CONSUME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint, C.c_void_p)
 
 # every symbol include/octpipe.h and include/octhost.h declare (checked by tests/test_abi.py)
 OCTPIPE_SYMBOLS = [
-    "octpipe_abi_version", "octpipe_last_error", "octpipe_device_count", "octpipe_default_params", "octpipe_struct_sizes",
+    "octpipe_abi_version", "octpipe_last_error", "octpipe_callback_active", "octpipe_device_count", "octpipe_default_params", "octpipe_struct_sizes",
     "octpipe_polynomial_curve", "octpipe_resample_curve", "octpipe_custom_resample_curve",
     "octpipe_dispersion_curve", "octpipe_window_curve",
     "octpipe_create", "octpipe_create_with_format", "octpipe_raw_buffer_bytes", "octpipe_destroy", "octpipe_set_params", "octpipe_get_acquisition_params",
@@ -266,7 +288,10 @@ def lib():
         if sp.value != C.sizeof(PipeParams) or sa.value != C.sizeof(AcquisitionParams):
             raise OctPipeError(-1, "struct mirror out of date: library %d/%d bytes, python %d/%d"
                                % (sp.value, sa.value, C.sizeof(PipeParams), C.sizeof(AcquisitionParams)))
+        L.octpipe_callback_active.argtypes = []
         _lib = L
+        import atexit
+        atexit.register(drain_deferred)
     return _lib
 
 

@@ -110,6 +110,11 @@ int mixed1664_lanczos_unit(int sample, int c);  // 16-byte unit of weights 4 c .
 // the same length with a real transform input (no dispersion compensation): two A-scans per transform (mixed1664_real2.h)
 hipError_t launch_mixed1664_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 
+// every other even length whose prime factors lie in {2, 3, 5, 7, 11, 13} and whose tables fit the LDS: generic mixed-radix kernel
+// (mixedn_kernel.h).  mixedn_plan: the radices of its passes (at most 8); launch_mixedn: FusedArgs::twiddle = W_N^j, j < N
+bool mixedn_plan(unsigned n, int* passes, int* radix);
+hipError_t launch_mixedn(unsigned n, int passes, const int* radix, int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream);
+
 // power-of-two lengths run the direct FFT
 inline bool fused_supported(unsigned n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
 // every other length up to 2048 runs Bluestein on the padded length 2^log2m >= 2n-1 (log2m in 8..12)

@@ -26,6 +26,7 @@
 namespace {
 
 thread_local std::string g_lastError;
+thread_local bool t_inCallback = false;  // this thread is inside a data / event callback of the pipeline (hipLaunchHostFunc)
 
 int fail(int code, const std::string& msg) {
 	g_lastError = msg;
@@ -109,6 +110,9 @@ struct octpipe {
 	float* d_lanczosW = nullptr;   // [N][16] Lanczos tap weights (uploaded with the LUT while that interpolation is selected)
 	float4* d_lutPlain = nullptr;  // mixed: the LUT without the Bluestein chirp folded in
 	f2* d_twMixed = nullptr;       // mixed: W_1664^{n2 k1}, [32][52]
+	bool mixedN = false;           // a generic mixed-radix plan exists for this length (mixedn_kernel.h): every variant but Lanczos runs on it
+	int mxnPasses = 0, mxnRadix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	f2* d_twMixedN = nullptr;      // W_N^j, j < N
 	f2* d_twTeam = nullptr;        // N = 4096: twiddles of the 16 x 16 x 16 plan of the one-A-scan-per-team kernel (team_kernel.h)
 	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
 	f2* d_filter = nullptr;    // [M] Bluestein filter spectrum
@@ -153,6 +157,10 @@ struct CallbackCtx {  // heap object handed to hipLaunchHostFunc; freed by the c
 void hostCallback(void* p) {
 	CallbackCtx* c = static_cast<CallbackCtx*>(p);
 	octpipe* h = c->h;
+	// HIP calls are not allowed inside a host function, and waiting for the stream that runs it would never return: while the user's
+	// callback runs, every device-touching entry point of the library called from this thread fails with OCTPIPE_ERR_IN_CALLBACK
+	// instead (a garbage collector that finalises some pipeline object on this thread is enough to get there)
+	struct Scope { Scope() { t_inCallback = true; } ~Scope() { t_inCallback = false; } } scope;
 	// argument list of Gpu2HostNotifier::emitCurrentStreamingBuffer (gpu2hostnotifier.cpp:45-53)
 	if (c->kind == 0 && h->onStreaming)
 		h->onStreaming(c->buffer, h->acq.bitDepth, h->acq.samplesPerLine / 2, h->acq.ascansPerBscan, h->acq.bscansPerBuffer, h->acq.buffersPerVolume, c->bufferNr, h->user);
@@ -402,6 +410,18 @@ int uploadTeamTables(octpipe* h) {
 	return uploadSync(h, h->d_twTeam, tw.data(), sizeof(f2) * tw.size());
 }
 
+// the one twiddle table of the generic mixed-radix kernel: W_N^j = e^{+2 pi i j / N}, j < N
+int uploadMixedNTable(octpipe* h) {
+	const int N = h->N;
+	std::vector<f2> tw((size_t)N);
+	for (int j = 0; j < N; ++j) {
+		const double ang = 2.0 * 3.14159265358979323846 * (double)j / (double)N;
+		tw[(size_t)j] = f2{(float)cos(ang), (float)sin(ang)};
+	}
+	HIP_TRY(hipMalloc((void**)&h->d_twMixedN, sizeof(f2) * tw.size()));
+	return uploadSync(h, h->d_twMixedN, tw.data(), sizeof(f2) * tw.size());
+}
+
 // twiddles between the 32-point and the 52-point stage of the N = 1664 plan: W^{n2 k1}, W = e^{+2 pi i / 1664}, as [k1][n2]
 int uploadMixedTables(octpipe* h) {
 	const int N = 1664, N1 = 32, N2 = 52;
@@ -558,7 +578,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	const bool teamLib = h->libfft && h->d_twTeam && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
 	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO &&
 	                        (!roll || (rollInKernel && rs != oct::RS_LANCZOS));  // (rolling average in front of Lanczos: prepared rows)
-	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect) {
+	// lengths with a generic mixed-radix plan (mixedn_kernel.h): everything but Lanczos; plain uint16 rows directly, other containers
+	// and the rolling average through the prepared float32 rows
+	const bool mxn = h->mixedN && rs != oct::RS_LANCZOS && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN);
+	const bool mxnDirect = mxn && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
+	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect && !mxnDirect) {
 		int rc = ensure(h, (void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
 		if ((rc = launchPrepare(h, d_raw, h->d_prepared, h->S, roll ? p.rollingAverageWindowSize : 0))) return rc;
@@ -571,7 +595,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
 	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
 	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
-	if (wantBg && !spectrum && (!h->libfft || teamLib) && (useMixed || !h->bluestein)) {
+	if (wantBg && !spectrum && (!h->libfft || teamLib || mxn) && (useMixed || !h->bluestein || mxn)) {
 		int rc = ensure(h, (void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
 		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {
@@ -618,7 +642,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (teamLib && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !p.dispersionCompensation &&
+	if (mxn) {
+		a.twiddle = h->d_twMixedN;
+		path |= OCTPIPE_PATH_MIXED_RADIX;
+		HIP_TRY(oct::launch_mixedn((unsigned)h->N, h->mxnPasses, h->mxnRadix, intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
+	} else if (teamLib && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !p.dispersionCompensation &&
 	    !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
 		// N = 8192, real FFT input (no dispersion compensation): two A-scans per team transform
 		a.twiddle = h->d_twTeam;
@@ -630,6 +658,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
 	} else if (h->libfft) {
 		path |= OCTPIPE_PATH_LIBRARY_FFT;
+		if (!h->fftExecC2C) return fail(OCTPIPE_ERR_UNSUPPORTED, "this variant of this samplesPerLine needs libhipfft.so, which could not be loaded");
 		int rc = launchLibFft(h, a, rs, spectrum, p.signalLogScaling != 0);
 		if (rc) return rc;
 	} else if (useMixed) {
@@ -968,6 +997,7 @@ bool fftLibraryAvailable() {
 }
 
 int setDevice(const octpipe* h) {
+	if (t_inCallback) return fail(OCTPIPE_ERR_IN_CALLBACK, "called from inside a pipeline callback: no device work is allowed there");
 	HIP_TRY(hipSetDevice(h->device));
 	// hipLaunchKernelGGL reports through the thread's last-error slot, and the launchers return hipGetLastError(): a status a host
 	// application left there on this thread (PyTorch probes host pointers with calls that fail by design) must not be taken for a
@@ -1100,7 +1130,16 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	if ((rc = ensure(h, (void**)&h->d_sinusCurve, sizeof(float) * h->A))) return rc;
 	if ((rc = ensure(h, (void**)&h->d_dispBscan, sizeof(float) * ((size_t)h->N * h->A / 2)))) return rc;
 	if ((rc = ensure(h, (void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
-	if (h->libfft) { if ((rc = bindFftLibrary(h))) return rc; }
+	// lengths without a dedicated kernel: the generic mixed-radix kernel where the length factors into 2, 3, 5, 7, 11, 13 and its
+	// tables fit the LDS (mixedn_plan); the library route / Bluestein stay for Lanczos and for every other length
+	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT)) && oct::mixedn_plan(acq->samplesPerLine, &h->mxnPasses, h->mxnRadix)) {
+		h->mixedN = true;
+		if ((rc = uploadMixedNTable(h))) return rc;
+	}
+	if (h->libfft) {
+		rc = bindFftLibrary(h);
+		if (rc && !h->mixedN) return rc;  // (with a mixed-radix plan only Lanczos needs the library: it fails when it is asked for)
+	}
 	else if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
 	if (h->mixed && (rc = uploadMixedTables(h))) return rc;
@@ -1126,8 +1165,11 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	return OCTPIPE_OK;
 }
 
+int octpipe_callback_active(void) { return t_inCallback ? 1 : 0; }
+
 int octpipe_destroy(octpipe_t* h) {
 	if (!h) return OCTPIPE_OK;
+	if (t_inCallback) return fail(OCTPIPE_ERR_IN_CALLBACK, "octpipe_destroy from inside a pipeline callback: destroy the handle from another thread");
 	hipSetDevice(h->device);
 	if (h->stream) hipStreamSynchronize(h->stream);
 	if (h->copyStream) hipStreamSynchronize(h->copyStream);
@@ -1146,7 +1188,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_processedAlt, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW};
+	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW, h->d_twMixedN};
 	for (void* b : bufs) if (b) hipFree(b);
 	// the (drained) streams of the handle go to the idle list of the device; the next handle created there takes them over
 	if (h->stream && h->ownStream && h->copyStream && h->outStream) {
@@ -1317,7 +1359,7 @@ int octpipe_process_device(octpipe_t* h, const void* d_raw) {
 
 int octpipe_synchronize(octpipe_t* h) {
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
-	int rc = setDevice(h); if (rc) return rc;
+	int rc = setDevice(h); if (rc) return rc;  // (fails inside a callback: waiting there for the stream that runs it would never return)
 	HIP_TRY(hipStreamSynchronize(h->copyStream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	HIP_TRY(hipStreamSynchronize(h->outStream));  // after the compute stream: its work waits on events recorded there

@@ -415,6 +415,7 @@ int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const
 
 int octpipe_group_destroy(octpipe_group_t* g) {
 	if (!g) return OCTPIPE_OK;
+	if (octpipe_callback_active()) return gfail(OCTPIPE_ERR_IN_CALLBACK, "octpipe_group_destroy from inside a pipeline callback: destroy the group from another thread");
 	for (size_t i = 0; i < g->members.size(); ++i) if (g->members[i]) octpipe_synchronize(g->members[i]);
 	for (size_t i = 0; i < g->comms.size(); ++i) {  // (also what a creation that failed half-way has built so far)
 		hipSetDevice(g->devices[i]);

@@ -21,6 +21,7 @@ class Pipeline:
         self.params = params
         self._h = C.c_void_p()
         self._lib = _lib.lib()
+        _lib.drain_deferred()
         acq = params.acquisition()
         pod = params.pod()
         self._keep = (h_buffer1, h_buffer2)
@@ -55,7 +56,7 @@ class Pipeline:
 
     def cleanupCuda(self):
         if self._h:
-            self._lib.octpipe_destroy(self._h)
+            _lib.destroy_or_defer("pipeline", self._h)  # (a finaliser may run on a callback thread: destroyed later then)
             self._h = C.c_void_p()
 
     close = cleanupCuda
@@ -253,6 +254,7 @@ class PipelineGroup:
     def __init__(self, params: OctAlgorithmParameters, devices, h_buffer1=None, h_buffer2=None, flags=0):
         self.params = params
         self._lib = _lib.lib()
+        _lib.drain_deferred()
         self._g = C.c_void_p()
         devs = (C.c_int * len(devices))(*devices)
         acq, pod = params.acquisition(), params.pod()
@@ -350,7 +352,7 @@ class PipelineGroup:
 
     def close(self):
         if self._g:
-            self._lib.octpipe_group_destroy(self._g)
+            _lib.destroy_or_defer("group", self._g)
             self._g = C.c_void_p()
 
     cleanupCuda = close

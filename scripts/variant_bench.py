@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1024)
     ap.add_argument("--ascans", type=int, default=512)
     ap.add_argument("--bscans", type=int, default=256)
+    ap.add_argument("--route", type=int, default=0, help="OCTPIPE_ROUTE_* flags (include/octpipe_debug.h), e.g. 128 = keep the library route where a generic mixed-radix plan exists")
     args = ap.parse_args()
     N, A, B = args.samples, args.ascans, args.bscans
     vols = [synthetic_raw_torch(N, A, B, "cuda:0", seed=i) for i in range(4)]
@@ -55,7 +56,7 @@ def main():
             import numpy as np
             p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
         p.update_all_curves()
-        pipe = Pipeline(p, device=0)
+        pipe = Pipeline(p, device=0, route=args.route)
         for i in range(10):
             pipe.process_device(vols[i % 4].data_ptr(), sync_params=(i == 0))
         pipe.synchronize()
@@ -66,7 +67,7 @@ def main():
         dt = (time.perf_counter() - t) / 100
         out.append({"settings": name, "ms_per_buffer": dt * 1e3, "ascans_per_s": A * B / dt})
         pipe.close()
-    print(json.dumps({"workload": "%dx%dx%d" % (N, A, B), "variants": out}))
+    print(json.dumps({"workload": "%dx%dx%d" % (N, A, B), "route_flags": args.route, "variants": out}))
 
 
 if __name__ == "__main__":

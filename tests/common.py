@@ -75,8 +75,8 @@ def image_to_power(v, p):
 # comparison, asserts the count against a stated bound, and adds it to a session-wide ledger that the test run prints at its end
 # (tests/conftest.py: "tolerance ledger").  `strict=True` allows none of them.
 EXEMPT_FRAC = 1e-3          # one-sided -inf: at most this fraction of the buffer's bins per call (strict: none)
-CANCEL_FRAC = 1e-2          # bins excused from the dB comparison by the cancellation rule (randomised tests only, cancel=True; measured
-                            # up to 0.8 % of a buffer on draws with large DC terms; strict: the rule does not exist)
+CANCEL_FRAC = 2e-2          # bins excused from the dB comparison by the cancellation rule (randomised tests only, cancel=True; measured
+                            # up to 1.2 % of a buffer on draws with large DC terms; strict: the rule does not exist)
 # Bins under the dB floor are counted and reported, not bounded: on the synthetic fringes with the v1.8.0 settings the noise floor
 # sits at ~1e-6 of the line maximum (2 % of the bins under the floor at N = 1024, 41 % at N = 2048), and in the settings that
 # keep the DC term (no fixed-pattern-noise removal, or its exact cancellation without dispersion compensation) 75-97 % of the

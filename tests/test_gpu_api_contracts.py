@@ -70,10 +70,11 @@ def test_library_fft_route_follows_set_stream(N):
     raw = synthetic_raw(N, A, B, seed=N)
     o = common.make_oracle(p)
     want = o.process(raw)
-    pipe = Pipeline(p, device=0)
+    pipe = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN)  # (both lengths have a generic mixed-radix plan since round 4: keep the library route)
     pipe.set_mean_line(o.mean_line(), pin=True)
     d = _dev(raw)
     pipe.process_device(d.data_ptr()); pipe.synchronize()  # plans exist and are bound to the handle's own stream
+    assert pipe.last_path() & _lib.PATH_LIBRARY_FFT
     first = pipe.processed_host()
     s = torch.cuda.Stream()
     pipe.set_stream(s.cuda_stream)
@@ -217,8 +218,14 @@ _ROUTING = [
     (1664, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64, "resamplingInterpolation": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
     (1664, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, _P.ROUTE_NO_TEAM, _P.PATH_MIXED_RADIX | _P.PATH_PREPARED_ROWS),
     (1664, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX),
-    (1000, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
-    (1000, {}, 0, _P.ROUTE_NO_LIBFFT, _P.PATH_BLUESTEIN | _P.PATH_PREPARED_ROWS),
+    (1000, {}, 0, 0, _P.PATH_MIXED_RADIX),                                                     # generic mixed-radix kernel (8 x 5 x 5 x 5), raw uint16 rows
+    (1000, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_PREPARED_ROWS),
+    (1000, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_FUSED_BG),
+    (1000, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),  # Lanczos stays on the library route
+    (1000, {}, 0, _P.ROUTE_NO_MIXEDN, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
+    (1000, {}, 0, _P.ROUTE_NO_LIBFFT | _P.ROUTE_NO_MIXEDN, _P.PATH_BLUESTEIN | _P.PATH_PREPARED_ROWS),
+    (3000, {}, 0, 0, _P.PATH_MIXED_RADIX),
+    (1234, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # 2 x 617: no plan
 ]
 
 
@@ -241,3 +248,44 @@ def test_routing_table(N, settings, fmt, route, want):
     got = pipe.last_path()
     pipe.close()
     assert got == want, "N=%d %s: path bits %#x, expected %#x" % (N, settings, got, want)
+
+
+def test_device_work_inside_a_callback_is_refused_not_deadlocked():
+    """callbacks run inside hipLaunchHostFunc: HIP calls are not allowed there and a wait for the stream that runs the callback would
+    never return.  The library refuses every device-touching entry point on such a thread with OCTPIPE_ERR_IN_CALLBACK (7) -- found
+    when a leaked PipelineGroup was garbage-collected on the callback thread of a later streaming test and its finaliser hung the
+    whole test run in octpipe_group_destroy.  The Python wrapper defers such a finalisation to an ordinary thread."""
+    import gc
+    N, A, B = 1024, 32, 4
+    p = v180_benchmark_params(N, A, B)
+    p.streamFloatToHost = 1
+    raw = synthetic_raw(N, A, B, seed=77)
+    pipe = Pipeline(p, device=0)
+    victim = [Pipeline(v180_benchmark_params(256, 8, 2), device=0)]  # will be finalised on the callback thread
+    S2 = N * A * B // 2
+    fb = [np.zeros(S2, np.float32), np.zeros(S2, np.float32)]
+    pipe.register_float_streaming_buffers(fb[0], fb[1])
+    seen = {}
+
+    def on_float(buf, bit_depth, spl, lines, frames, bpv, nr, user):
+        L = _lib.lib()
+        seen["in_callback"] = L.octpipe_callback_active()
+        seen["sync"] = L.octpipe_synchronize(pipe.handle)
+        seen["msg"] = (L.octpipe_last_error() or b"").decode()
+        seen["destroy"] = L.octpipe_destroy(victim[0].handle)
+        seen["host_accessor"] = L.octpipe_get_acquisition_params(pipe.handle, __import__("ctypes").byref(_lib.AcquisitionParams()))
+        v = victim.pop()
+        del v
+        gc.collect()  # the wrapper's __del__ runs HERE, on the callback thread
+        seen["deferred"] = len(_lib._deferred)
+    pipe.set_callbacks(on_float_streaming=on_float)
+    pipe.octCudaPipeline(raw)
+    pipe.synchronize()
+    deferred = seen.pop("deferred")  # (>= 1: the collector may finalise other leaked wrappers on this thread as well)
+    assert deferred >= 1 and seen == {"in_callback": 1, "sync": 7, "msg": seen["msg"], "destroy": 7, "host_accessor": 0}, seen
+    assert "callback" in seen["msg"]
+    assert _lib.lib().octpipe_callback_active() == 0
+    _lib.drain_deferred()
+    assert _lib._deferred == []
+    pipe.unregister_float_streaming_buffers()
+    pipe.close()

@@ -86,7 +86,7 @@ def test_config4_host_buffer_equals_one_handle(volume, threads):
     for k in range(2):
         g.octCudaPipeline(volume["host"]); g.synchronize()
         _check(g.processed_host(), volume["want"], "host buffer, threads=%s, pass %d" % (threads, k))
-    assert g.info["serial_submits"] == 0 and g.broadcasts == 0
+    assert g.info["serial_submits"] == 0 and g.broadcasts == 1  # (the curves go out with the first buffer; the mean line is the pinned one)
     g.close()
 
 

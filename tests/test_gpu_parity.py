@@ -314,16 +314,19 @@ def test_every_supported_length(N):
     pipe.close(); o.close()
 
 
-@pytest.mark.parametrize("route", ["library", "bluestein"])
+@pytest.mark.parametrize("route", ["default", "library", "bluestein"])
 @pytest.mark.parametrize("N", [1664, 1000, 1536, 300, 96, 2046])
 @pytest.mark.parametrize("interp", [INTERPOLATION.CUBIC, INTERPOLATION.LINEAR, INTERPOLATION.LANCZOS])
 def test_non_power_of_two_lengths_bluestein(N, interp, route):
-    # lengths that are neither a power of two nor 1664 take the library route by default (faster), Bluestein on the in-register
-    # FFT where hipFFT is not available or with OCTPIPE_ROUTE_NO_LIBFFT: both against the oracle
-    flags = (_lib.ROUTE_NO_LIBFFT | _lib.ROUTE_NO_MIXED) if route == "bluestein" else 0
+    # lengths that are neither a power of two nor 1664: the generic mixed-radix kernel by default where the length factors into
+    # 2, 3, 5, 7, 11, 13 (mixedn_kernel.h, round 4; everything but Lanczos), else / with OCTPIPE_ROUTE_NO_MIXEDN the library route,
+    # and Bluestein on the in-register FFT where hipFFT is not available or with OCTPIPE_ROUTE_NO_LIBFFT: all against the oracle
+    flags = {"default": 0, "library": _lib.ROUTE_NO_MIXEDN, "bluestein": _lib.ROUTE_NO_LIBFFT | _lib.ROUTE_NO_MIXED | _lib.ROUTE_NO_MIXEDN}[route]
     """the reference gives any samplesPerLine to cuFFT (cu:1140); its own recording has 1664 samples"""
     if interp != INTERPOLATION.CUBIC and N not in (1664, 300):
         pytest.skip("interpolation variants on two lengths only")
+    if route == "library" and N in (1664, 2046):
+        pytest.skip("no generic plan for this length: the default IS the library route (2046 = 2 x 3 x 11 x 31) / the dedicated kernel (1664)")
     A, B = 20, 2
     p = v180_benchmark_params(N, A, B)
     p.resamplingInterpolation = interp
@@ -331,11 +334,103 @@ def test_non_power_of_two_lengths_bluestein(N, interp, route):
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=N)
     o, pipe, d, want, got = run_both(p, raw, route=flags)
+    if N != 1664:  # which implementation ran (a silent fall-back to another correct route would go unnoticed otherwise)
+        lanczos = interp == INTERPOLATION.LANCZOS
+        expect = {"default": _lib.PATH_MIXED_RADIX if (N != 2046 and not lanczos) else _lib.PATH_LIBRARY_FFT,
+                  "library": _lib.PATH_LIBRARY_FFT, "bluestein": _lib.PATH_BLUESTEIN}[route]
+        assert pipe.last_path() & (_lib.PATH_MIXED_RADIX | _lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN) == expect, hex(pipe.last_path())
     common.compare_images(got, want, p, "N=%d" % N, mean_line=o.mean_line())
     spec = pipe.debug_spectrum(d.data_ptr(), A * B)
     ospec = o.last_spectrum().reshape(-1, N).copy()
     ospec[:, :N // 2] += o.mean_line()[:N // 2]
     common.compare_spectra(spec, ospec, N, "N=%d" % N)
+    pipe.close(); o.close()
+
+
+MIXEDN_CASES = {
+    "v180": mutate(),
+    "linear": mutate(resamplingInterpolation=INTERPOLATION.LINEAR),
+    "nothing": mutate(windowing=0, dispersionCompensation=0, resampling=0),
+    "no_dispersion": mutate(dispersionCompensation=0),
+    "lin_scale_flip": mutate(signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0, bscanFlip=1),
+    "rolling8": mutate(backgroundRemoval=1, rollingAverageWindowSize=8),        # prepared float32 rows in front of the kernel
+    "bitshift": mutate(bitshift=1, bitDepth=16),
+    "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
+                        signalGrayscaleMax=110.0, signalGrayscaleMin=20.0),       # background removal inside the store
+}
+
+
+@pytest.mark.parametrize("N", [1000, 1200, 2000, 2304, 3072, 3600, 5000, 130, 182, 2310, 4620, 64])
+@pytest.mark.parametrize("case", list(MIXEDN_CASES))
+def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case):
+    """mixedn_kernel.h: one A-scan per workgroup, Stockham passes over a run-time plan of radices 16, 13, 11, 8, 7, 5, 4, 3, 2 (1000 = 8 x 5^3,
+    2304 = 16 x 16 x 3 x 3, 2310 = 2 x 3 x 5 x 7 x 11, 182 = 2 x 7 x 13 ...), the whole chain on chip.  Against the oracle (image and
+    spectrum) and against the library route (gather -> hipFFT -> epilogue), which is really different code."""
+    if N > 2400 and case not in ("v180", "nothing", "lin_scale_flip"):
+        pytest.skip("long lengths on three cases (the oracle's DFT is O(N^2))")
+    A, B = 20, 2
+    p = v180_benchmark_params(N, A, B)
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    MIXEDN_CASES[case](p)
+    if p.postProcessBackgroundRemoval:
+        p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + len(case), msb_aligned=bool(p.bitshift))
+    o, pipe, d, want, got = run_both(p, raw)
+    assert pipe.last_path() & _lib.PATH_MIXED_RADIX and not pipe.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN), hex(pipe.last_path())
+    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (case == "rolling8")
+    p.postProcessBackgroundUpdated = True
+    lib = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN)
+    if p.fixedPatternNoiseRemoval:
+        lib.set_mean_line(o.mean_line(), pin=True)
+    lib.process_device(d.data_ptr()); lib.synchronize()
+    ref = lib.processed_host()
+    assert lib.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN)
+    if p.postProcessBackgroundRemoval:  # behind the clamp the image is compared directly (both sides clamp the same way)
+        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - got).max() < 1e-3
+        assert got.min() >= 0.0 and got.max() <= 1.0
+        assert pipe.last_path() & _lib.PATH_FUSED_BG
+    else:
+        common.compare_images(got, want, p, "generic kernel N=%d %s" % (N, case), mean_line=o.mean_line())
+        common.compare_images(got, ref, p, "generic kernel vs library route N=%d %s" % (N, case), mean_line=o.mean_line())
+    if not p.bscanFlip:
+        spec = pipe.debug_spectrum(d.data_ptr(), A * B)
+        ospec = o.last_spectrum().reshape(-1, N).copy()
+        if p.fixedPatternNoiseRemoval:
+            ospec[:, :N // 2] += o.mean_line()[:N // 2]
+        common.compare_spectra(spec, ospec, N, "N=%d %s" % (N, case))
+    pipe.close(); lib.close(); o.close()
+
+
+@pytest.mark.parametrize("N,A,B", [(130, 900, 3), (1000, 700, 4), (1000, 7, 3), (1000, 1, 1), (2000, 1, 1)])
+@pytest.mark.parametrize("container", ["uint16", "uint8", "uint32"])
+def test_generic_mixed_radix_kernel_line_counts_and_containers(N, A, B, container):
+    """more A-scans than persistent workgroups (every workgroup loops), ragged and single-line buffers; 8-bit and 32-bit containers
+    (cu:109-147) arrive as prepared float32 rows; the mean line is determined by the kernel's own spectrum output (cu:1518-1525)"""
+    bits = {"uint16": 12, "uint8": 8, "uint32": 24}[container]
+    if container != "uint16" and A * B > 100:
+        pytest.skip("containers on the small buffers")
+    p = v180_benchmark_params(N, A, B)
+    p.bitDepth = bits
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    if A < 18:
+        p.fixedPatternNoiseRemoval = 0  # the estimate takes the first B-scan: fewer than 18 lines give no meaningful segments
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + A)
+    if container == "uint8":
+        raw = (raw >> 4).astype(np.uint8)
+    elif container == "uint32":
+        raw = raw.astype(np.uint32) * 4096
+    o, pipe, d, want, got = run_both(p, raw, pin=False)  # unpinned: the GPU determines the mean line from its own spectra
+    assert pipe.last_path() & _lib.PATH_MIXED_RADIX
+    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (container != "uint16")
+    if p.fixedPatternNoiseRemoval:
+        spec = pipe.debug_spectrum(d.data_ptr(), A)
+        common.check_min_variance_mean(pipe.mean_line(), spec, N, "N=%d" % N)
+        pipe.set_mean_line(o.mean_line(), pin=True)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        got = pipe.processed_host()
+    common.compare_images(got, want, p, "N=%d %dx%d %s" % (N, A, B, container), mean_line=o.mean_line())
     pipe.close(); o.close()
 
 
@@ -354,7 +449,8 @@ def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
     CASES[case](p)
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=N + len(case))
-    o, pipe, d, want, got = run_both(p, raw)
+    o, pipe, d, want, got = run_both(p, raw, route=_lib.ROUTE_NO_MIXEDN)  # (3000 and 2500 have a generic mixed-radix plan: test above)
+    assert pipe.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_TEAM), hex(pipe.last_path())
     common.compare_images(got, want, p, "N=%d %s" % (N, case), mean_line=o.mean_line())
     if not p.bscanFlip:
         spec = pipe.debug_spectrum(d.data_ptr(), A * B)
