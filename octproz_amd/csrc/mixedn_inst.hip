@@ -7,7 +7,9 @@ namespace oct {
 // N = R_0 R_1 ... with radices from {16, 13, 11, 8, 7, 5, 4, 3, 2}: false when N has another prime factor, is odd (N / 2 bins), lies
 // outside 8 .. MXN_MAXN or does not fit the LDS of a CU (29 N bytes + 2 N for the background term).  Large radices first: fewer passes, fewer barriers.
 bool mixedn_plan(unsigned n, int* passes, int* radix) {
-	if (n < 8 || n > (unsigned)MXN_MAXN || (n & 1u) || mxn_lds_bytes((int)n) + (int)n * 2 > 160 * 1024) return false;
+	// beyond ~2 300 samples the two exchange buffers leave one or two workgroups per CU and the library route is faster (measured,
+	// profiles/r4j_mixedn_ab.txt: N = 3072 23 vs 31 M A-scans/s): those lengths keep it
+	if (n < 8 || n > (unsigned)MXN_MAXN_ROUTED || (n & 1u) || mxn_lds_bytes((int)n) + (int)n * 2 > 160 * 1024) return false;
 	unsigned rest = n;
 	int twos = 0, count = 0, odd[MXN_MAXPASSES * 2];
 	int nodd = 0;
@@ -27,30 +29,35 @@ bool mixedn_plan(unsigned n, int* passes, int* radix) {
 	else if (twos == 1) r[count++] = 2;
 	for (int i = 0; i < nodd; ++i) r[count++] = odd[i];
 	if (count > MXN_MAXPASSES) return false;
-	// every pass must fit the thread's register slots: N / R butterflies over MXN_T threads
 	for (int i = 0; i < count; ++i) radix[i] = r[i];
 	*passes = count;
 	return true;
 }
 
 namespace {
-template <int INTYPE, int RS, int MODE>
-hipError_t launch_mixedn_one(const MixedNArgs& g, hipStream_t stream) {
-	auto kernel = oct_mixedn_kernel<INTYPE, RS, MODE>;
+template <int T, int INTYPE, int RS, int MODE>
+hipError_t launch_mixedn_t(const MixedNArgs& g, hipStream_t stream) {
+	auto kernel = oct_mixedn_kernel<T, INTYPE, RS, MODE>;
 	const size_t lds = (size_t)mxn_lds_bytes(g.N) + ((MODE & MODE_BG) ? (size_t)g.N * 2 : 0);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
 	KernelLaunchInfo info;
 	// the opt-in to > 64 KiB of dynamic LDS is per kernel: ask for the whole CU once, size every launch by its own length
-	hipError_t e = kernel_launch_info(kernel, MXN_T, 160 * 1024, &info);
+	hipError_t e = kernel_launch_info(kernel, T, 160 * 1024, &info);
 	if (e != hipSuccess) return e;
 	size_t perCU = (160 * 1024) / lds;
-	if (perCU > 8) perCU = 8;  // 2048 threads per CU
+	if (perCU > (size_t)(OCT_MXN_MINW * 256 / T)) perCU = (size_t)(OCT_MXN_MINW * 256 / T);  // the register budget: OCT_MXN_MINW waves per SIMD
 	if (perCU < 1) perCU = 1;
 	unsigned blocks = (unsigned)((size_t)info.numCU * perCU);
 	if (blocks > g.a.numLines) blocks = g.a.numLines;
 	if (blocks == 0) return hipSuccess;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(MXN_T), lds, stream, g);
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(T), lds, stream, g);
 	return hipGetLastError();
+}
+template <int INTYPE, int RS, int MODE>
+hipError_t launch_mixedn_one(const MixedNArgs& g, hipStream_t stream) {
+	// short lengths: 128 threads per A-scan (the passes of a 1000-sample transform have 125-200 butterflies; measured: N = 1000 105 ->
+	// 130 M A-scans/s, N = 1200 90 M; from N = 1536 on 256 threads are faster: 77 vs 63 M)
+	return g.N <= 1280 ? launch_mixedn_t<128, INTYPE, RS, MODE>(g, stream) : launch_mixedn_t<256, INTYPE, RS, MODE>(g, stream);
 }
 template <int INTYPE, int RS>
 hipError_t launch_mixedn_mode(bool spectrum, bool logScale, const MixedNArgs& g, hipStream_t stream) {

@@ -1,14 +1,14 @@
 // mixedn_kernel.h -- the fused A-scan chain for the lengths that have no dedicated kernel: every even samplesPerLine whose prime
-// factors lie in {2, 3, 5, 7, 11, 13} and whose tables fit the LDS of a CU (up to ~5 500: 1000, 1200, 1536, 2000, 2304, 3072, 3600,
-// 4000, 5000 ...).  The reference hands any length to cuFFT (cu:1140, cu:1514-1515); until round 4 these lengths took the library
+// factors lie in {2, 3, 5, 7, 11, 13}, up to 2304 (1000, 1200, 1536, 2000, 2304 ...; the kernel itself runs any such length whose
+// tables fit the LDS, ~5 500, but beyond ~2 300 its two exchange buffers leave too few workgroups per CU to beat the library route).  The reference hands any length to cuFFT (cu:1140, cu:1514-1515); until round 4 these lengths took the library
 // route here as well (gather kernel -> hipFFT -> epilogue kernel through a complex buffer in HBM, ~28 B of traffic per sample).
 // This kernel keeps the whole chain of kernels.h on chip for them too: 4 N bytes of HBM traffic per A-scan.
 //
-// One A-scan per workgroup of MXN_T threads, persistent.  Stockham autosort with a run-time plan N = R_0 R_1 ... R_{p-1}
+// One A-scan per workgroup of 256 (N <= 1280: 128) threads, persistent.  Stockham autosort with a run-time plan N = R_0 R_1 ... R_{p-1}
 // (radices 16, 13, 11, 8, 7, 5, 4, 3, 2; host: mixedn_plan):
 //   pass i, butterflies b < N / R:  inputs b + t N / R (t < R), twiddle W_N^{t k N / (NS R)} with k = b mod NS, NS = R_0 ... R_{i-1};
 //                                   outputs (b / NS) NS R + k + u NS (u < R)
-// A thread takes the butterflies b = tid, tid + MXN_T, ... one at a time: reads the inputs from one exchange buffer (first pass:
+// A thread takes the butterflies b = tid, tid + T, ... one at a time: reads the inputs from one exchange buffer (first pass:
 // gathers them from the staged row -- k-linearisation x window x phasor, the expressions of the general kernel), transforms them
 // in registers and writes the outputs to the OTHER exchange buffer (element j at j + (j >> 4): the stride-R writes of the
 // first pass and the unit-stride reads spread over the banks); one barrier per pass.  The last pass' outputs are the bins
@@ -22,8 +22,10 @@
 
 namespace oct {
 
-constexpr int MXN_T = 256;         // threads per A-scan
+constexpr int MXN_TMAX = 256;      // threads per A-scan: 256, or 128 for the short lengths (N <= 1280: the passes of a 1000- or 1536-sample
+                                   // transform have 125-200 butterflies, half of 256 lanes would idle)
 constexpr int MXN_MAXN = 8192;
+constexpr int MXN_MAXN_ROUTED = 2304;  // longest length the host routes here (mixedn_plan)
 constexpr int MXN_MAXPASSES = 8;
 struct MixedNArgs {
 	FusedArgs a;  // a.twiddle: W_N^j, j < N
@@ -118,15 +120,15 @@ template <int RS> OCT_DEV f2 gather(const float* row, const float4* lut, int e) 
 	return f2{yw * L.z, yw * L.w};
 }
 
-// one pass: butterflies b = tid, tid + MXN_T, ... < NB.  FIRST: inputs gathered from the staged row; LAST: outputs = bins b + u NB,
+// one pass: butterflies b = tid, tid + T, ... < NB.  FIRST: inputs gathered from the staged row; LAST: outputs = bins b + u NB,
 // through the epilogue to HBM instead of into `dst`
-template <int R, int RS, int MODE, bool FIRST, bool LAST>
+template <int T, int R, int RS, int MODE, bool FIRST, bool LAST>
 OCT_DEV void pass(const f2* src, f2* dst, const f2* twL, const float* row, const FusedArgs& a, int N, int NB, int step, int NS, float rcpNS,
                   unsigned line, unsigned orow, const float* termL, int tid) {
 	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
 	const int half = N / 2;
 #pragma unroll 1
-	for (int b = tid; b < NB; b += MXN_T) {
+	for (int b = tid; b < NB; b += T) {
 		f2 x[R];
 #pragma unroll
 		for (int t = 0; t < R; t++) {
@@ -169,23 +171,23 @@ OCT_DEV void pass(const f2* src, f2* dst, const f2* twL, const float* row, const
 		}
 	}
 }
-template <int R, int RS, int MODE>
+template <int T, int R, int RS, int MODE>
 OCT_DEV void pass_any(bool first, bool last, const f2* src, f2* dst, const f2* twL, const float* row, const FusedArgs& a, int N, int NB, int step, int NS,
                       float rcpNS, unsigned line, unsigned orow, const float* termL, int tid) {
-	if (first && last) pass<R, RS, MODE, true, true>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
-	else if (first) pass<R, RS, MODE, true, false>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
-	else if (last) pass<R, RS, MODE, false, true>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
-	else pass<R, RS, MODE, false, false>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
+	if (first && last) pass<T, R, RS, MODE, true, true>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
+	else if (first) pass<T, R, RS, MODE, true, false>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
+	else if (last) pass<T, R, RS, MODE, false, true>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
+	else pass<T, R, RS, MODE, false, false>(src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid);
 }
 }  // namespace mxn
 
 // INTYPE: IN_U16 (raw rows, bitDepth 9..16) or IN_F32 (rows prepared by oct_prepare[_rows]_kernel: other containers, the rolling
 // average); RS: RS_NONE / RS_LINEAR / RS_CUBIC (Lanczos stays on the library route); MODE: MODE_SPECTRUM | MODE_LOG | MODE_BG
-template <int INTYPE, int RS, int MODE>
+template <int T, int INTYPE, int RS, int MODE>
 #ifndef OCT_MXN_MINW
 #define OCT_MXN_MINW 4
 #endif
-__global__ __launch_bounds__(MXN_T, OCT_MXN_MINW) void oct_mixedn_kernel(const MixedNArgs g) {
+__global__ __launch_bounds__(T, OCT_MXN_MINW) void oct_mixedn_kernel(const MixedNArgs g) {
 	static_assert(INTYPE == IN_U16 || INTYPE == IN_F32, "raw uint16 rows or prepared float32 rows");
 	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "resampling mode");
 	const FusedArgs& a = g.a;
@@ -196,19 +198,23 @@ __global__ __launch_bounds__(MXN_T, OCT_MXN_MINW) void oct_mixedn_kernel(const M
 	f2* xa = reinterpret_cast<f2*>(smem + (size_t)N * 8 + mxn_row_bytes(N));
 	f2* xb = reinterpret_cast<f2*>(smem + (size_t)N * 8 + mxn_row_bytes(N) + mxn_xbuf_bytes(N));
 	const float* termL = reinterpret_cast<const float*>(smem + mxn_lds_bytes(N));
-	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + mxn_lds_bytes(N)), a.bgTerm, N / 2, tid, MXN_T);
-	for (int i = tid; i < N; i += MXN_T) twL[i] = a.twiddle[i];
+	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + mxn_lds_bytes(N)), a.bgTerm, N / 2, tid, T);
+	for (int i = tid; i < N; i += T) twL[i] = a.twiddle[i];
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 
 	for (unsigned line = blockIdx.x; line < a.numLines; line += gridDim.x) {
 		__syncthreads();  // tables filled / every thread is past the previous A-scan's gather
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141)
 		if constexpr (INTYPE == IN_U16) {
-			const uint16_t* src = reinterpret_cast<const uint16_t*>(a.raw) + (size_t)line * N;
-			for (int i = tid; i < N; i += MXN_T) row[ROW_OFF + i] = (float)((uint32_t)src[i] >> shift);
+			// N is even: a row starts on a 4-byte boundary and is read two samples per lane and load
+			const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.raw) + (size_t)line * N);
+			for (int i = tid; i < N / 2; i += T) {
+				const uint32_t w = src[i];
+				*reinterpret_cast<f2*>(&row[ROW_OFF + 2 * i]) = f2{(float)((w & 0xffffu) >> shift), (float)((w >> 16) >> shift)};
+			}
 		} else {
 			const float* src = reinterpret_cast<const float*>(a.raw) + (size_t)line * N;
-			for (int i = tid; i < N; i += MXN_T) row[ROW_OFF + i] = src[i];
+			for (int i = tid; i < N; i += T) row[ROW_OFF + i] = src[i];
 		}
 		__syncthreads();
 		if constexpr (RS == RS_CUBIC) {
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(MXN_T, OCT_MXN_MINW) void oct_mixedn_kernel(const M
 			const int R = g.radix[p], NB = g.nb[p], step = g.step[p];
 			const float rcpNS = __fdiv_rn(1.0f, (float)NS);
 			const bool first = p == 0, last = p == g.passes - 1;
-#define MXN_CASE(RR) case RR: mxn::pass_any<RR, RS, MODE>(first, last, src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid); break;
+#define MXN_CASE(RR) case RR: mxn::pass_any<T, RR, RS, MODE>(first, last, src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid); break;
 			switch (R) {
 				MXN_CASE(16) MXN_CASE(13) MXN_CASE(11) MXN_CASE(8) MXN_CASE(7) MXN_CASE(5) MXN_CASE(4) MXN_CASE(3) MXN_CASE(2)
 			default: break;

@@ -70,7 +70,7 @@ def test_library_fft_route_follows_set_stream(N):
     raw = synthetic_raw(N, A, B, seed=N)
     o = common.make_oracle(p)
     want = o.process(raw)
-    pipe = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN)  # (both lengths have a generic mixed-radix plan since round 4: keep the library route)
+    pipe = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN)  # (600 has a generic mixed-radix plan since round 4: keep the library route)
     pipe.set_mean_line(o.mean_line(), pin=True)
     d = _dev(raw)
     pipe.process_device(d.data_ptr()); pipe.synchronize()  # plans exist and are bound to the handle's own stream
@@ -224,7 +224,8 @@ _ROUTING = [
     (1000, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),  # Lanczos stays on the library route
     (1000, {}, 0, _P.ROUTE_NO_MIXEDN, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
     (1000, {}, 0, _P.ROUTE_NO_LIBFFT | _P.ROUTE_NO_MIXEDN, _P.PATH_BLUESTEIN | _P.PATH_PREPARED_ROWS),
-    (3000, {}, 0, 0, _P.PATH_MIXED_RADIX),
+    (2000, {}, 0, 0, _P.PATH_MIXED_RADIX),
+    (3000, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # a plan exists, but beyond 2304 the library route is faster
     (1234, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # 2 x 617: no plan
 ]
 
