@@ -358,9 +358,8 @@ def group_run(args):
     N, A, B = args.samples, args.ascans, args.bscans
     slots = max(1, args.out_slots)
     p = v180_benchmark_params(N, A, B * n, buffers_per_volume=slots)  # the WHOLE buffer: n slabs of B B-scans
-    g = PipelineGroup(p, devices)
-    if n > 1 and ndev == 1:
-        g.set_submit_threads(True)  # exercise the threaded submission on a one-GPU box too
+    from octproz_amd import _lib as _plib
+    g = PipelineGroup(p, devices, flags=_plib.GROUP_SUBMIT_THREADS if n > 1 else 0)  # one submitting thread per member (opt-in since round 4)
     vols = []
     for v in range(max(1, args.volumes)):
         vols.append([synthetic_raw_torch(N, A, B, torch.device("cuda", devices[i]), seed=1000 * i + 7 + v) for i in range(n)])

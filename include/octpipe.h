@@ -276,14 +276,14 @@ int octpipe_register_gl_buffer_volume_view(unsigned buf); /* always OCTPIPE_ERR_
 typedef struct octpipe_group octpipe_group_t;
 int octpipe_group_create(octpipe_group_t** out, const int* devices, int n, const OctPipeAcquisitionParams* acqWholeBuffer,
                          const OctPipeParams* params, void* h_buffer1, void* h_buffer2);          /* initializeCuda */
-/* The same with options.  octpipe_group_create == flags 0: submitting threads exactly when every member has a device of its
- * own, and NO change to the caller's memory policy.
+/* The same with options.  octpipe_group_create == flags 0: the caller's thread submits to every member, and NO change to the
+ * caller's memory policy.
  *   OCTPIPE_GROUP_PLACE_RING_SLABS  move the pages of every member's slab of the two ring slots to the NUMA node of that member's
  *                                   GPU before pinning them (mbind MPOL_PREFERRED | MPOL_MF_MOVE on the caller's buffers, best
  *                                   effort; octpipe_group_info reports how many slabs could be placed).  A side effect on memory
  *                                   the caller owns, hence opt-in.
- *   OCTPIPE_GROUP_NO_SUBMIT_THREADS the caller's thread submits to every member even on distinct devices
- *   OCTPIPE_GROUP_SUBMIT_THREADS    one submitting thread per member even when members share a device
+ *   OCTPIPE_GROUP_SUBMIT_THREADS    one submitting host thread per member (see octpipe_group_set_submit_threads)
+ *   OCTPIPE_GROUP_NO_SUBMIT_THREADS the default spelled out: the caller's thread submits to every member
  * On failure *out is NULL and everything the call had allocated (member handles, communicators, staging buffers, pinning of
  * the ring slots) has been released again; octpipe_group_last_error() names the step and the member that failed. */
 enum { OCTPIPE_GROUP_PLACE_RING_SLABS = 1, OCTPIPE_GROUP_NO_SUBMIT_THREADS = 2, OCTPIPE_GROUP_SUBMIT_THREADS = 4 };
@@ -293,9 +293,10 @@ int octpipe_group_destroy(octpipe_group_t* g);                                  
 int octpipe_group_size(const octpipe_group_t* g);
 octpipe_t* octpipe_group_member(octpipe_group_t* g, int i);   /* NULL for a member without B-scans */
 int octpipe_group_slab(const octpipe_group_t* g, int i, unsigned* firstBscan, unsigned* bscanCount);
-/* One submitting host thread per member (persistent, asleep between buffers): on by default when the members sit on distinct
- * devices, so that the n enqueue sequences of a call run side by side instead of one after the other; can be switched on
- * for members that share a device (tests on a one-GPU box) and off.  A caller-owned host buffer that is NOT one of the two
+/* One submitting host thread per member (persistent, asleep between buffers), so that the n enqueue sequences of a call run
+ * side by side instead of one after the other: ~0.1 ms of host work per member and buffer, which at 8 members is more than a
+ * 32 MiB slab copy takes over a member's own PCIe link.  OPT-IN (OCTPIPE_GROUP_SUBMIT_THREADS or this call): the default is the
+ * caller's thread.  A caller-owned host buffer that is NOT one of the two
  * registered ring slots (h_buffer1 / h_buffer2 of the creation call, pinned there) is submitted member after member by the
  * caller's thread instead: the threads only ever start DMA transfers out of pinned memory, never concurrent on-the-fly pinning
  * or staging of pageable memory (octpipe_group_serial_submit_count counts such calls).

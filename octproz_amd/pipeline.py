@@ -309,7 +309,7 @@ class PipelineGroup:
         return self._lib.octpipe_group_size(self._g)
 
     def set_submit_threads(self, enable=True):
-        """one submitting host thread per member (default: on when the members sit on distinct devices)"""
+        """one submitting host thread per member (opt-in; the default is the calling thread)"""
         self._check(self._lib.octpipe_group_set_submit_threads(self._g, 1 if enable else 0))
 
     @property

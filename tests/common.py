@@ -80,7 +80,7 @@ CANCEL_FRAC = 2e-2          # bins excused from the dB comparison by the cancell
 # Bins under the dB floor are counted and reported, not bounded: on the synthetic fringes with the v1.8.0 settings the noise floor
 # sits at ~1e-6 of the line maximum (2 % of the bins under the floor at N = 1024, 41 % at N = 2048), and in the settings that
 # keep the DC term (no fixed-pattern-noise removal, or its exact cancellation without dispersion compensation) 75-97 % of the
-# bins lie more than 60 dB under it (measured, profiles/r4*_tolerance_ledger.txt).  Those bins are not unchecked: the amplitude
+# bins lie more than 60 dB under it (measured, profiles/r4k_tolerance_ledger.txt).  Those bins are not unchecked: the amplitude
 # bound holds every one of them -- it is the same statement as a dB bound that widens with 1 / amplitude.
 LEDGER = {"calls": 0, "strict_calls": 0, "bins": 0, "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "db_checked": 0,
           "max_rel": 0.0, "max_amp": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0, "worst_fraction": {"one_sided_inf": (0.0, ""), "below_db_floor": (0.0, ""), "cancelled": (0.0, "")}}
