@@ -161,6 +161,14 @@ OCT_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
 }
 // byte offset = per-lane VGPR part + compile-time constant c; the constant is split into the
 // 12-bit immediate of the instruction and a 4 KiB-granular scalar offset, so no VALU add is needed
+// cache policy bits of the raw-row loads and the image stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  Both streams are touched
+// exactly once: OCT_LOAD_AUX / OCT_STORE_AUX = 2 marks them non-temporal (A/B switch; profiles/r4m_nt_ab.txt)
+#ifndef OCT_LOAD_AUX
+#define OCT_LOAD_AUX 0
+#endif
+#ifndef OCT_STORE_AUX
+#define OCT_STORE_AUX 2  // image stores non-temporal: +1 % on the headline kernel (0.1580 -> 0.1565 ms, same box interleaved)
+#endif
 OCT_DEV f32x4 buf_load128(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vbase + (c & 4095), c & ~4095, 0));
 }
@@ -169,10 +177,10 @@ OCT_DEV u32x3 buf_load96(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	return __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(r, vbase + (c & 4095), c & ~4095, 0));
 }
 OCT_DEV u32x2 buf_load64(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
-	return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, vbase + (c & 4095), c & ~4095, 0));
+	return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, vbase + (c & 4095), c & ~4095, OCT_LOAD_AUX));
 }
 OCT_DEV void buf_store32(float v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
-	__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, vbase + (c & 4095), c & ~4095, 0);
+	__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, vbase + (c & 4095), c & ~4095, OCT_STORE_AUX);
 }
 // Image store with the post-process background removal folded in (cu:757-767: saturate(v - (weight bg[bin] + offset)), the only
 // clamp of the float path).  Valid whenever no sinusoidal correction sits between the grey-scale mapping and the removal: the
