@@ -33,7 +33,9 @@ enum {
 	OCTPIPE_ROUTE_NO_LIBFFT     = 16,  /* creation: Bluestein on the in-register FFT instead of hipFFT for lengths without a fused kernel (<= 2047) */
 	OCTPIPE_ROUTE_FORCE_LIBFFT  = 32,  /* creation: every length through unpack -> gather -> hipFFT -> epilogue (the reference's pass structure) */
 	OCTPIPE_ROUTE_NO_MIXED      = 64,  /* creation: samplesPerLine = 1664 without the mixed-radix kernel */
-	OCTPIPE_ROUTE_NO_MIXEDN     = 128  /* lengths with a generic mixed-radix plan (1000, 1536, 2000 ...): keep the library route / Bluestein */
+	OCTPIPE_ROUTE_NO_MIXEDN     = 128, /* lengths with a generic mixed-radix plan (1000, 1536, 2000 ...): keep the library route / Bluestein */
+	OCTPIPE_ROUTE_NO_MIXEDN_STATIC = 512, /* keep the run-time-plan kernel (mixedn_kernel.h) where a kernel compiled for the length exists (mixedn_static.h) */
+	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256 /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
 };
 int octpipe_debug_set_route(octpipe_t* h, unsigned flags);
 /* octpipe_create_with_format with OCTPIPE_ROUTE_* flags from the start (the creation-time ones select the FFT backend) */
@@ -55,10 +57,19 @@ enum {
 	OCTPIPE_PATH_REAL_INPUT    = 8,   /* two A-scans per complex transform */
 	OCTPIPE_PATH_LIBRARY_FFT   = 16,  /* gather -> hipFFT -> epilogue */
 	OCTPIPE_PATH_ROLL_IN_KERNEL = 32, /* rolling average inside the transform kernel */
-	OCTPIPE_PATH_MIXED_RADIX   = 64,  /* mixed1664.h / mixed1664_real2.h */
-	OCTPIPE_PATH_BLUESTEIN     = 128
+	OCTPIPE_PATH_MIXED_RADIX   = 64,  /* mixed1664.h / mixed1664_real2.h, mixedn_kernel.h */
+	OCTPIPE_PATH_BLUESTEIN     = 128,
+	OCTPIPE_PATH_STATIC_PLAN   = 256  /* with MIXED_RADIX: the kernel compiled for this length (mixedn_static.h) instead of the run-time plan */
 };
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
+
+/* Lengths without a dedicated kernel run a kernel compiled for them at run time (hiprtc; csrc/mixedn_rtc.hip).  Status: whether
+ * the handle's length does (h may be NULL), its plan (five radices, 0 = unused), how many instances the process has compiled, the
+ * seconds that took, and why the last attempt failed / why this handle keeps another route (empty: no failure). */
+int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int* compiledInProcess, double* compileSeconds, char* message, size_t messageBytes);
+/* The build check of that path without a device: plan samplesPerLine and compile the instance (intype 1 = uint16 rows, 3 = prepared
+ * float32 rows; rs 0 none / 1 linear / 2 cubic; mode 2 spectrum, 4 log, 8 background removal in the store) for `arch` ("gfx950"). */
+int octpipe_debug_rtc_compile(unsigned samplesPerLine, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, int* radices5, double* seconds);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,9 @@
 // Everything is fully unrolled on compile-time indices so the arrays live in VGPRs
 // (runtime-indexed arrays would go to scratch).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 

@@ -19,7 +19,9 @@
 // arithmetic is spent in the VALU.  Algorithmic HBM traffic: 2*N bytes in (uint16), 2*N bytes out
 // (N/2 float32) per A-scan.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "fft_regs.h"

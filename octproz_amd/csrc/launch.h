@@ -4,10 +4,13 @@
 
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
+#include <vector>
 
 #include "bluestein.h"
 #include "kernels.h"
+#include "mixedn_static_plan.h"
 
 namespace oct {
 
@@ -112,7 +115,17 @@ hipError_t launch_mixed1664_real2(int rs, bool logScale, const FusedArgs& a, hip
 
 // every other even length whose prime factors lie in {2, 3, 5, 7, 11, 13} and whose tables fit the LDS: generic mixed-radix kernel
 // (mixedn_kernel.h).  mixedn_plan: the radices of its passes (at most 8); launch_mixedn: FusedArgs::twiddle = W_N^j, j < N
-bool mixedn_plan(unsigned n, int* passes, int* radix);
+bool mixedn_plan(unsigned n, int* passes, int* radix, bool simpleRadicesOnly = false);
+// the same chain with a COMPILE-TIME plan, one wave per A-scan (mixedn_static.h), compiled at run time for the handle's length
+// (mixedn_rtc.hip): mixedn_rtc_plan = the plan of a length (false: not an even length that factors into the radices, or too long);
+// FusedArgs::twiddle = the tables of mixedn_static_twiddles; launch_mixedn_rtc compiles the instance it needs on first use
+// (hipErrorNotSupported + *why when that is impossible in this process)
+bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* d);
+bool mixedn_rtc_available(std::string* why);
+void mixedn_static_twiddles(const mxs::PlanDesc& d, std::vector<f2>& tw);
+hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why);
+int mixedn_rtc_compiled_count(double* seconds, std::string* lastMessage);
+bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why);
 hipError_t launch_mixedn(unsigned n, int passes, const int* radix, int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream);
 
 // power-of-two lengths run the direct FFT

@@ -3,37 +3,53 @@
 #include "mixedn_kernel.h"
 
 namespace oct {
+hipError_t launch_mixedn_rs0(int intype, bool spectrum, bool logScale, const MixedNArgs& g, hipStream_t stream);
+hipError_t launch_mixedn_rs1(int intype, bool spectrum, bool logScale, const MixedNArgs& g, hipStream_t stream);
+hipError_t launch_mixedn_rs2(int intype, bool spectrum, bool logScale, const MixedNArgs& g, hipStream_t stream);
+#define OCT_MXN_LAUNCH_NAME_(rs) launch_mixedn_rs##rs
+#define OCT_MXN_LAUNCH_NAME(rs) OCT_MXN_LAUNCH_NAME_(rs)
 
-// N = R_0 R_1 ... with radices from {16, 13, 11, 8, 7, 5, 4, 3, 2}: false when N has another prime factor, is odd (N / 2 bins), lies
-// outside 8 .. MXN_MAXN or does not fit the LDS of a CU (29 N bytes + 2 N for the background term).  Large radices first: fewer passes, fewer barriers.
-bool mixedn_plan(unsigned n, int* passes, int* radix) {
+// One object per resampling mode (-DOCT_MXN_RS=0|1|2: 20 kernels of 15 butterflies each, minutes of compile time) and one
+// without the macro: the plan and the dispatcher.
+#ifndef OCT_MXN_RS
+// N = R_0 R_1 ... with radices from {20, 16, 15, 14, 13, 12, 11, 10, 8, 7, 6, 5, 4, 3, 2} (the composite ones run the prime-factor map inside
+// the butterfly): false when N has another prime factor, is odd (N / 2 bins), lies outside 8 .. MXN_MAXN_ROUTED or does not fit the LDS
+// of a CU (29 N bytes + 2 N for the background term).  The plan with the FEWEST passes (one barrier and one LDS round trip each);
+// among those the one with the smallest sum of radices (balanced butterflies), largest radix first.
+namespace {
+const int kRadices[15] = {20, 16, 15, 14, 13, 12, 11, 10, 8, 7, 6, 5, 4, 3, 2};
+struct PlanSearch {
+	int best[MXN_MAXPASSES], bestCount = 99, bestSum = 1 << 30, cur[MXN_MAXPASSES];
+	bool simpleOnly = false;  // only the prime and power-of-two radices (OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES: the A/B of the composite ones)
+	void go(unsigned rest, int depth, int sum, int firstCandidate) {
+		if (rest == 1) {
+			if (depth < bestCount || (depth == bestCount && sum < bestSum)) { bestCount = depth; bestSum = sum; for (int i = 0; i < depth; ++i) best[i] = cur[i]; }
+			return;
+		}
+		if (depth >= MXN_MAXPASSES || depth + 1 > bestCount) return;
+		for (int c = firstCandidate; c < 15; ++c) {  // non-increasing radices: every multiset is visited once
+			const unsigned r = (unsigned)kRadices[c];
+			if (rest % r || (simpleOnly && (r == 20 || r == 15 || r == 14 || r == 12 || r == 10 || r == 6))) continue;
+			cur[depth] = (int)r;
+			go(rest / r, depth + 1, sum + (int)r, c);
+		}
+	}
+};
+}  // namespace
+bool mixedn_plan(unsigned n, int* passes, int* radix, bool simpleRadicesOnly) {
 	// beyond ~2 300 samples the two exchange buffers leave one or two workgroups per CU and the library route is faster (measured,
 	// profiles/r4j_mixedn_ab.txt: N = 3072 23 vs 31 M A-scans/s): those lengths keep it
 	if (n < 8 || n > (unsigned)MXN_MAXN_ROUTED || (n & 1u) || mxn_lds_bytes((int)n) + (int)n * 2 > 160 * 1024) return false;
-	unsigned rest = n;
-	int twos = 0, count = 0, odd[MXN_MAXPASSES * 2];
-	int nodd = 0;
-	while ((rest & 1u) == 0) { rest >>= 1; ++twos; }
-	const int primes[5] = {13, 11, 7, 5, 3};
-	for (int p : primes)
-		while (rest % (unsigned)p == 0) {
-			if (nodd >= MXN_MAXPASSES) return false;
-			odd[nodd++] = p;
-			rest /= (unsigned)p;
-		}
-	if (rest != 1) return false;
-	int r[MXN_MAXPASSES * 2];
-	while (twos >= 4) { r[count++] = 16; twos -= 4; }
-	if (twos == 3) r[count++] = 8;
-	else if (twos == 2) r[count++] = 4;
-	else if (twos == 1) r[count++] = 2;
-	for (int i = 0; i < nodd; ++i) r[count++] = odd[i];
-	if (count > MXN_MAXPASSES) return false;
-	for (int i = 0; i < count; ++i) radix[i] = r[i];
-	*passes = count;
+	PlanSearch ps;
+	ps.simpleOnly = simpleRadicesOnly;
+	ps.go(n, 0, 0, 0);
+	if (ps.bestCount > MXN_MAXPASSES) return false;
+	for (int i = 0; i < ps.bestCount; ++i) radix[i] = ps.best[i];
+	*passes = ps.bestCount;
 	return true;
 }
 
+#else  // OCT_MXN_RS
 namespace {
 template <int T, int INTYPE, int RS, int MODE>
 hipError_t launch_mixedn_t(const MixedNArgs& g, hipStream_t stream) {
@@ -65,17 +81,16 @@ hipError_t launch_mixedn_mode(bool spectrum, bool logScale, const MixedNArgs& g,
 	if (g.a.bgTerm) return logScale ? launch_mixedn_one<INTYPE, RS, MODE_LOG | MODE_BG>(g, stream) : launch_mixedn_one<INTYPE, RS, MODE_BG>(g, stream);
 	return logScale ? launch_mixedn_one<INTYPE, RS, MODE_LOG>(g, stream) : launch_mixedn_one<INTYPE, RS, 0>(g, stream);
 }
-template <int INTYPE>
-hipError_t launch_mixedn_rs(int rs, bool spectrum, bool logScale, const MixedNArgs& g, hipStream_t stream) {
-	switch (rs) {
-	case RS_NONE: return launch_mixedn_mode<INTYPE, RS_NONE>(spectrum, logScale, g, stream);
-	case RS_LINEAR: return launch_mixedn_mode<INTYPE, RS_LINEAR>(spectrum, logScale, g, stream);
-	case RS_CUBIC: return launch_mixedn_mode<INTYPE, RS_CUBIC>(spectrum, logScale, g, stream);
-	default: return hipErrorInvalidValue;  // Lanczos: library route
-	}
-}
 }  // namespace
 
+hipError_t OCT_MXN_LAUNCH_NAME(OCT_MXN_RS)(int intype, bool spectrum, bool logScale, const MixedNArgs& g, hipStream_t stream) {
+	if (intype == IN_U16) return launch_mixedn_mode<IN_U16, OCT_MXN_RS>(spectrum, logScale, g, stream);
+	if (intype == IN_F32) return launch_mixedn_mode<IN_F32, OCT_MXN_RS>(spectrum, logScale, g, stream);
+	return hipErrorInvalidValue;
+}
+#endif  // OCT_MXN_RS
+
+#ifndef OCT_MXN_RS
 // intype IN_U16 (raw rows) or IN_F32 (prepared rows); a.twiddle = W_N^j (j < N); passes / radix from mixedn_plan
 hipError_t launch_mixedn(unsigned n, int passes, const int* radix, int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream) {
 	MixedNArgs g{};
@@ -90,9 +105,13 @@ hipError_t launch_mixedn(unsigned n, int passes, const int* radix, int intype, i
 		ns *= radix[i];
 	}
 	if (ns != (int)n) return hipErrorInvalidValue;
-	if (intype == IN_U16) return launch_mixedn_rs<IN_U16>(rs, spectrum, logScale, g, stream);
-	if (intype == IN_F32) return launch_mixedn_rs<IN_F32>(rs, spectrum, logScale, g, stream);
-	return hipErrorInvalidValue;
+	switch (rs) {
+	case RS_NONE: return launch_mixedn_rs0(intype, spectrum, logScale, g, stream);
+	case RS_LINEAR: return launch_mixedn_rs1(intype, spectrum, logScale, g, stream);
+	case RS_CUBIC: return launch_mixedn_rs2(intype, spectrum, logScale, g, stream);
+	default: return hipErrorInvalidValue;  // Lanczos: library route
+	}
 }
+#endif
 
 }  // namespace oct

@@ -5,7 +5,7 @@
 // This kernel keeps the whole chain of kernels.h on chip for them too: 4 N bytes of HBM traffic per A-scan.
 //
 // One A-scan per workgroup of 256 (N <= 1280: 128) threads, persistent.  Stockham autosort with a run-time plan N = R_0 R_1 ... R_{p-1}
-// (radices 16, 13, 11, 8, 7, 5, 4, 3, 2; host: mixedn_plan):
+// (radices 20, 16, 15, 14, 13, 12, 11, 10, 8, 7, 6, 5, 4, 3, 2 -- the composite ones by the prime-factor map inside the butterfly; host: mixedn_plan):
 //   pass i, butterflies b < N / R:  inputs b + t N / R (t < R), twiddle W_N^{t k N / (NS R)} with k = b mod NS, NS = R_0 ... R_{i-1};
 //                                   outputs (b / NS) NS R + k + u NS (u < R)
 // A thread takes the butterflies b = tid, tid + T, ... one at a time: reads the inputs from one exchange buffer (first pass:
@@ -69,7 +69,7 @@ template <> struct Trig<13> {
 
 // in-place inverse R-point transform, natural order in and out.  Odd primes in the real-symmetric form of mixed1664.h:
 //   X[d] = A_d + i B_d,  X[R - d] = A_d - i B_d,  A_d = x0 + sum_j (x_j + x_{R-j}) cos(2 pi j d / R),  B_d = sum_j (x_j - x_{R-j}) sin(2 pi j d / R)
-template <int R> OCT_DEV void dft(f2 (&x)[R]) {
+template <int R> OCT_DEV void dft_prime_or_pow2(f2 (&x)[R]) {
 	if constexpr (R == 2 || R == 4 || R == 8 || R == 16) {
 		octfft::Dft<R, 1, false>::run(&x[0]);
 	} else {
@@ -96,6 +96,40 @@ template <int R> OCT_DEV void dft(f2 (&x)[R]) {
 #pragma unroll
 		for (int u = 0; u < R; u++) x[u] = X[u];
 	}
+}
+// composite radices R = R1 R2 with coprime factors by the prime-factor (Good-Thomas) map INSIDE the butterfly: inputs
+// n = (R2 n1 + R1 n2) mod R, R2 transforms of length R1 over n1, R1 transforms of length R2 over n2, outputs k with k = k1 (mod R1),
+// k = k2 (mod R2) -- no twiddles between the two stages, every index a compile-time constant (register renaming).  A 1000-point
+// transform is 10 x 10 x 10 instead of 8 x 5 x 5 x 5: three passes, barriers and LDS round trips instead of four.
+constexpr int mod_inverse(int a, int m) { for (int i = 1; i < m; i++) if ((a * i) % m == 1) return i; return 0; }
+template <int R1, int R2> OCT_DEV void dft_pfa(f2 (&x)[R1 * R2]) {
+	constexpr int R = R1 * R2;
+	f2 y[R2][R1];
+#pragma unroll
+	for (int n2 = 0; n2 < R2; n2++) {
+#pragma unroll
+		for (int n1 = 0; n1 < R1; n1++) y[n2][n1] = x[(R2 * n1 + R1 * n2) % R];
+		dft_prime_or_pow2<R1>(y[n2]);  // over n1 -> k1
+	}
+	constexpr int E1 = R2 * mod_inverse(R2 % R1, R1), E2 = R1 * mod_inverse(R1 % R2, R2);  // k = (E1 k1 + E2 k2) mod R
+#pragma unroll
+	for (int k1 = 0; k1 < R1; k1++) {
+		f2 z[R2];
+#pragma unroll
+		for (int n2 = 0; n2 < R2; n2++) z[n2] = y[n2][k1];
+		dft_prime_or_pow2<R2>(z);  // over n2 -> k2
+#pragma unroll
+		for (int k2 = 0; k2 < R2; k2++) x[(E1 * k1 + E2 * k2) % R] = z[k2];
+	}
+}
+template <int R> OCT_DEV void dft(f2 (&x)[R]) {
+	if constexpr (R == 6) dft_pfa<2, 3>(x);
+	else if constexpr (R == 10) dft_pfa<2, 5>(x);
+	else if constexpr (R == 12) dft_pfa<4, 3>(x);
+	else if constexpr (R == 14) dft_pfa<2, 7>(x);
+	else if constexpr (R == 15) dft_pfa<3, 5>(x);
+	else if constexpr (R == 20) dft_pfa<4, 5>(x);
+	else dft_prime_or_pow2<R>(x);
 }
 
 OCT_DEV int pad16(int j) { return j + (j >> 4); }
@@ -235,7 +269,8 @@ __global__ __launch_bounds__(T, OCT_MXN_MINW) void oct_mixedn_kernel(const Mixed
 			const bool first = p == 0, last = p == g.passes - 1;
 #define MXN_CASE(RR) case RR: mxn::pass_any<T, RR, RS, MODE>(first, last, src, dst, twL, row, a, N, NB, step, NS, rcpNS, line, orow, termL, tid); break;
 			switch (R) {
-				MXN_CASE(16) MXN_CASE(13) MXN_CASE(11) MXN_CASE(8) MXN_CASE(7) MXN_CASE(5) MXN_CASE(4) MXN_CASE(3) MXN_CASE(2)
+				MXN_CASE(20) MXN_CASE(16) MXN_CASE(15) MXN_CASE(14) MXN_CASE(13) MXN_CASE(12) MXN_CASE(11) MXN_CASE(10) MXN_CASE(8) MXN_CASE(7) MXN_CASE(6)
+				MXN_CASE(5) MXN_CASE(4) MXN_CASE(3) MXN_CASE(2)
 			default: break;
 			}
 #undef MXN_CASE

@@ -1,0 +1,205 @@
+// mixedn_static.h -- the fused A-scan chain for ONE length with a COMPILE-TIME plan, one wave per A-scan: the kernel a length
+// without a dedicated kernel gets when it is compiled FOR that length (run-time compilation, mixedn_rtc.hip; the
+// reference hands any length to cuFFT, cu:1140, which plans at run time as well).  mixedn_kernel.h is the same chain over a
+// RUN-TIME plan: every address there costs instructions (pads, twiddle index, k = b mod NS), its passes leave lanes idle and its
+// workgroup pays a barrier per pass.  With N and the radices as template parameters
+//   * one WAVE holds a whole A-scan (N / 64 complex values per lane) and exchanges it between the passes IN PLACE through its
+//     own LDS slice -- no workgroup barrier at all (LDS operations of a wave execute in issue order), 8 N bytes per A-scan
+//     in flight instead of 29 N, the staged row aliased with the exchange buffer;
+//   * every LDS / buffer address is one per-lane base (loop invariant) plus an instruction immediate;
+//   * the twiddles of pass p sit as [k][t - 1] (k < NS_p, row pitch odd): one base per butterfly, immediates for t.
+// Stockham autosort, pass p (radix R, NS = R_0 ... R_{p-1}, NB = N / R butterflies b = lane + 64 it):
+//   inputs b + t NB,  twiddle exp(+2 pi i t k / (NS R)) with k = b mod NS,  outputs (b / NS) NS R + k + u NS
+// Exchange layout: element j at j + j / R_0 when R_0 is even (the first pass writes a butterfly's R_0 outputs contiguously: the
+// lane stride R_0 + 1 is odd, conflict-free; NB_p and NS_p are multiples of R_0 for p >= 1, so j / R_0 splits into a per-lane
+// part and a constant).  The last pass' outputs are the bins b + u NB: those below N / 2 go through the epilogue to HBM.
+#pragma once
+#include "mixedn_kernel.h"
+#include "mixedn_static_plan.h"
+
+namespace oct {
+namespace mxs {
+
+template <int N_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 = 1> struct Plan {
+	static constexpr PlanDesc D = {N_, (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1) + (R4 > 1), {R0, R1, R2, R3, R4}};
+	static constexpr int N = N_, PASSES = D.passes;
+	static_assert(pd_ns(D, D.passes) == N_, "the radices multiply to N (unused trailing radices are 1)");
+	static_assert(N_ % 2 == 0, "N / 2 bins");
+};
+
+OCT_DEV void buf_store64(f2 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
+	__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vbase + (c & 4095), c & ~4095, 0);
+}
+
+// pass p of the plan on the wave's slice (xb = exchange buffer, row = the staged row at the same address)
+template <class P, int p, int RS, int MODE, int MEANN>
+OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, __amdgpu_buffer_rsrc_t lutR, __amdgpu_buffer_rsrc_t outR,
+                  __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane) {
+	constexpr PlanDesc D = P::D;
+	constexpr int N = D.N, R = D.radix[p], NB = N / R, NS = pd_ns(D, p), ITS = pd_its(D, p), PADP = pd_padp(D);
+	constexpr bool FIRST = p == 0, LAST = p == D.passes - 1;
+	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
+	f2 x[ITS][R];
+	// ---- inputs (all of them before the first output is written: the exchange is in place)
+#pragma unroll
+	for (int it = 0; it < ITS; it++) {
+		const int b = lane + 64 * it;
+		if ((it + 1) * 64 <= NB || b < NB) {
+			if constexpr (FIRST) {
+				// k-linearisation x window x dispersion phasor (cu:213-295, cu:341-489): sample b + t NB, the LUT entry through L1 / L2
+				// (in chunks of at most five samples: the 16-byte entries of a whole radix-20 butterfly would hold 80 registers)
+				constexpr int CH = R % 5 == 0 ? 5 : R % 4 == 0 ? 4 : R % 3 == 0 ? 3 : R <= 7 ? R : 1;
+#pragma unroll
+				for (int t0 = 0; t0 < R; t0 += CH) {
+					f32x4 L[CH];
+#pragma unroll
+					for (int c = 0; c < CH; c++) L[c] = buf_load128(lutR, lane * 16, (64 * it + (t0 + c) * NB) * 16);
+#pragma unroll
+					for (int c = 0; c < CH; c++) {
+						const int t = t0 + c;
+						float y;
+						if constexpr (RS == RS_CUBIC) {
+							const float* tp = row + ROW_OFF + (int)L[c].x - 1;  // tap 0 = sample n1 - 1 (the mirror tap of n1 = 0 sits at row[ROW_OFF - 1])
+							y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], __builtin_amdgcn_fractf(L[c].x));
+						} else if constexpr (RS == RS_LINEAR) {
+							const float* tp = row + ROW_OFF + (int)L[c].x;
+							y = tp[0] + (tp[1] - tp[0]) * __builtin_amdgcn_fractf(L[c].x);
+						} else {
+							y = row[ROW_OFF + b + t * NB];
+						}
+						const float yw = y * L[c].y;
+						x[it][t] = f2{yw * L[c].z, yw * L[c].w};
+					}
+				}
+			} else {
+				// element b + t NB at (b + b / R_0) + t (NB + NB / R_0)
+				const f2* src = xb + (PADP ? b + b / PADP : b);
+				constexpr int TS = PADP ? NB + NB / PADP : NB;
+#pragma unroll
+				for (int t = 0; t < R; t++) x[it][t] = src[t * TS];
+			}
+		}
+	}
+	wave_sync_lds();
+	// ---- twiddles, butterflies, outputs
+#pragma unroll
+	for (int it = 0; it < ITS; it++) {
+		const int b = lane + 64 * it;
+		if ((it + 1) * 64 <= NB || b < NB) {
+			const int q = b / NS, k = b - q * NS;
+			if constexpr (!FIRST) {
+				const f2* tw = twL + pd_twoff(D, p) + k * pd_tws(D, p);
+#pragma unroll
+				for (int t = 1; t < R; t++) x[it][t] = octfft::cmul(x[it][t], tw[t - 1]);
+			}
+			mxn::dft<R>(x[it]);
+			if constexpr (!LAST) {
+				// element j0 + u NS, j0 = q NS R + k, at (j0 + j0 / R_0) + u (NS + NS / R_0); first pass: b (R_0 + 1) + u
+				const int j0 = q * (NS * R) + k;
+				f2* dst = xb + (FIRST ? (PADP ? b * (R + 1) : b * R) : (PADP ? j0 + j0 / PADP : j0));
+				constexpr int US = FIRST ? 1 : (PADP ? NS + NS / PADP : NS);
+#pragma unroll
+				for (int u = 0; u < R; u++) dst[u * US] = x[it][u];
+			} else if constexpr (SPECTRUM) {
+#pragma unroll
+				for (int u = 0; u < R; u++) buf_store64(x[it][u], specR, b * 8, u * NB * 8);
+			} else {
+				// bins b + u NB below N / 2: mean A-line, |.|^2, log / lin, grey-scale mapping (cu:492-661); the descriptor of the output row ends
+				// at bin N / 2 (an odd last radix: the bins of its middle output beyond that are dropped by the bounds check)
+#pragma unroll
+				for (int u = 0; u < (R + 1) / 2; u++) {
+					f2 z = x[it][u] - mean[it * ((R + 1) / 2) + u];
+					const float pw = z.x * z.x + z.y * z.y;
+					const float s = LOGSCALE ? __builtin_amdgcn_logf(pw) : __builtin_amdgcn_sqrtf(pw);
+					store_image<BG>(a.sA * s + a.sB, outR, termL, b * 4, u * NB * 4);
+				}
+			}
+		}
+	}
+	if constexpr (!LAST) wave_sync_lds();
+}
+
+template <class P, int p, int RS, int MODE, int MEANN>
+OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, const FusedArgs& a, __amdgpu_buffer_rsrc_t lutR, __amdgpu_buffer_rsrc_t outR,
+                         __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane) {
+	pass<P, p, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane);
+	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane);
+}
+
+// INTYPE: IN_U16 (raw rows, bitDepth 9..16) or IN_F32 (rows prepared by oct_prepare[_rows]_kernel: other containers, the rolling
+// average); RS: RS_NONE / RS_LINEAR / RS_CUBIC; MODE: MODE_SPECTRUM | MODE_LOG | MODE_BG.  a.twiddle: the tables of passes 1 ..
+// in the [k][t - 1] layout above (host: mixedn_static_twiddles).  W waves per workgroup, one workgroup per CU.
+// smem: the workgroup's LDS, pd_lds_bytes(P::D, W, BG) bytes (a static array in the run-time compiled wrapper: its size is a
+// compile-time constant there, and no per-kernel opt-in to more than 64 KiB of dynamic LDS is needed)
+template <class P, int W, int INTYPE, int RS, int MODE>
+OCT_DEV void body(const FusedArgs& a, char* smem) {
+	static_assert(INTYPE == IN_U16 || INTYPE == IN_F32, "raw uint16 rows or prepared float32 rows");
+	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "resampling mode");
+	constexpr PlanDesc D = P::D;
+	constexpr int N = D.N, HALF = N / 2, LP = D.passes - 1, RL = D.radix[LP], NBL = N / RL;
+	constexpr int MEANN = pd_its(D, LP) * ((RL + 1) / 2);
+	constexpr bool BG = (MODE & MODE_BG) != 0;
+	f2* twL = reinterpret_cast<f2*>(smem);
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D);
+	float* row = reinterpret_cast<float*>(slice);
+	f2* xb = reinterpret_cast<f2*>(slice);
+	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + W * pd_slice_bytes(D));
+	if constexpr (BG) fill_bg_term(termL, a.bgTerm, HALF, tid, W * 64);
+	for (int i = tid; i < pd_twelems(D); i += W * 64) twL[i] = a.twiddle[i];
+	// the lane's share of the mean A-line (cu:492-520) for the whole persistent loop: bins b + u NB of the last pass
+	f2 mean[MEANN];
+#pragma unroll
+	for (int it = 0; it < pd_its(D, LP); it++)
+#pragma unroll
+		for (int u = 0; u < (RL + 1) / 2; u++) {
+			const int bin = lane + 64 * it + u * NBL;
+			mean[it * ((RL + 1) / 2) + u] = (a.subtractMean && bin < HALF) ? a.meanLine[bin] : f2{0.0f, 0.0f};
+		}
+	__syncthreads();
+	const uint32_t shift = a.bitshift ? 4u : 0u;
+	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16);
+	constexpr int IN_BYTES = INTYPE == IN_U16 ? 2 : 4;
+
+	for (unsigned line = blockIdx.x * W + wave; line < a.numLines; line += gridDim.x * W) {
+		// ---- stage the raw row as float32 (cu:119-121 / 139-141): 8 bytes of LDS per lane and instruction; the descriptor ends with the
+		// row (lanes beyond it read zeros into the slack of the slice)
+		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * N * IN_BYTES, N * IN_BYTES);
+		if constexpr (INTYPE == IN_U16) {
+			constexpr int LOADS = (HALF + 63) / 64;
+			uint32_t w[LOADS];
+#pragma unroll
+			for (int m = 0; m < LOADS; m++) w[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
+#pragma unroll
+			for (int m = 0; m < LOADS; m++)
+				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF)
+					*reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = f2{(float)((w[m] & 0xffffu) >> shift), (float)((w[m] >> 16) >> shift)};
+		} else {
+			constexpr int LOADS = (HALF + 63) / 64;
+			u32x2 w[LOADS];
+#pragma unroll
+			for (int m = 0; m < LOADS; m++) w[m] = buf_load64(rawR, lane * 8, m * 512);
+#pragma unroll
+			for (int m = 0; m < LOADS; m++)
+				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF)
+					*reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = __builtin_bit_cast(f2, w[m]);
+		}
+		if constexpr (RS == RS_CUBIC) {
+			wave_sync_lds();
+			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
+		}
+		wave_sync_lds();
+		unsigned orow = line;
+		if (a.flip) {
+			const unsigned bs = line / a.ascansPerBscan, as = line - bs * a.ascansPerBscan;
+			if ((bs & 1u) == 0u && (bs + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = bs * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
+		}
+		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * HALF, HALF * 4);
+		const __amdgpu_buffer_rsrc_t specR = make_rsrc(a.spectrum + (size_t)line * N, (MODE & MODE_SPECTRUM) ? N * 8 : 0);
+		passes_from<P, 0, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane);
+		wave_sync_lds();  // the last pass' reads of the slice precede the next row
+	}
+}
+
+}  // namespace mxs
+}  // namespace oct

@@ -1,0 +1,46 @@
+// mixedn_static_plan.h -- the plan of the static-plan kernel (mixedn_static.h) and the layout rules that follow from it, as constexpr
+// functions the kernel (compile time) and the host (table upload, LDS size, waves per workgroup) share
+#pragma once
+#include "kernels.h"
+
+namespace oct {
+namespace mxs {
+
+constexpr int MAXPASSES = 5;
+constexpr int MXS_MAXN = 5120;       // longest length planned (N / 64 complex values per lane)
+constexpr int MXS_MAXVALUES = 80;    // values a lane may hold in a pass (idle butterfly slots included): 160 of its 256 registers
+struct PlanDesc {
+	int N, passes, radix[MAXPASSES];
+};
+constexpr int pd_ns(const PlanDesc& d, int p) { int s = 1; for (int i = 0; i < p; i++) s *= d.radix[i]; return s; }
+constexpr int pd_padp(const PlanDesc& d) { return (d.radix[0] % 2 == 0 && d.passes > 1) ? d.radix[0] : 0; }
+constexpr int pd_xelems(const PlanDesc& d) { return d.N + (pd_padp(d) ? d.N / pd_padp(d) : 0); }
+constexpr int pd_tws(const PlanDesc& d, int p) { return (d.radix[p] - 1) | 1; }  // row pitch of pass p's twiddle table: odd
+constexpr int pd_twoff(const PlanDesc& d, int p) { int o = 0; for (int q = 1; q < p; q++) o += pd_ns(d, q) * pd_tws(d, q); return o; }
+constexpr int pd_twelems(const PlanDesc& d) { return pd_twoff(d, d.passes); }
+constexpr int pd_its(const PlanDesc& d, int p) { return (d.N / d.radix[p] + 63) / 64; }
+constexpr int pd_values(const PlanDesc& d) { int v = 0; for (int p = 0; p < d.passes; p++) { const int w = pd_its(d, p) * d.radix[p]; v = w > v ? w : v; } return v; }
+constexpr int pd_slice_bytes(const PlanDesc& d) {
+	const int x = pd_xelems(d) * 8, r = (d.N + 2 * ROW_OFF) * 4;
+	return ((x > r ? x : r) + 15) & ~15;
+}
+constexpr int pd_tw_bytes(const PlanDesc& d) { return (pd_twelems(d) * 8 + 15) & ~15; }
+// waves (= A-scans in flight) per workgroup, one workgroup per CU: as many as the LDS holds, capped by the register budget that
+// goes with them (16 waves = 128 registers, 12 = 168, 8 = 256).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_ab.txt):
+// cubic 16 waves 298 M A-scans/s (51 registers spilled), 12 waves 340 M, 8 waves 315 M; linear / none 464 / 420 / 362 M.
+constexpr int pd_waves(const PlanDesc& d, bool bg, int rs) {
+	const int room = 160 * 1024 - pd_tw_bytes(d) - (bg ? d.N * 2 : 0);
+	int w = room / pd_slice_bytes(d);
+#ifdef OCT_MXS_WCAP
+	const int cap = OCT_MXS_WCAP;
+#else
+	const int v = pd_values(d) + (rs == RS_CUBIC ? 8 : 0);
+	const int cap = v <= 24 ? 16 : v <= 40 ? 12 : 8;
+#endif
+	if (w > cap) w = cap;
+	return w;
+}
+constexpr int pd_lds_bytes(const PlanDesc& d, int waves, bool bg) { return pd_tw_bytes(d) + waves * pd_slice_bytes(d) + (bg ? d.N * 2 : 0); }
+
+}  // namespace mxs
+}  // namespace oct

@@ -112,6 +112,10 @@ struct octpipe {
 	f2* d_twMixed = nullptr;       // mixed: W_1664^{n2 k1}, [32][52]
 	bool mixedN = false;           // a generic mixed-radix plan exists for this length (mixedn_kernel.h): every variant but Lanczos runs on it
 	int mxnPasses = 0, mxnRadix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	bool mixedStatic = false;      // ... and a static-plan instance of it (mixedn_static.h, one wave per A-scan) for this length
+	oct::mxs::PlanDesc mxsPlan{};
+	std::string rtcMessage;        // why this length has no static-plan kernel although a plan exists (hiprtc not loadable ...)
+	f2* d_twMixedStatic = nullptr;
 	f2* d_twMixedN = nullptr;      // W_N^j, j < N
 	f2* d_twTeam = nullptr;        // N = 4096: twiddles of the 16 x 16 x 16 plan of the one-A-scan-per-team kernel (team_kernel.h)
 	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
@@ -580,7 +584,9 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	                        (!roll || (rollInKernel && rs != oct::RS_LANCZOS));  // (rolling average in front of Lanczos: prepared rows)
 	// lengths with a generic mixed-radix plan (mixedn_kernel.h): everything but Lanczos; plain uint16 rows directly, other containers
 	// and the rolling average through the prepared float32 rows
-	const bool mxn = h->mixedN && rs != oct::RS_LANCZOS && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN);
+	// (mixedStatic: the kernel compiled for this length at run time, mixedn_static.h -- also for lengths beyond the run-time plan's 2304)
+	const bool mxnStatic = h->mixedStatic && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN_STATIC);
+	const bool mxn = (h->mixedN || mxnStatic) && rs != oct::RS_LANCZOS && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN);
 	const bool mxnDirect = mxn && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect && !mxnDirect) {
 		int rc = ensure(h, (void**)&h->d_prepared, sizeof(float) * h->S);
@@ -642,7 +648,15 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		HIP_TRY(hipEventCreate(&t.stop));
 		HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	if (mxn) {
+	if (mxn && mxnStatic) {
+		// (the probe instance compiled when the handle was created: hiprtc works in this process; an instance that fails now is an error)
+		a.twiddle = h->d_twMixedStatic;
+		path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_STATIC_PLAN;
+		std::string why;
+		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream, &why);
+		if (e == hipErrorNotSupported) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);
+		HIP_TRY(e);
+	} else if (mxn) {
 		a.twiddle = h->d_twMixedN;
 		path |= OCTPIPE_PATH_MIXED_RADIX;
 		HIP_TRY(oct::launch_mixedn((unsigned)h->N, h->mxnPasses, h->mxnRadix, intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
@@ -1132,9 +1146,29 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	if ((rc = ensure(h, (void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
 	// lengths without a dedicated kernel: the generic mixed-radix kernel where the length factors into 2, 3, 5, 7, 11, 13 and its
 	// tables fit the LDS (mixedn_plan); the library route / Bluestein stay for Lanczos and for every other length
-	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT)) && oct::mixedn_plan(acq->samplesPerLine, &h->mxnPasses, h->mxnRadix)) {
+	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT)) && oct::mixedn_plan(acq->samplesPerLine, &h->mxnPasses, h->mxnRadix, (createRoute & OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES) != 0)) {
 		h->mixedN = true;
 		if ((rc = uploadMixedNTable(h))) return rc;
+	}
+	// ... and, up to 4096, the static-plan kernel compiled for this very length at run time (mixedn_static.h, mixedn_rtc.hip), if hiprtc
+	// can be had in this process: a probe launch of zero A-scans compiles the most likely instance now, so that a process without a
+	// working hiprtc keeps its other route for the length and says why (octpipe_debug_rtc_status)
+	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT | OCTPIPE_ROUTE_NO_MIXEDN_STATIC)) && oct::mixedn_rtc_plan(acq->samplesPerLine, &h->mxsPlan)) {
+		oct::FusedArgs probe{};
+		std::string why;
+		const bool plain16 = h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO;
+		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, plain16 ? oct::IN_U16 : oct::IN_F32, h->params.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC : oct::RS_LINEAR,
+		                                            false, true, probe, h->stream, &why);
+		if (e == hipSuccess) {
+			std::vector<f2> tw;
+			oct::mixedn_static_twiddles(h->mxsPlan, tw);
+			HIP_TRY(hipMalloc((void**)&h->d_twMixedStatic, sizeof(f2) * tw.size()));
+			if ((rc = uploadSync(h, h->d_twMixedStatic, tw.data(), sizeof(f2) * tw.size()))) return rc;
+			h->mixedStatic = true;
+		} else {
+			(void)hipGetLastError();
+			h->rtcMessage = e == hipErrorNotSupported ? why : std::string(hipGetErrorString(e));
+		}
 	}
 	if (h->libfft) {
 		rc = bindFftLibrary(h);
@@ -1188,7 +1222,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_processedAlt, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW, h->d_twMixedN};
+	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW, h->d_twMixedN, h->d_twMixedStatic};
 	for (void* b : bufs) if (b) hipFree(b);
 	// the (drained) streams of the handle go to the idle list of the device; the next handle created there takes them over
 	if (h->stream && h->ownStream && h->copyStream && h->outStream) {
@@ -1507,6 +1541,31 @@ int octpipe_release_idle_streams(void) {
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path) {
 	if (!h || !path) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	*path = h->lastPath;
+	return OCTPIPE_OK;
+}
+int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int* compiledInProcess, double* compileSeconds, char* message, size_t messageBytes) {
+	std::string last;
+	double sec = 0.0;
+	const int n = oct::mixedn_rtc_compiled_count(&sec, &last);
+	if (compiledInProcess) *compiledInProcess = n;
+	if (compileSeconds) *compileSeconds = sec;
+	if (h) {
+		if (usesIt) *usesIt = h->mixedStatic ? 1 : 0;
+		if (radices5) for (int i = 0; i < oct::mxs::MAXPASSES; ++i) radices5[i] = h->mixedStatic && i < h->mxsPlan.passes ? h->mxsPlan.radix[i] : 0;
+		if (!h->mixedStatic && !h->rtcMessage.empty()) last = h->rtcMessage;
+	}
+	if (message && messageBytes) std::snprintf(message, messageBytes, "%s", last.c_str());
+	return OCTPIPE_OK;
+}
+int octpipe_debug_rtc_compile(unsigned samplesPerLine, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, int* radices5, double* seconds) {
+	oct::mxs::PlanDesc d{};
+	if (!arch) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	if (!oct::mixedn_rtc_plan(samplesPerLine, &d)) return fail(OCTPIPE_ERR_UNSUPPORTED, "no static plan for this samplesPerLine");
+	if (radices5) for (int i = 0; i < oct::mxs::MAXPASSES; ++i) radices5[i] = i < d.passes ? d.radix[i] : 0;
+	std::string why;
+	int w = 0;
+	if (!oct::mixedn_rtc_compile_only(d, intype, rs, mode, arch, codeBytes, &w, seconds, &why)) return fail(OCTPIPE_ERR_UNSUPPORTED, why);
+	if (waves) *waves = w;
 	return OCTPIPE_OK;
 }
 int octpipe_debug_last_grid(const octpipe_t* h, int* blocks) {

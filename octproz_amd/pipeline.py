@@ -170,6 +170,16 @@ class Pipeline:
         check(self._lib.octpipe_debug_last_path(self._h, C.byref(n)))
         return n.value
 
+    def rtc_status(self):
+        """run-time compiled kernel of this handle's length (csrc/mixedn_rtc.hip): {"uses_it", "radices", "compiled_in_process",
+        "compile_seconds", "message"}; message = why the length keeps another route / why the last compilation failed"""
+        uses, n, sec = C.c_int(), C.c_int(), C.c_double()
+        rad = (C.c_int * 5)()
+        msg = C.create_string_buffer(2048)
+        check(self._lib.octpipe_debug_rtc_status(self._h, C.byref(uses), rad, C.byref(n), C.byref(sec), msg, C.c_size_t(2048)))
+        return {"uses_it": bool(uses.value), "radices": [r for r in rad if r], "compiled_in_process": n.value,
+                "compile_seconds": sec.value, "message": msg.value.decode(errors="replace")}
+
     def last_grid(self):
         n = C.c_int()
         check(self._lib.octpipe_debug_last_grid(self._h, C.byref(n)))

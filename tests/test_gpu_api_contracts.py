@@ -218,14 +218,20 @@ _ROUTING = [
     (1664, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64, "resamplingInterpolation": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
     (1664, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, _P.ROUTE_NO_TEAM, _P.PATH_MIXED_RADIX | _P.PATH_PREPARED_ROWS),
     (1664, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX),
-    (1000, {}, 0, 0, _P.PATH_MIXED_RADIX),                                                     # generic mixed-radix kernel (8 x 5 x 5 x 5), raw uint16 rows
-    (1000, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_PREPARED_ROWS),
-    (1000, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_FUSED_BG),
+    (1000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                               # the kernel compiled for the length at run time (10 x 10 x 10), raw uint16 rows
+    (1000, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),
+    (1000, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_FUSED_BG),
+    (1000, {"bitDepth": 8}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),
     (1000, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),  # Lanczos stays on the library route
+    (1000, {}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_MIXED_RADIX),                             # the run-time-plan kernel (mixedn_kernel.h)
+    (1000, {"postProcessBackgroundRemoval": 1}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_MIXED_RADIX | _P.PATH_FUSED_BG),
     (1000, {}, 0, _P.ROUTE_NO_MIXEDN, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
     (1000, {}, 0, _P.ROUTE_NO_LIBFFT | _P.ROUTE_NO_MIXEDN, _P.PATH_BLUESTEIN | _P.PATH_PREPARED_ROWS),
-    (2000, {}, 0, 0, _P.PATH_MIXED_RADIX),
-    (3000, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # a plan exists, but beyond 2304 the library route is faster
+    (2000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
+    (3000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                               # 20 x 15 x 10: beyond the run-time plan's 2304
+    (3000, {}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
+    (5000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                               # 20 x 10 x 5 x 5: the longest lengths (<= 5120) run two A-scans per CU
+    (6000, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # beyond the registers of one wave
     (1234, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # 2 x 617: no plan
 ]
 

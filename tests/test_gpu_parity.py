@@ -360,14 +360,24 @@ MIXEDN_CASES = {
 }
 
 
-@pytest.mark.parametrize("N", [1000, 1200, 1536, 2000, 2304, 130, 182, 2002, 1260, 64])
+MIXEDN_LENGTHS = [1000, 1200, 1536, 2000, 2304, 130, 182, 2002, 1260, 64]
+MIXEDN_STATIC_ONLY = [2500, 3000, 3072, 3600, 4000, 5000, 5120, 24, 4050]  # (4050 = 2 x 3^4 x 5^2: 15 x 15 x 9 has no radix 9 -> 15 x 15 x 6 x 3)
+
+
+@pytest.mark.parametrize("plan", ["static", "runtime"])
+@pytest.mark.parametrize("N", MIXEDN_LENGTHS + MIXEDN_STATIC_ONLY)
 @pytest.mark.parametrize("case", list(MIXEDN_CASES))
-def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case):
-    """mixedn_kernel.h: one A-scan per workgroup, Stockham passes over a run-time plan of radices 16, 13, 11, 8, 7, 5, 4, 3, 2 (1000 = 8 x 5^3,
+def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case, plan):
+    """plan = static: mixedn_static.h, the kernel compiled for the length at run time (hiprtc, mixedn_rtc.hip) -- one wave per A-scan,
+    every even length up to 5120 that factors into the radices 20 ... 2 and fits a wave's registers (1000 = 10 x 10 x 10, 3000 = 20 x 15 x 10,
+    5000 = 20 x 10 x 5 x 5).  plan = runtime (OCTPIPE_ROUTE_NO_MIXEDN_STATIC; the route of a process without hiprtc):
+    mixedn_kernel.h: one A-scan per workgroup, Stockham passes over a run-time plan of radices 16, 13, 11, 8, 7, 5, 4, 3, 2 (1000 = 8 x 5^3,
     2304 = 16 x 16 x 3 x 3, 2002 = 2 x 7 x 11 x 13, 1260 = 4 x 3 x 3 x 5 x 7, 182 = 2 x 7 x 13 ...; up to 2304, longer ones keep the library route), the whole chain on chip.  Against the oracle (image and
     spectrum) and against the library route (gather -> hipFFT -> epilogue), which is really different code."""
     if N > 1600 and case not in ("v180", "nothing", "lin_scale_flip", "no_fpn_bg"):
         pytest.skip("long lengths on four cases (the oracle's DFT is O(N^2))")
+    if plan == "runtime" and N in MIXEDN_STATIC_ONLY:
+        pytest.skip("the run-time plan stops at 2304")
     A, B = 20, 2
     p = v180_benchmark_params(N, A, B)
     p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
@@ -376,8 +386,9 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
         p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=N + len(case), msb_aligned=bool(p.bitshift))
-    o, pipe, d, want, got = run_both(p, raw)
+    o, pipe, d, want, got = run_both(p, raw, route=0 if plan == "static" else _lib.ROUTE_NO_MIXEDN_STATIC)
     assert pipe.last_path() & _lib.PATH_MIXED_RADIX and not pipe.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN), hex(pipe.last_path())
+    assert bool(pipe.last_path() & _lib.PATH_STATIC_PLAN) == (plan == "static"), (hex(pipe.last_path()), pipe.rtc_status())
     assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (case == "rolling8")
     p.postProcessBackgroundUpdated = True
     lib = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN)
@@ -402,14 +413,17 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
     pipe.close(); lib.close(); o.close()
 
 
-@pytest.mark.parametrize("N,A,B", [(130, 900, 3), (1000, 700, 4), (1000, 7, 3), (1000, 1, 1), (2000, 1, 1)])
+@pytest.mark.parametrize("plan", ["static", "runtime"])
+@pytest.mark.parametrize("N,A,B", [(130, 900, 3), (130, 1500, 4), (1000, 700, 4), (1000, 900, 4), (1000, 7, 3), (1000, 1, 1), (2000, 1, 1), (3000, 1300, 1), (3000, 3, 1)])
 @pytest.mark.parametrize("container", ["uint16", "uint8", "uint32"])
-def test_generic_mixed_radix_kernel_line_counts_and_containers(N, A, B, container):
-    """more A-scans than persistent workgroups (every workgroup loops), ragged and single-line buffers; 8-bit and 32-bit containers
+def test_generic_mixed_radix_kernel_line_counts_and_containers(N, A, B, container, plan):
+    """more A-scans than persistent workgroups / waves (every one loops: 256 CUs x 16 waves at N = 130, x 12 at N = 1000, x 5 at N = 3000), ragged and single-line buffers; 8-bit and 32-bit containers
     (cu:109-147) arrive as prepared float32 rows; the mean line is determined by the kernel's own spectrum output (cu:1518-1525)"""
     bits = {"uint16": 12, "uint8": 8, "uint32": 24}[container]
     if container != "uint16" and A * B > 100:
         pytest.skip("containers on the small buffers")
+    if plan == "runtime" and N > 2304:
+        pytest.skip("the run-time plan stops at 2304")
     p = v180_benchmark_params(N, A, B)
     p.bitDepth = bits
     p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
@@ -421,8 +435,9 @@ def test_generic_mixed_radix_kernel_line_counts_and_containers(N, A, B, containe
         raw = (raw >> 4).astype(np.uint8)
     elif container == "uint32":
         raw = raw.astype(np.uint32) * 4096
-    o, pipe, d, want, got = run_both(p, raw, pin=False)  # unpinned: the GPU determines the mean line from its own spectra
+    o, pipe, d, want, got = run_both(p, raw, pin=False, route=0 if plan == "static" else _lib.ROUTE_NO_MIXEDN_STATIC)  # unpinned: the GPU determines the mean line from its own spectra
     assert pipe.last_path() & _lib.PATH_MIXED_RADIX
+    assert bool(pipe.last_path() & _lib.PATH_STATIC_PLAN) == (plan == "static"), (hex(pipe.last_path()), pipe.rtc_status())
     assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (container != "uint16")
     if p.fixedPatternNoiseRemoval:
         spec = pipe.debug_spectrum(d.data_ptr(), A)

@@ -1,0 +1,67 @@
+"""The kernels that are compiled at RUN TIME (csrc/mixedn_rtc.hip: the static-plan kernel of csrc/mixedn_static.h, one instance per
+samplesPerLine without a dedicated kernel) have a build check of their own: hiprtc compiles them for gfx950 without a device, from
+the header text inside liboctpipe.so (csrc/rtc_sources.S) -- what __graft_entry__.build() is for the ahead-of-time kernels.
+Reference: any length goes to cufftPlan1d (cuda_code.cu:1140), which plans at run time too."""
+import ctypes as C
+
+import pytest
+
+from octproz_amd import _lib
+
+IN_U16, IN_F32 = 1, 3
+RS_NONE, RS_LINEAR, RS_CUBIC = 0, 1, 2
+MODE_SPECTRUM, MODE_LOG, MODE_BG = 2, 4, 8
+
+
+def _compile(n, intype=IN_U16, rs=RS_CUBIC, mode=MODE_LOG):
+    L = _lib.lib()
+    L.octpipe_last_error.restype = C.c_char_p
+    code, waves, sec = C.c_size_t(0), C.c_int(0), C.c_double(0)
+    rad = (C.c_int * 5)()
+    rc = L.octpipe_debug_rtc_compile(C.c_uint(n), intype, rs, mode, b"gfx950", C.byref(code), C.byref(waves), rad, C.byref(sec))
+    return rc, [r for r in rad if r], waves.value, code.value, sec.value, (L.octpipe_last_error() or b"").decode(errors="replace")
+
+
+def _hiprtc_present():
+    for name in ("libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"):
+        try:
+            C.CDLL(name)
+            return True
+        except OSError:
+            continue
+    return False
+
+
+needs_hiprtc = pytest.mark.skipif(not _hiprtc_present(), reason="libhiprtc.so is not in the library path of this machine")
+
+
+@needs_hiprtc
+@pytest.mark.parametrize("n,plan", [(1000, [10, 10, 10]), (2000, [20, 10, 10]), (1536, [16, 12, 8]), (3000, [20, 15, 10]), (4000, [20, 20, 10]),
+                                    (2500, [10, 5, 5, 10]), (2002, [13, 11, 14]), (130, [13, 10]), (24, [6, 4]), (5120, None), (5000, None)])
+def test_static_plan_kernel_compiles_for_gfx950_without_a_device(n, plan):
+    rc, radices, waves, code, sec, err = _compile(n)
+    assert rc == 0, err
+    assert code > 4000 and waves >= 2, (code, waves)
+    prod = 1
+    for r in radices:
+        prod *= r
+    assert prod == n and radices[-1] % 2 == 0 and all(2 <= r <= 20 for r in radices), radices
+    if plan is not None:
+        assert radices == plan
+    print("N = %d: plan %s, %d waves per workgroup, %d bytes of code, %.2f s" % (n, " x ".join(map(str, radices)), waves, code, sec))
+
+
+@needs_hiprtc
+@pytest.mark.parametrize("intype", [IN_U16, IN_F32])
+@pytest.mark.parametrize("rs", [RS_NONE, RS_LINEAR, RS_CUBIC])
+@pytest.mark.parametrize("mode", [MODE_SPECTRUM, 0, MODE_LOG, MODE_BG, MODE_LOG | MODE_BG])
+def test_every_instance_of_one_length_compiles(intype, rs, mode):
+    rc, radices, waves, code, sec, err = _compile(1200, intype, rs, mode)
+    assert rc == 0, err
+
+
+@pytest.mark.parametrize("n", [1234, 4094, 1001, 6000, 8190, 7])
+def test_lengths_without_a_static_plan_are_refused(n):
+    """2 x 617, 2 x 23 x 89: a prime factor above 13; odd lengths (N / 2 bins); beyond 5120 / the registers of one wave"""
+    rc, radices, waves, code, sec, err = _compile(n)
+    assert rc == 5 and "no static plan" in err, (rc, err)  # OCTPIPE_ERR_UNSUPPORTED
