@@ -79,18 +79,19 @@ struct Instance {
 	std::string why;
 	double compileSeconds = 0.0;
 };
-typedef std::tuple<int, int, int, int, int, int, int, int, int, int> Key;  // device, N, five radices, intype, rs, mode
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, std::string> Key;  // device, N, five radices, intype, rs, mode, extra options
 struct Cache {
 	std::mutex mtx;
 	std::map<Key, Instance> entries;
 	std::string lastMessage;
+	std::string extraOptions;  // octpipe_debug_rtc_set_options: further compiler options (A/B switches like -DOCT_MXS_PREFETCH=0), separated by blanks
 	int compiled = 0;
 	double compileSeconds = 0.0;
 };
 Cache& cache() { static Cache c; return c; }
 
 // source -> code object for `arch` (no device needed); waves = the launch shape compiled in
-bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, std::vector<char>& code, int* waves, double* seconds, std::string* why) {
+bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, const std::string& extra, std::vector<char>& code, int* waves, double* seconds, std::string* why) {
 	if (!bindRtc(why)) return false;
 	const bool bg = (mode & MODE_BG) != 0;
 	const int W = mxs::pd_waves(d, bg, rs);
@@ -114,9 +115,17 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	rtcProgram prog = nullptr;
 	if (r.createProgram(&prog, src, "oct_mxs.hip", 5, texts, names) != 0) { *why = "hiprtcCreateProgram failed"; return false; }
 	const std::string archOpt = std::string("--offload-arch=") + arch;
-	const char* opts[] = {archOpt.c_str(), "-std=c++17", "-O3", "-Wno-pass-failed"};
+	std::vector<std::string> extras;
+	for (size_t i = 0; i < extra.size();) {
+		const size_t j = extra.find(' ', i);
+		if (j != i) extras.push_back(extra.substr(i, j == std::string::npos ? std::string::npos : j - i));
+		if (j == std::string::npos) break;
+		i = j + 1;
+	}
+	std::vector<const char*> opts = {archOpt.c_str(), "-std=c++17", "-O3", "-Wno-pass-failed"};
+	for (const std::string& e : extras) opts.push_back(e.c_str());
 	const auto t0 = std::chrono::steady_clock::now();
-	const int rc = r.compileProgram(prog, 4, opts);
+	const int rc = r.compileProgram(prog, (int)opts.size(), opts.data());
 	if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	if (rc != 0) {
 		size_t n = 0;
@@ -136,12 +145,12 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	return true;
 }
 
-void compileInstance(const mxs::PlanDesc& d, int intype, int rs, int mode, int dev, Instance& in) {
+void compileInstance(const mxs::PlanDesc& d, int intype, int rs, int mode, int dev, const std::string& extra, Instance& in) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); in.failed = true; in.why = "hipGetDeviceProperties failed"; return; }
 	in.numCU = prop.multiProcessorCount;
 	std::vector<char> code;
-	if (!compileCode(d, intype, rs, mode, prop.gcnArchName, code, &in.waves, &in.compileSeconds, &in.why)) { in.failed = true; return; }
+	if (!compileCode(d, intype, rs, mode, prop.gcnArchName, extra, code, &in.waves, &in.compileSeconds, &in.why)) { in.failed = true; return; }
 	hipError_t e = hipModuleLoadData(&in.module, code.data());
 	if (e == hipSuccess) e = hipModuleGetFunction(&in.fn, in.module, "oct_mxs");
 	if (e != hipSuccess) { (void)hipGetLastError(); in.failed = true; in.why = std::string("loading the compiled kernel failed: ") + hipGetErrorString(e); }
@@ -199,7 +208,7 @@ bool mixedn_rtc_available(std::string* why) { return bindRtc(why); }
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why) {
 	std::vector<char> code;
 	std::lock_guard<std::mutex> lock(cache().mtx);
-	const bool ok = compileCode(d, intype, rs, mode, arch, code, waves, seconds, why);
+	const bool ok = compileCode(d, intype, rs, mode, arch, cache().extraOptions, code, waves, seconds, why);
 	if (codeBytes) *codeBytes = code.size();
 	return ok;
 }
@@ -228,11 +237,11 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool sp
 	Instance* in = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(c.mtx);
-		const Key key{dev, d.N, d.radix[0], d.radix[1], d.radix[2], d.radix[3], d.radix[4], intype, rs, mode};
+		const Key key{dev, d.N, d.radix[0], d.radix[1], d.radix[2], d.radix[3], d.radix[4], intype, rs, mode, c.extraOptions};
 		auto it = c.entries.find(key);
 		if (it == c.entries.end()) {
 			Instance fresh;
-			compileInstance(d, intype, rs, mode, dev, fresh);
+			compileInstance(d, intype, rs, mode, dev, c.extraOptions, fresh);
 			if (fresh.failed) c.lastMessage = fresh.why; else { c.compiled++; c.compileSeconds += fresh.compileSeconds; }
 			it = c.entries.emplace(key, fresh).first;
 		}
@@ -246,6 +255,12 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool sp
 	FusedArgs args = a;
 	void* params[] = {&args};
 	return hipModuleLaunchKernel(in->fn, blocks, 1, 1, (unsigned)in->waves * 64u, 1, 1, 0, stream, params, nullptr);
+}
+
+void mixedn_rtc_set_options(const char* extra) {
+	Cache& c = cache();
+	std::lock_guard<std::mutex> lock(c.mtx);
+	c.extraOptions = extra ? extra : "";
 }
 
 // instances compiled so far in this process, the seconds hiprtc took for them, the message of the last failure

@@ -27,14 +27,32 @@ template <int N_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 = 1> struct
 	static_assert(N_ % 2 == 0, "N / 2 bins");
 };
 
+#ifndef OCT_MXS_PREFETCH
+#define OCT_MXS_PREFETCH 1
+#endif
+template <int INTYPE> struct RawWord { typedef uint32_t T; };  // two uint16 samples
+template <> struct RawWord<IN_F32> { typedef u32x2 T; };      // two float32 samples
+
+// store_image of kernels.h for a lane that may be idle: its store goes beyond the descriptor (dropped), its table read stays in place
+template <bool BG> OCT_DEV void store_image_masked(float v, __amdgpu_buffer_rsrc_t outR, const float* termL, int vbase, int c, bool active) {
+	if constexpr (BG) {
+		const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(termL) + vbase + c);
+		v = v - t;
+		v = !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v);
+	}
+	buf_store32(v, outR, active ? vbase : 0x40000000, c);
+}
+
 OCT_DEV void buf_store64(f2 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vbase + (c & 4095), c & ~4095, 0);
 }
 
 // pass p of the plan on the wave's slice (xb = exchange buffer, row = the staged row at the same address)
-template <class P, int p, int RS, int MODE, int MEANN>
+// (afterInputs: called once the pass has issued all its reads -- the first pass gives the prefetch of the next raw row its place there,
+// behind the LUT loads: vector-memory loads return in order, a row requested earlier would stand in front of them)
+template <class P, int p, int RS, int MODE, int MEANN, class F>
 OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, __amdgpu_buffer_rsrc_t lutR, __amdgpu_buffer_rsrc_t outR,
-                  __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane) {
+                  __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane, F&& afterInputs) {
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, R = D.radix[p], NB = N / R, NS = pd_ns(D, p), ITS = pd_its(D, p), PADP = pd_padp(D);
 	constexpr bool FIRST = p == 0, LAST = p == D.passes - 1;
@@ -43,8 +61,11 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 	// ---- inputs (all of them before the first output is written: the exchange is in place)
 #pragma unroll
 	for (int it = 0; it < ITS; it++) {
-		const int b = lane + 64 * it;
-		if ((it + 1) * 64 <= NB || b < NB) {
+		// (the last iteration of a pass whose NB is no multiple of 64: the idle lanes run butterfly NB - 1 again and keep its outputs to
+		// themselves.  Everything but the stores outside divergent control flow -- with the loads and the arithmetic inside an
+		// `if (b < NB)` the compiler spilled 200-300 registers per lane at N = 3000 / 4000)
+		const int b = ((it + 1) * 64 <= NB || lane + 64 * it < NB) ? lane + 64 * it : NB - 1;
+		{
 			if constexpr (FIRST) {
 				// k-linearisation x window x dispersion phasor (cu:213-295, cu:341-489): sample b + t NB, the LUT entry through L1 / L2
 				// (in chunks of at most five samples: the 16-byte entries of a whole radix-20 butterfly would hold 80 registers)
@@ -53,7 +74,7 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 				for (int t0 = 0; t0 < R; t0 += CH) {
 					f32x4 L[CH];
 #pragma unroll
-					for (int c = 0; c < CH; c++) L[c] = buf_load128(lutR, lane * 16, (64 * it + (t0 + c) * NB) * 16);
+					for (int c = 0; c < CH; c++) L[c] = buf_load128(lutR, b * 16, (t0 + c) * NB * 16);
 #pragma unroll
 					for (int c = 0; c < CH; c++) {
 						const int t = t0 + c;
@@ -80,12 +101,14 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 			}
 		}
 	}
+	afterInputs();
 	wave_sync_lds();
 	// ---- twiddles, butterflies, outputs
 #pragma unroll
 	for (int it = 0; it < ITS; it++) {
-		const int b = lane + 64 * it;
-		if ((it + 1) * 64 <= NB || b < NB) {
+		const bool active = (it + 1) * 64 <= NB || lane + 64 * it < NB;
+		const int b = active ? lane + 64 * it : NB - 1;
+		{
 			const int q = b / NS, k = b - q * NS;
 			if constexpr (!FIRST) {
 				const f2* tw = twL + pd_twoff(D, p) + k * pd_tws(D, p);
@@ -98,11 +121,14 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 				const int j0 = q * (NS * R) + k;
 				f2* dst = xb + (FIRST ? (PADP ? b * (R + 1) : b * R) : (PADP ? j0 + j0 / PADP : j0));
 				constexpr int US = FIRST ? 1 : (PADP ? NS + NS / PADP : NS);
+				if (active) {
 #pragma unroll
-				for (int u = 0; u < R; u++) dst[u * US] = x[it][u];
+					for (int u = 0; u < R; u++) dst[u * US] = x[it][u];
+				}
 			} else if constexpr (SPECTRUM) {
+				const int vb = active ? b * 8 : 0x40000000;  // (beyond the descriptor: dropped)
 #pragma unroll
-				for (int u = 0; u < R; u++) buf_store64(x[it][u], specR, b * 8, u * NB * 8);
+				for (int u = 0; u < R; u++) buf_store64(x[it][u], specR, vb, u * NB * 8);
 			} else {
 				// bins b + u NB below N / 2: mean A-line, |.|^2, log / lin, grey-scale mapping (cu:492-661); the descriptor of the output row ends
 				// at bin N / 2 (an odd last radix: the bins of its middle output beyond that are dropped by the bounds check)
@@ -111,7 +137,7 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 					f2 z = x[it][u] - mean[it * ((R + 1) / 2) + u];
 					const float pw = z.x * z.x + z.y * z.y;
 					const float s = LOGSCALE ? __builtin_amdgcn_logf(pw) : __builtin_amdgcn_sqrtf(pw);
-					store_image<BG>(a.sA * s + a.sB, outR, termL, b * 4, u * NB * 4);
+					store_image_masked<BG>(a.sA * s + a.sB, outR, termL, b * 4, u * NB * 4, active);
 				}
 			}
 		}
@@ -119,11 +145,12 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 	if constexpr (!LAST) wave_sync_lds();
 }
 
-template <class P, int p, int RS, int MODE, int MEANN>
+template <class P, int p, int RS, int MODE, int MEANN, class F>
 OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, const FusedArgs& a, __amdgpu_buffer_rsrc_t lutR, __amdgpu_buffer_rsrc_t outR,
-                         __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane) {
-	pass<P, p, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane);
-	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane);
+                         __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane, F&& afterFirstInputs) {
+	if constexpr (p == 0) pass<P, p, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, afterFirstInputs);
+	else pass<P, p, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, [] {});
+	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, afterFirstInputs);
 }
 
 // INTYPE: IN_U16 (raw rows, bitDepth 9..16) or IN_F32 (rows prepared by oct_prepare[_rows]_kernel: other containers, the rolling
@@ -161,32 +188,33 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16);
 	constexpr int IN_BYTES = INTYPE == IN_U16 ? 2 : 4;
 
-	for (unsigned line = blockIdx.x * W + wave; line < a.numLines; line += gridDim.x * W) {
-		// ---- stage the raw row as float32 (cu:119-121 / 139-141): 8 bytes of LDS per lane and instruction; the descriptor ends with the
-		// row (lanes beyond it read zeros into the slack of the slice)
-		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * N * IN_BYTES, N * IN_BYTES);
-		if constexpr (INTYPE == IN_U16) {
-			constexpr int LOADS = (HALF + 63) / 64;
-			uint32_t w[LOADS];
+	// the raw row of a wave's NEXT A-scan is requested while the current one is transformed (OCT_MXS_PREFETCH; HBM latency off the
+	// critical path: N = 1000 cubic 340 -> ... M A-scans/s) and held in N / 128 (uint16) or N / 64 (float32) registers
+	constexpr int LOADS = (HALF + 63) / 64;
+	typedef typename RawWord<INTYPE>::T RawT;
+	RawT w[LOADS];
+	auto fetch = [&](unsigned ln) {
+		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * N * IN_BYTES, N * IN_BYTES);
 #pragma unroll
-			for (int m = 0; m < LOADS; m++) w[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
-#pragma unroll
-			for (int m = 0; m < LOADS; m++)
-				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF)
-					*reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = f2{(float)((w[m] & 0xffffu) >> shift), (float)((w[m] >> 16) >> shift)};
-		} else {
-			constexpr int LOADS = (HALF + 63) / 64;
-			u32x2 w[LOADS];
-#pragma unroll
-			for (int m = 0; m < LOADS; m++) w[m] = buf_load64(rawR, lane * 8, m * 512);
-#pragma unroll
-			for (int m = 0; m < LOADS; m++)
-				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF)
-					*reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = __builtin_bit_cast(f2, w[m]);
+		for (int m = 0; m < LOADS; m++) {
+			if constexpr (INTYPE == IN_U16) w[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
+			else w[m] = buf_load64(rawR, lane * 8, m * 512);
 		}
-		if constexpr (RS == RS_CUBIC) {
-			wave_sync_lds();
-			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
+	};
+	const unsigned first = blockIdx.x * W + wave, stride = gridDim.x * W;
+	if (OCT_MXS_PREFETCH && first < a.numLines) fetch(first);
+
+	for (unsigned line = first; line < a.numLines; line += stride) {
+		// ---- stage the raw row as float32 (cu:119-121 / 139-141): 8 bytes of LDS per lane and instruction (the descriptor ends with the
+		// row: lanes beyond it read zeros and write nothing)
+		if (!OCT_MXS_PREFETCH) fetch(line);
+#pragma unroll
+		for (int m = 0; m < LOADS; m++) {
+			f2 v;
+			if constexpr (INTYPE == IN_U16) v = f2{(float)((w[m] & 0xffffu) >> shift), (float)((w[m] >> 16) >> shift)};
+			else v = __builtin_bit_cast(f2, w[m]);
+			if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = v;
+			if (RS == RS_CUBIC && m == 0 && lane == 0) row[ROW_OFF - 1] = v.y;  // n0 = |n1 - 1| mirror tap (cu:284): sample 1
 		}
 		wave_sync_lds();
 		unsigned orow = line;
@@ -196,7 +224,9 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 		}
 		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * HALF, HALF * 4);
 		const __amdgpu_buffer_rsrc_t specR = make_rsrc(a.spectrum + (size_t)line * N, (MODE & MODE_SPECTRUM) ? N * 8 : 0);
-		passes_from<P, 0, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane);
+		passes_from<P, 0, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, [&] {
+			if (OCT_MXS_PREFETCH) { const unsigned next = line + stride; fetch(next < a.numLines ? next : line); }  // (a wave's last A-scan: its own row again)
+		});
 		wave_sync_lds();  // the last pass' reads of the slice precede the next row
 	}
 }

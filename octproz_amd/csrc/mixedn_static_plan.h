@@ -26,7 +26,7 @@ constexpr int pd_slice_bytes(const PlanDesc& d) {
 }
 constexpr int pd_tw_bytes(const PlanDesc& d) { return (pd_twelems(d) * 8 + 15) & ~15; }
 // waves (= A-scans in flight) per workgroup, one workgroup per CU: as many as the LDS holds, capped by the register budget that
-// goes with them (16 waves = 128 registers, 12 = 168, 8 = 256).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_ab.txt):
+// goes with them (16 waves = 128 registers, 12 = 168, 8 = 256, 4 = 512).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_ab.txt):
 // cubic 16 waves 298 M A-scans/s (51 registers spilled), 12 waves 340 M, 8 waves 315 M; linear / none 464 / 420 / 362 M.
 constexpr int pd_waves(const PlanDesc& d, bool bg, int rs) {
 	const int room = 160 * 1024 - pd_tw_bytes(d) - (bg ? d.N * 2 : 0);
@@ -35,7 +35,7 @@ constexpr int pd_waves(const PlanDesc& d, bool bg, int rs) {
 	const int cap = OCT_MXS_WCAP;
 #else
 	const int v = pd_values(d) + (rs == RS_CUBIC ? 8 : 0);
-	const int cap = v <= 24 ? 16 : v <= 40 ? 12 : 8;
+	const int cap = v <= 24 ? 16 : v <= 40 ? 12 : v <= 48 ? 8 : 4;  // (4 waves: one per SIMD, 512 registers -- 60 values and more spill at 256)
 #endif
 	if (w > cap) w = cap;
 	return w;

@@ -1557,6 +1557,10 @@ int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int
 	if (message && messageBytes) std::snprintf(message, messageBytes, "%s", last.c_str());
 	return OCTPIPE_OK;
 }
+int octpipe_debug_rtc_set_options(const char* extraOptions) {
+	oct::mixedn_rtc_set_options(extraOptions);
+	return OCTPIPE_OK;
+}
 int octpipe_debug_rtc_compile(unsigned samplesPerLine, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, int* radices5, double* seconds) {
 	oct::mxs::PlanDesc d{};
 	if (!arch) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");

@@ -44,7 +44,11 @@ def main():
     ap.add_argument("--ascans", type=int, default=512)
     ap.add_argument("--bscans", type=int, default=256)
     ap.add_argument("--route", type=int, default=0, help="OCTPIPE_ROUTE_* flags (include/octpipe_debug.h), e.g. 128 = keep the library route where a generic mixed-radix plan exists")
+    ap.add_argument("--rtc-opts", default="", help="extra compiler options for the run-time compiled kernels (octpipe_debug_rtc_set_options), e.g. '-DOCT_MXS_PREFETCH=0'")
     args = ap.parse_args()
+    if args.rtc_opts:
+        from octproz_amd import _lib
+        _lib.lib().octpipe_debug_rtc_set_options(args.rtc_opts.encode())
     N, A, B = args.samples, args.ascans, args.bscans
     vols = [synthetic_raw_torch(N, A, B, "cuda:0", seed=i) for i in range(4)]
     out = []
@@ -67,7 +71,7 @@ def main():
         dt = (time.perf_counter() - t) / 100
         out.append({"settings": name, "ms_per_buffer": dt * 1e3, "ascans_per_s": A * B / dt})
         pipe.close()
-    print(json.dumps({"workload": "%dx%dx%d" % (N, A, B), "route_flags": args.route, "variants": out}))
+    print(json.dumps({"workload": "%dx%dx%d" % (N, A, B), "route_flags": args.route, "rtc_opts": args.rtc_opts, "variants": out}))
 
 
 if __name__ == "__main__":

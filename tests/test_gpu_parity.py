@@ -360,8 +360,8 @@ MIXEDN_CASES = {
 }
 
 
-MIXEDN_LENGTHS = [1000, 1200, 1536, 2000, 2304, 130, 182, 2002, 1260, 64]
-MIXEDN_STATIC_ONLY = [2500, 3000, 3072, 3600, 4000, 5000, 5120, 24, 4050]  # (4050 = 2 x 3^4 x 5^2: 15 x 15 x 9 has no radix 9 -> 15 x 15 x 6 x 3)
+MIXEDN_LENGTHS = [1000, 1200, 1536, 2000, 2304, 130, 182, 2002, 1260, 64, 48]
+MIXEDN_STATIC_ONLY = [2500, 3000, 3072, 3600, 4000, 5000, 5120, 4050]  # (4050 = 2 x 3^4 x 5^2: 15 x 15 x 9 has no radix 9 -> 15 x 15 x 6 x 3)
 
 
 @pytest.mark.parametrize("plan", ["static", "runtime"])
