@@ -27,8 +27,11 @@ template <int N_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 = 1> struct
 	static_assert(N_ % 2 == 0, "N / 2 bins");
 };
 
+#ifndef OCT_MXS_LUT_AHEAD
+#define OCT_MXS_LUT_AHEAD 8  // table entries in flight per lane in the first pass (16 B each; cubic weights: 32 B)
+#endif
 #ifndef OCT_MXS_PREFETCH
-#define OCT_MXS_PREFETCH 1
+#define OCT_MXS_PREFETCH 0
 #endif
 template <int INTYPE> struct RawWord { typedef uint32_t T; };  // two uint16 samples
 template <> struct RawWord<IN_F32> { typedef u32x2 T; };      // two float32 samples
@@ -59,46 +62,51 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
 	f2 x[ITS][R];
 	// ---- inputs (all of them before the first output is written: the exchange is in place)
+	// (the last iteration of a pass whose NB is no multiple of 64: the idle lanes run butterfly NB - 1 again and keep its outputs to
+	// themselves.  Everything but the stores outside divergent control flow -- with the loads and the arithmetic inside an
+	// `if (b < NB)` the compiler spilled 200-300 registers per lane at N = 3000 / 4000)
+	int bIn[ITS];
 #pragma unroll
-	for (int it = 0; it < ITS; it++) {
-		// (the last iteration of a pass whose NB is no multiple of 64: the idle lanes run butterfly NB - 1 again and keep its outputs to
-		// themselves.  Everything but the stores outside divergent control flow -- with the loads and the arithmetic inside an
-		// `if (b < NB)` the compiler spilled 200-300 registers per lane at N = 3000 / 4000)
-		const int b = ((it + 1) * 64 <= NB || lane + 64 * it < NB) ? lane + 64 * it : NB - 1;
-		{
-			if constexpr (FIRST) {
-				// k-linearisation x window x dispersion phasor (cu:213-295, cu:341-489): sample b + t NB, the LUT entry through L1 / L2
-				// (in chunks of at most five samples: the 16-byte entries of a whole radix-20 butterfly would hold 80 registers)
-				constexpr int CH = R % 5 == 0 ? 5 : R % 4 == 0 ? 4 : R % 3 == 0 ? 3 : R <= 7 ? R : 1;
+	for (int it = 0; it < ITS; it++) bIn[it] = ((it + 1) * 64 <= NB || lane + 64 * it < NB) ? lane + 64 * it : NB - 1;
+	if constexpr (FIRST) {
+		// k-linearisation x window x dispersion phasor (cu:213-295, cu:341-489): sample b + t NB, its table entry through L1 / L2.  The
+		// lane's ITS x R samples as one software pipeline: the entry of sample s + AHEAD is requested before sample s is
+		// interpolated (a ring of AHEAD entries in registers; chunks that were loaded, awaited and consumed one after the other
+		// paid the L2 latency once per chunk)
+		constexpr int S = ITS * R, AHEAD = S < OCT_MXS_LUT_AHEAD ? S : OCT_MXS_LUT_AHEAD;
+		f32x4 L[AHEAD];
+		auto request = [&](int sIdx) { L[sIdx % AHEAD] = buf_load128(lutR, bIn[sIdx / R] * 16, (sIdx % R) * NB * 16); };
 #pragma unroll
-				for (int t0 = 0; t0 < R; t0 += CH) {
-					f32x4 L[CH];
+		for (int sIdx = 0; sIdx < AHEAD; sIdx++) request(sIdx);
 #pragma unroll
-					for (int c = 0; c < CH; c++) L[c] = buf_load128(lutR, b * 16, (t0 + c) * NB * 16);
-#pragma unroll
-					for (int c = 0; c < CH; c++) {
-						const int t = t0 + c;
-						float y;
-						if constexpr (RS == RS_CUBIC) {
-							const float* tp = row + ROW_OFF + (int)L[c].x - 1;  // tap 0 = sample n1 - 1 (the mirror tap of n1 = 0 sits at row[ROW_OFF - 1])
-							y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], __builtin_amdgcn_fractf(L[c].x));
-						} else if constexpr (RS == RS_LINEAR) {
-							const float* tp = row + ROW_OFF + (int)L[c].x;
-							y = tp[0] + (tp[1] - tp[0]) * __builtin_amdgcn_fractf(L[c].x);
-						} else {
-							y = row[ROW_OFF + b + t * NB];
-						}
-						const float yw = y * L[c].y;
-						x[it][t] = f2{yw * L[c].z, yw * L[c].w};
-					}
+		for (int sIdx = 0; sIdx < S; sIdx++) {
+			const int it = sIdx / R, t = sIdx % R;
+			const f32x4 e = L[sIdx % AHEAD];
+			{
+				float y;
+				if constexpr (RS == RS_CUBIC) {
+					const float* tp = row + ROW_OFF + (int)e.x - 1;  // tap 0 = sample n1 - 1 (the mirror tap of n1 = 0 sits at row[ROW_OFF - 1])
+					y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], __builtin_amdgcn_fractf(e.x));
+				} else if constexpr (RS == RS_LINEAR) {
+					const float* tp = row + ROW_OFF + (int)e.x;
+					y = tp[0] + (tp[1] - tp[0]) * __builtin_amdgcn_fractf(e.x);
+				} else {
+					y = row[ROW_OFF + bIn[it] + t * NB];
 				}
-			} else {
-				// element b + t NB at (b + b / R_0) + t (NB + NB / R_0)
-				const f2* src = xb + (PADP ? b + b / PADP : b);
-				constexpr int TS = PADP ? NB + NB / PADP : NB;
-#pragma unroll
-				for (int t = 0; t < R; t++) x[it][t] = src[t * TS];
+				const float yw = y * e.y;
+				x[it][t] = f2{yw * e.z, yw * e.w};
 			}
+			if (sIdx + AHEAD < S) request(sIdx + AHEAD);
+		}
+	} else {
+#pragma unroll
+		for (int it = 0; it < ITS; it++) {
+			// element b + t NB at (b + b / R_0) + t (NB + NB / R_0)
+			const int b = bIn[it];
+			const f2* src = xb + (PADP ? b + b / PADP : b);
+			constexpr int TS = PADP ? NB + NB / PADP : NB;
+#pragma unroll
+			for (int t = 0; t < R; t++) x[it][t] = src[t * TS];
 		}
 	}
 	afterInputs();
@@ -188,8 +196,10 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16);
 	constexpr int IN_BYTES = INTYPE == IN_U16 ? 2 : 4;
 
-	// the raw row of a wave's NEXT A-scan is requested while the current one is transformed (OCT_MXS_PREFETCH; HBM latency off the
-	// critical path: N = 1000 cubic 340 -> ... M A-scans/s) and held in N / 128 (uint16) or N / 64 (float32) registers
+	// OCT_MXS_PREFETCH = 1: the raw row of a wave's NEXT A-scan is requested while the current one is transformed and held in N / 128
+	// (uint16) or N / 64 (float32) registers.  Measured (profiles/r4x_static_plan_tuning.txt): no gain -- the other waves of the
+	// SIMD cover the latency already -- and a loss where registers are short (N = 2000 cubic 170 -> 143 M A-scans/s, no resampling
+	// 201 -> 135 M): off
 	constexpr int LOADS = (HALF + 63) / 64;
 	typedef typename RawWord<INTYPE>::T RawT;
 	RawT w[LOADS];

@@ -26,7 +26,7 @@ constexpr int pd_slice_bytes(const PlanDesc& d) {
 }
 constexpr int pd_tw_bytes(const PlanDesc& d) { return (pd_twelems(d) * 8 + 15) & ~15; }
 // waves (= A-scans in flight) per workgroup, one workgroup per CU: as many as the LDS holds, capped by the register budget that
-// goes with them (16 waves = 128 registers, 12 = 168, 8 = 256, 4 = 512).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_ab.txt):
+// goes with them (16 waves = 128 registers, 12 = 168, 8 = 256, 4 = 512).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_waves_ab.jsonl):
 // cubic 16 waves 298 M A-scans/s (51 registers spilled), 12 waves 340 M, 8 waves 315 M; linear / none 464 / 420 / 362 M.
 constexpr int pd_waves(const PlanDesc& d, bool bg, int rs) {
 	const int room = 160 * 1024 - pd_tw_bytes(d) - (bg ? d.N * 2 : 0);

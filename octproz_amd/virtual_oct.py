@@ -36,7 +36,7 @@ def synthetic_raw(samples_per_line, ascans_per_bscan, bscans, seed=7, msb_aligne
         e = min(lines, s + chunk_lines)
         m = e - s
         acc = np.broadcast_to(base, (m, N)).copy()
-        z = rng.uniform(20.0, 0.4 * N, size=(m, 3)).astype(np.float32)
+        z = rng.uniform(20.0 if N > 50 else 0.1 * N, 0.4 * N, size=(m, 3)).astype(np.float32)  # (short test lengths: reflectors inside the image all the same)
         amp = rng.uniform(100.0, 500.0, size=(m, 3)).astype(np.float32)
         for r in range(3):
             acc += amp[:, r:r + 1] * np.cos((2 * np.pi) * z[:, r:r + 1] * k[None, :])
@@ -62,7 +62,7 @@ def synthetic_raw_torch(samples_per_line, ascans_per_bscan, bscans, device, seed
     for s in range(0, lines, step):
         m = min(lines, s + step) - s
         acc = base.expand(m, N).clone()
-        z = torch.empty((m, 3), device=device).uniform_(20.0, 0.4 * N, generator=g)
+        z = torch.empty((m, 3), device=device).uniform_(20.0 if N > 50 else 0.1 * N, 0.4 * N, generator=g)
         amp = torch.empty((m, 3), device=device).uniform_(100.0, 500.0, generator=g)
         for r in range(3):
             acc += amp[:, r:r + 1] * torch.cos((2 * torch.pi) * z[:, r:r + 1] * k[None, :])

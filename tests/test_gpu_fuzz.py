@@ -105,11 +105,23 @@ def test_random_setting_combination_matches_oracle(seed):
     _check_draw(*draw(seed))
 
 
-def _check_draw(p, raw, what):
+RTC_LENGTHS = [1000, 1200, 1536, 2000, 3000, 130, 48, 2500]  # no dedicated kernel: compiled at run time (mixedn_static.h), or the run-time plan
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SEEDS", "96")) // 2))
+def test_random_setting_combination_on_lengths_without_a_dedicated_kernel(seed):
+    """the kernel compiled for the length at run time (even seeds) and the run-time-plan kernel behind it (odd seeds, up to 2304);
+    Lanczos draws take the library route on these lengths"""
+    p, raw, what = draw(seed, RTC_LENGTHS, 9000)
+    from octproz_amd import _lib
+    _check_draw(p, raw, what, route=_lib.ROUTE_NO_MIXEDN_STATIC if seed % 2 else 0)
+
+
+def _check_draw(p, raw, what, route=0):
     import torch
     o = common.make_oracle(p)
     want = o.process(raw)
-    pipe = Pipeline(p, device=0)
+    pipe = Pipeline(p, device=0, route=route)
     if p.fixedPatternNoiseRemoval:
         pipe.set_mean_line(o.mean_line(), pin=True)
     d = torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).to("cuda:0")
@@ -127,7 +139,7 @@ def _check_draw(p, raw, what):
         p0.postProcessBackgroundRemoval = 0
         o0 = common.make_oracle(p0)
         want0 = o0.process(raw)
-        pipe0 = Pipeline(p0, device=0)
+        pipe0 = Pipeline(p0, device=0, route=route)
         if p0.fixedPatternNoiseRemoval:
             pipe0.set_mean_line(o0.mean_line(), pin=True)
         pipe0.process_device(d.data_ptr()); pipe0.synchronize()
