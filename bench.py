@@ -491,6 +491,14 @@ def main():
         kernel_name = {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_fused_kernel<10, 1, 2, 4>",
                        2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_team_kernel<12, 1, 2, 4>", 8192: "oct_team_kernel<13, 1, 2, 4>",
                        1664: "oct_team1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)")
+        single_kernel = N in (256, 512, 1024, 2048, 4096, 8192, 1664)
+        if not single_kernel:  # lengths without a dedicated kernel: which route the handle took (include/octpipe_debug.h OCTPIPE_PATH_*)
+            from octproz_amd import _lib as _l
+            path = pipe.last_path()
+            if path & _l.PATH_STATIC_PLAN:
+                kernel_name, single_kernel = "oct_mxs", True  # compiled for this length at run time (csrc/mixedn_static.h, extern "C" name); plan in config
+            elif path & _l.PATH_MIXED_RADIX:
+                kernel_name, single_kernel = "oct_mixedn_kernel", True  # the run-time-plan kernel (csrc/mixedn_kernel.h)
         # second axis (SURVEY 8(d) "ridge warning"): the path sits at ~20 flop/B = the machine balance, so the record carries the
         # FP32 rate too.  Convention: 5 N log2 N for the transform + ~30 N for unpack, 4-tap cubic, window x phasor, |z|^2, log
         flops_fft, flops_other = 5.0 * N * math.log2(N), 30.0 * N
@@ -523,6 +531,10 @@ def main():
                                               "no skeleton study for this length"},
             "preflight": pre_all,
         }
+        if kernel_name == "oct_mxs":
+            st = pipe.rtc_status()
+            out["config"]["run_time_compiled_plan"] = " x ".join(map(str, st["radices"]))
+            out["roofline"]["run_time_compile_seconds"] = st["compile_seconds"]
     pipe.close()
     if rank == 0:
         # HBM traffic of the dominant kernel: measured now (child passes under rocprofv3 --pmc), or null with the reason
@@ -530,7 +542,7 @@ def main():
             out["roofline"]["traffic_source"] = "measured in the N = 1 run only"
         elif args.no_traffic:
             out["roofline"]["traffic_source"] = "skipped (--no-traffic)"
-        elif N not in (256, 512, 1024, 2048, 4096, 8192, 1664):
+        elif not single_kernel:
             out["roofline"]["traffic_source"] = "library route: several kernels, no single dominant one"
         else:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measure_traffic(args, kernel_name)
