@@ -33,6 +33,10 @@ template <int N_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 = 1> struct
 #ifndef OCT_MXS_PREFETCH
 #define OCT_MXS_PREFETCH 0
 #endif
+// MODE_ROLL: load m holds samples 128 m .. 128 m + 127; it can contain a clipped window (for some W <= ROLL_PAD) if it lies within
+// ROLL_PAD samples of either end of the row.  roll_edge_index(N, m) = how many such loads precede load m (m = LOADS: their number)
+constexpr bool roll_edge_load(int N, int m) { return 128 * m < ROLL_PAD - 1 || 128 * m + 127 > N - 1 - ROLL_PAD; }
+constexpr int roll_edge_index(int N, int m) { int e = 0; for (int i = 0; i < m; i++) e += roll_edge_load(N, i) ? 1 : 0; return e; }
 template <int INTYPE> struct RawWord { typedef uint32_t T; };  // two uint16 samples
 template <> struct RawWord<IN_F32> { typedef u32x2 T; };      // two float32 samples
 
@@ -173,13 +177,14 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, HALF = N / 2, LP = D.passes - 1, RL = D.radix[LP], NBL = N / RL;
 	constexpr int MEANN = pd_its(D, LP) * ((RL + 1) / 2);
-	constexpr bool BG = (MODE & MODE_BG) != 0;
+	constexpr bool BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0;
+	static_assert(!ROLL || INTYPE == IN_U16, "the rolling average inside the kernel works on the raw integers");
 	f2* twL = reinterpret_cast<f2*>(smem);
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D);
+	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D, ROLL);
 	float* row = reinterpret_cast<float*>(slice);
 	f2* xb = reinterpret_cast<f2*>(slice);
-	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + W * pd_slice_bytes(D));
+	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + W * pd_slice_bytes(D, ROLL));
 	if constexpr (BG) fill_bg_term(termL, a.bgTerm, HALF, tid, W * 64);
 	for (int i = tid; i < pd_twelems(D); i += W * 64) twL[i] = a.twiddle[i];
 	// the lane's share of the mean A-line (cu:492-520) for the whole persistent loop: bins b + u NB of the last pass
@@ -211,6 +216,29 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 			else w[m] = buf_load64(rawR, lane * 8, m * 512);
 		}
 	};
+	// Rolling-average DC removal inside the kernel (MODE_ROLL; cu:165-211: mean over [j - W + 1, j + W] clipped to the A-scan), the scheme
+	// of the general kernel (kernels.h): integer window sums from one uint32 prefix-sum array per A-scan, built from the raw
+	// integers with a wave scan, padded by ROLL_PAD entries on both sides (0 in front, the total behind) so that the clipped
+	// window is P[j + W] - P[j - W] without a clamp; the exact IEEE quotient by two FMAs.  The host sends only windows
+	// W <= ROLL_PAD whose sums are exact in float32 (launch.h roll_in_kernel_ok).  The element counts of the clipped windows
+	// differ from 2 W only within ROLL_PAD samples of the row's ends: those loads (128 samples each) carry their counts and
+	// reciprocals in registers for the whole loop, the others use constants.
+	constexpr int EDGE_LOADS = ROLL ? roll_edge_index(N, LOADS) : 0;
+	float cntE[EDGE_LOADS > 0 ? EDGE_LOADS : 1][2], rcE[EDGE_LOADS > 0 ? EDGE_LOADS : 1][2];
+	if constexpr (ROLL) {
+#pragma unroll
+		for (int m = 0; m < LOADS; m++)
+			if (roll_edge_load(N, m)) {
+#pragma unroll
+				for (int c = 0; c < 2; c++) {
+					const int j = 2 * (lane + 64 * m) + c;
+					const int lo = max(0, j - a.rollingW + 1), hi = min(N - 1, j + a.rollingW);
+					const float cnt = (float)max(hi - lo + 1, 1);
+					cntE[roll_edge_index(N, m)][c] = cnt;
+					rcE[roll_edge_index(N, m)][c] = __fdiv_rn(1.0f, cnt);
+				}
+			}
+	}
 	const unsigned first = blockIdx.x * W + wave, stride = gridDim.x * W;
 	if (OCT_MXS_PREFETCH && first < a.numLines) fetch(first);
 
@@ -218,13 +246,52 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141): 8 bytes of LDS per lane and instruction (the descriptor ends with the
 		// row: lanes beyond it read zeros and write nothing)
 		if (!OCT_MXS_PREFETCH) fetch(line);
+		if constexpr (ROLL) {
+			uint32_t* pfx = reinterpret_cast<uint32_t*>(slice + pd_row_bytes(D));  // [ROLL_PAD | N | ROLL_PAD]
+			const int Wr = a.rollingW;
+			uint32_t base = 0;
 #pragma unroll
-		for (int m = 0; m < LOADS; m++) {
-			f2 v;
-			if constexpr (INTYPE == IN_U16) v = f2{(float)((w[m] & 0xffffu) >> shift), (float)((w[m] >> 16) >> shift)};
-			else v = __builtin_bit_cast(f2, w[m]);
-			if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = v;
-			if (RS == RS_CUBIC && m == 0 && lane == 0) row[ROW_OFF - 1] = v.y;  // n0 = |n1 - 1| mirror tap (cu:284): sample 1
+			for (int m = 0; m < LOADS; m++) {
+				const uint32_t wv = __builtin_bit_cast(uint32_t, w[m]);
+				const uint32_t x0 = (wv & 0xffffu) >> shift, x1 = (wv >> 16) >> shift, tot = x0 + x1;  // (beyond the row: zeros -- the running total lands in the back pad)
+				const uint32_t incl = wave_inclusive_scan(tot);
+				const uint32_t p0 = base + incl - tot + x0;
+				*reinterpret_cast<u32x2*>(&pfx[ROLL_PAD + 2 * (lane + 64 * m)]) = u32x2{p0, p0 + x1};
+				base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			}
+			static_assert(ROLL_PAD == 256, "pad writes: four entries per lane");
+			*reinterpret_cast<u32x4*>(&pfx[4 * lane]) = u32x4{0u, 0u, 0u, 0u};
+			*reinterpret_cast<u32x2*>(&pfx[ROLL_PAD + N + 4 * lane]) = u32x2{base, base};
+			*reinterpret_cast<u32x2*>(&pfx[ROLL_PAD + N + 4 * lane + 2]) = u32x2{base, base};
+			wave_sync_lds();
+			const uint32_t* hiP = pfx + ROLL_PAD + 2 * lane + Wr;  // P[j + W]
+			const uint32_t* loP = pfx + ROLL_PAD + 2 * lane - Wr;  // P[j - W]
+			const float cntIn = (float)(2 * Wr), rcIn = __fdiv_rn(1.0f, cntIn);
+#pragma unroll
+			for (int m = 0; m < LOADS; m++) {
+				const uint32_t wv = __builtin_bit_cast(uint32_t, w[m]);
+				const uint32_t xs[2] = {(wv & 0xffffu) >> shift, (wv >> 16) >> shift};
+				float o[2];
+#pragma unroll
+				for (int c = 0; c < 2; c++) {
+					const float sum = (float)(hiP[128 * m + c] - loP[128 * m + c]);
+					float cnt = cntIn, rc = rcIn;
+					if (roll_edge_load(N, m)) { cnt = cntE[roll_edge_index(N, m)][c]; rc = rcE[roll_edge_index(N, m)][c]; }
+					const float q0 = sum * rc;
+					o[c] = (float)xs[c] - __builtin_fmaf(__builtin_fmaf(-q0, cnt, sum), rc, q0);  // RN(sum / cnt) for integer sums < 2^24, cnt <= 512
+				}
+				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = f2{o[0], o[1]};
+				if (RS == RS_CUBIC && m == 0 && lane == 0) row[ROW_OFF - 1] = o[1];  // n0 = |n1 - 1| mirror tap (cu:284): sample 1
+			}
+		} else {
+#pragma unroll
+			for (int m = 0; m < LOADS; m++) {
+				f2 v;
+				if constexpr (INTYPE == IN_U16) v = f2{(float)((w[m] & 0xffffu) >> shift), (float)((w[m] >> 16) >> shift)};
+				else v = __builtin_bit_cast(f2, w[m]);
+				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = v;
+				if (RS == RS_CUBIC && m == 0 && lane == 0) row[ROW_OFF - 1] = v.y;  // n0 = |n1 - 1| mirror tap (cu:284): sample 1
+			}
 		}
 		wave_sync_lds();
 		unsigned orow = line;

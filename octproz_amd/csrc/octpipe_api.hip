@@ -587,7 +587,8 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	// (mixedStatic: the kernel compiled for this length at run time, mixedn_static.h -- also for lengths beyond the run-time plan's 2304)
 	const bool mxnStatic = h->mixedStatic && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN_STATIC);
 	const bool mxn = (h->mixedN || mxnStatic) && rs != oct::RS_LANCZOS && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN);
-	const bool mxnDirect = mxn && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !roll;
+	// (the kernel compiled for the length also runs the rolling average itself, under the rule of the general kernel: W <= ROLL_PAD, exact sums)
+	const bool mxnDirect = mxn && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && (!roll || (rollInKernel && mxnStatic));
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect && !mxnDirect) {
 		int rc = ensure(h, (void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
@@ -653,7 +654,8 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		a.twiddle = h->d_twMixedStatic;
 		path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_STATIC_PLAN;
 		std::string why;
-		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream, &why);
+		if (roll) path |= OCTPIPE_PATH_ROLL_IN_KERNEL;
+		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, h->stream, &why, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0);
 		if (e == hipErrorNotSupported) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);
 		HIP_TRY(e);
 	} else if (mxn) {
@@ -1158,7 +1160,7 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 		std::string why;
 		const bool plain16 = h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO;
 		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, plain16 ? oct::IN_U16 : oct::IN_F32, h->params.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC : oct::RS_LINEAR,
-		                                            false, true, probe, h->stream, &why);
+		                                            false, false, true, probe, h->stream, &why);
 		if (e == hipSuccess) {
 			std::vector<f2> tw;
 			oct::mixedn_static_twiddles(h->mxsPlan, tw);

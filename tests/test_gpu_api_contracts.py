@@ -219,7 +219,9 @@ _ROUTING = [
     (1664, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, _P.ROUTE_NO_TEAM, _P.PATH_MIXED_RADIX | _P.PATH_PREPARED_ROWS),
     (1664, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX),
     (1000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                               # the kernel compiled for the length at run time (10 x 10 x 10), raw uint16 rows
-    (1000, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),
+    (1000, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_ROLL_IN_KERNEL),
+    (1000, {"backgroundRemoval": 1, "rollingAverageWindowSize": 300}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),  # beyond the prefix-sum range
+    (1000, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_MIXED_RADIX | _P.PATH_PREPARED_ROWS),
     (1000, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_FUSED_BG),
     (1000, {"bitDepth": 8}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),
     (1000, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),  # Lanczos stays on the library route

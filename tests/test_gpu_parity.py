@@ -129,7 +129,9 @@ def test_rolling_average_wide_windows(N, W, bits):
 
 
 @pytest.mark.parametrize("N,W", [(1024, 8), (1024, 100), (1024, 128), (1024, 200), (256, 32), (2048, 64),
-                                 (4096, 64), (4096, 128), (8192, 100), (1664, 128), (1664, 7)])
+                                 (4096, 64), (4096, 128), (8192, 100), (1664, 128), (1664, 7),
+                                 # lengths on the kernel compiled at run time (mixedn_static.h MODE_ROLL): windows wider than the row, odd widths, one load
+                                 (1000, 8), (1000, 128), (1000, 200), (1200, 101), (1536, 64), (2000, 7), (3000, 128), (130, 32), (130, 100), (48, 5), (5000, 33)])
 def test_rolling_average_prefix_sum_route_is_bit_identical_to_the_ordered_float_sum(N, W):
     """(N = 4096, 8192, 1664: the prefix sums are carried across the waves of a team, team_roll_stage; the prepared rows of the
     second run go through the same team kernel.)
@@ -353,7 +355,8 @@ MIXEDN_CASES = {
     "nothing": mutate(windowing=0, dispersionCompensation=0, resampling=0),
     "no_dispersion": mutate(dispersionCompensation=0),
     "lin_scale_flip": mutate(signalLogScaling=0, signalGrayscaleMax=900.0, signalGrayscaleMin=0.0, bscanFlip=1),
-    "rolling8": mutate(backgroundRemoval=1, rollingAverageWindowSize=8),        # prepared float32 rows in front of the kernel
+    "rolling8": mutate(backgroundRemoval=1, rollingAverageWindowSize=8),        # static plan: inside the kernel; run-time plan: prepared float32 rows in front of it
+    "rolling256_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=256, resamplingInterpolation=INTERPOLATION.LINEAR),
     "bitshift": mutate(bitshift=1, bitDepth=16),
     "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
                         signalGrayscaleMax=110.0, signalGrayscaleMin=20.0),       # background removal inside the store
@@ -361,7 +364,7 @@ MIXEDN_CASES = {
 
 
 MIXEDN_LENGTHS = [1000, 1200, 1536, 2000, 2304, 130, 182, 2002, 1260, 64, 48]
-MIXEDN_STATIC_ONLY = [2500, 3000, 3072, 3600, 4000, 5000, 5120, 4050]  # (4050 = 2 x 3^4 x 5^2: 15 x 15 x 9 has no radix 9 -> 15 x 15 x 6 x 3)
+MIXEDN_STATIC_ONLY = [2500, 3000, 4050, 5120]  # (4050 = 2 x 3^4 x 5^2: 15 x 15 x 9 has no radix 9 -> 15 x 15 x 6 x 3)
 
 
 @pytest.mark.parametrize("plan", ["static", "runtime"])
@@ -374,7 +377,7 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
     mixedn_kernel.h: one A-scan per workgroup, Stockham passes over a run-time plan of radices 16, 13, 11, 8, 7, 5, 4, 3, 2 (1000 = 8 x 5^3,
     2304 = 16 x 16 x 3 x 3, 2002 = 2 x 7 x 11 x 13, 1260 = 4 x 3 x 3 x 5 x 7, 182 = 2 x 7 x 13 ...; up to 2304, longer ones keep the library route), the whole chain on chip.  Against the oracle (image and
     spectrum) and against the library route (gather -> hipFFT -> epilogue), which is really different code."""
-    if N > 1600 and case not in ("v180", "nothing", "lin_scale_flip", "no_fpn_bg"):
+    if N > 1600 and case not in ("v180", "lin_scale_flip", "no_fpn_bg", "rolling256_linear"):
         pytest.skip("long lengths on four cases (the oracle's DFT is O(N^2))")
     if plan == "runtime" and N in MIXEDN_STATIC_ONLY:
         pytest.skip("the run-time plan stops at 2304")
@@ -389,7 +392,9 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
     o, pipe, d, want, got = run_both(p, raw, route=0 if plan == "static" else _lib.ROUTE_NO_MIXEDN_STATIC)
     assert pipe.last_path() & _lib.PATH_MIXED_RADIX and not pipe.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN), hex(pipe.last_path())
     assert bool(pipe.last_path() & _lib.PATH_STATIC_PLAN) == (plan == "static"), (hex(pipe.last_path()), pipe.rtc_status())
-    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (case == "rolling8")
+    rolling = case.startswith("rolling")
+    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (rolling and plan == "runtime")
+    assert bool(pipe.last_path() & _lib.PATH_ROLL_IN_KERNEL) == (rolling and plan == "static")
     p.postProcessBackgroundUpdated = True
     lib = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN)
     if p.fixedPatternNoiseRemoval:
@@ -414,16 +419,20 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
 
 
 @pytest.mark.parametrize("plan", ["static", "runtime"])
-@pytest.mark.parametrize("N,A,B", [(130, 900, 3), (130, 1500, 4), (1000, 700, 4), (1000, 900, 4), (1000, 7, 3), (1000, 1, 1), (2000, 1, 1), (3000, 1300, 1), (3000, 3, 1)])
+@pytest.mark.parametrize("N,A,B", [(130, 900, 3), (1000, 700, 4), (1000, 7, 3), (1000, 1, 1), (2000, 1, 1), (3000, 3, 1), (130, 50, 2), (1000, 45, 1), (3000, 23, 1)])
 @pytest.mark.parametrize("container", ["uint16", "uint8", "uint32"])
 def test_generic_mixed_radix_kernel_line_counts_and_containers(N, A, B, container, plan):
-    """more A-scans than persistent workgroups / waves (every one loops: 256 CUs x 16 waves at N = 130, x 12 at N = 1000, x 5 at N = 3000), ragged and single-line buffers; 8-bit and 32-bit containers
+    """more A-scans than persistent workgroups / waves (every one loops: the run-time plan's kernel on (130, 900, 3) and (1000, 700, 4); the
+    run-time compiled kernel -- 256 CUs x 16 / 12 / 4 waves -- on the last three buffers with OCTPIPE_ROUTE_TINY_GRID, two workgroups), ragged and single-line buffers; 8-bit and 32-bit containers
     (cu:109-147) arrive as prepared float32 rows; the mean line is determined by the kernel's own spectrum output (cu:1518-1525)"""
     bits = {"uint16": 12, "uint8": 8, "uint32": 24}[container]
-    if container != "uint16" and A * B > 100:
+    tiny = (N, A, B) in ((130, 50, 2), (1000, 45, 1), (3000, 23, 1))
+    if container != "uint16" and (A * B > 100 or tiny):
         pytest.skip("containers on the small buffers")
-    if plan == "runtime" and N > 2304:
-        pytest.skip("the run-time plan stops at 2304")
+    if plan == "runtime" and (N > 2304 or tiny):
+        pytest.skip("the run-time plan stops at 2304 / the two-workgroup launch is the run-time compiled kernel's")
+    if plan == "static" and A * B > 1000:
+        pytest.skip("the run-time compiled kernel loops in the two-workgroup cases")
     p = v180_benchmark_params(N, A, B)
     p.bitDepth = bits
     p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
@@ -435,7 +444,8 @@ def test_generic_mixed_radix_kernel_line_counts_and_containers(N, A, B, containe
         raw = (raw >> 4).astype(np.uint8)
     elif container == "uint32":
         raw = raw.astype(np.uint32) * 4096
-    o, pipe, d, want, got = run_both(p, raw, pin=False, route=0 if plan == "static" else _lib.ROUTE_NO_MIXEDN_STATIC)  # unpinned: the GPU determines the mean line from its own spectra
+    route = (_lib.ROUTE_TINY_GRID if tiny else 0) if plan == "static" else _lib.ROUTE_NO_MIXEDN_STATIC
+    o, pipe, d, want, got = run_both(p, raw, pin=False, route=route)  # unpinned: the GPU determines the mean line from its own spectra
     assert pipe.last_path() & _lib.PATH_MIXED_RADIX
     assert bool(pipe.last_path() & _lib.PATH_STATIC_PLAN) == (plan == "static"), (hex(pipe.last_path()), pipe.rtc_status())
     assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (container != "uint16")

@@ -60,6 +60,15 @@ def test_every_instance_of_one_length_compiles(intype, rs, mode):
     assert rc == 0, err
 
 
+@needs_hiprtc
+@pytest.mark.parametrize("n", [48, 130, 1000, 1536, 3000, 5000])
+@pytest.mark.parametrize("rs", [RS_NONE, RS_CUBIC])
+def test_rolling_average_instances_compile(n, rs):
+    """MODE_ROLL = 1: the rolling average inside the kernel (raw uint16 rows; a prefix-sum array behind the staged row)"""
+    rc, radices, waves, code, sec, err = _compile(n, IN_U16, rs, MODE_LOG | 1)
+    assert rc == 0 and waves >= 2, err
+
+
 @pytest.mark.parametrize("n", [1234, 4094, 1001, 6000, 8190, 7])
 def test_lengths_without_a_static_plan_are_refused(n):
     """2 x 617, 2 x 23 x 89: a prime factor above 13; odd lengths (N / 2 bins); beyond 5120 / the registers of one wave"""
