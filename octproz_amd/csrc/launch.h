@@ -123,7 +123,7 @@ bool mixedn_plan(unsigned n, int* passes, int* radix, bool simpleRadicesOnly = f
 bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* d);
 bool mixedn_rtc_available(std::string* why);
 void mixedn_static_twiddles(const mxs::PlanDesc& d, std::vector<f2>& tw);
-hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why, int maxBlocks = 0);
+hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why, int maxBlocks = 0);
 int mixedn_rtc_compiled_count(double* seconds, std::string* lastMessage);
 void mixedn_rtc_set_options(const char* extra);
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why);

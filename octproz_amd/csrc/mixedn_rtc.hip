@@ -93,8 +93,8 @@ Cache& cache() { static Cache c; return c; }
 // source -> code object for `arch` (no device needed); waves = the launch shape compiled in
 bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, const std::string& extra, std::vector<char>& code, int* waves, double* seconds, std::string* why) {
 	if (!bindRtc(why)) return false;
-	const bool bg = (mode & MODE_BG) != 0, roll = (mode & MODE_ROLL) != 0;
-	const int W = mxs::pd_waves(d, bg, rs, roll);
+	const bool bg = (mode & MODE_BG) != 0, roll = (mode & MODE_ROLL) != 0, pair = (mode & mxs::MODE_PAIR) != 0;
+	const int W = mxs::pd_waves(d, bg, rs, roll, pair);
 	*waves = W;
 	if (W < 1) { *why = "one A-scan of this length does not fit the LDS"; return false; }
 	char src[1024];
@@ -102,13 +102,13 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	              "#include \"mixedn_static.h\"\n"
 	              "using P = oct::mxs::Plan<%d, %d, %d, %d, %d, %d>;\n"
 	              "constexpr int W = %d;\n"
-	              "static_assert(W == oct::mxs::pd_waves(P::D, %s, %d, %s), \"host and kernel agree on the launch shape\");\n"
+	              "static_assert(W == oct::mxs::pd_waves(P::D, %s, %d, %s, %s), \"host and kernel agree on the launch shape\");\n"
 	              "extern \"C\" __global__ __launch_bounds__(W * 64, (W + 3) / 4) void oct_mxs(const oct::FusedArgs a) {\n"
 	              "\t__shared__ __attribute__((aligned(16))) char smem[%d];\n"
 	              "\toct::mxs::body<P, W, %d, %d, %d>(a, smem);\n"
 	              "}\n",
 	              d.N, d.radix[0], d.passes > 1 ? d.radix[1] : 1, d.passes > 2 ? d.radix[2] : 1, d.passes > 3 ? d.radix[3] : 1, d.passes > 4 ? d.radix[4] : 1, W,
-	              bg ? "true" : "false", rs, roll ? "true" : "false", mxs::pd_lds_bytes(d, W, bg, roll), intype, rs, mode);
+	              bg ? "true" : "false", rs, roll ? "true" : "false", pair ? "true" : "false", mxs::pd_lds_bytes(d, W, bg, roll, pair), intype, rs, mode);
 	const char* names[] = {"kernels.h", "fft_regs.h", "mixedn_kernel.h", "mixedn_static.h", "mixedn_static_plan.h"};
 	const char* texts[] = {oct_rtc_src_kernels_h, oct_rtc_src_fft_regs_h, oct_rtc_src_mixedn_kernel_h, oct_rtc_src_mixedn_static_h, oct_rtc_src_mixedn_static_plan_h};
 	Rtc& r = rtc();
@@ -197,7 +197,7 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out) {
 		for (int i = evenAt; i < d.passes - 1; ++i) d.radix[i] = d.radix[i + 1];
 		d.radix[d.passes - 1] = r;
 	}
-	if (mxs::pd_values(d) > mxs::MXS_MAXVALUES || mxs::pd_waves(d, true, RS_CUBIC, true) < 2) return false;
+	if (mxs::pd_values(d) > mxs::MXS_MAXVALUES || mxs::pd_waves(d, true, RS_CUBIC, true, false) < 2 || mxs::pd_waves(d, true, RS_CUBIC, false, true) < 2) return false;
 	*out = d;
 	return true;
 }
@@ -228,9 +228,11 @@ void mixedn_static_twiddles(const mxs::PlanDesc& d, std::vector<f2>& tw) {
 
 // compile (if need be) and launch; hipErrorNotSupported with *why set when this instance cannot be had (the caller keeps its other route)
 // roll: the rolling average inside the kernel (raw uint16 rows; windows the prefix-sum scheme covers, roll_in_kernel_ok)
+// pair: two A-scans per transform (no dispersion compensation: real FFT input; raw uint16 rows, image output, no rolling average)
 // maxBlocks > 0: at most that many persistent workgroups (tests: every wave loops over many A-scans of a small buffer)
-hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why, int maxBlocks) {
-	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (a.bgTerm ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0);
+hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why, int maxBlocks) {
+	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (a.bgTerm ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0);
+	if (pair && (intype != IN_U16 || roll || spectrum)) return hipErrorInvalidValue;
 	if ((intype != IN_U16 && intype != IN_F32) || (rs != RS_NONE && rs != RS_LINEAR && rs != RS_CUBIC)) return hipErrorInvalidValue;
 	if (roll && (intype != IN_U16 || !roll_in_kernel_ok(a))) return hipErrorInvalidValue;
 	int dev = 0;
@@ -252,7 +254,8 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 	}
 	if (in->failed) { if (why) *why = in->why; return hipErrorNotSupported; }
 	unsigned blocks = (unsigned)in->numCU;
-	const unsigned need = (a.numLines + (unsigned)in->waves - 1u) / (unsigned)in->waves;
+	const unsigned units = pair ? (a.numLines + 1u) / 2u : a.numLines;
+	const unsigned need = (units + (unsigned)in->waves - 1u) / (unsigned)in->waves;
 	if (blocks > need) blocks = need;
 	if (maxBlocks > 0 && blocks > (unsigned)maxBlocks) blocks = (unsigned)maxBlocks;
 	if (blocks == 0) return hipSuccess;

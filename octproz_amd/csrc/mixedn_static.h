@@ -28,11 +28,14 @@ template <int N_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 = 1> struct
 };
 
 #ifndef OCT_MXS_LUT_AHEAD
-#define OCT_MXS_LUT_AHEAD 8  // table entries in flight per lane in the first pass (16 B each; cubic weights: 32 B)
+#define OCT_MXS_LUT_AHEAD 8  // table entries in flight per lane in the first pass (16 B each)
 #endif
-#ifndef OCT_MXS_PREFETCH
-#define OCT_MXS_PREFETCH 0
-#endif
+// MODE bit of this kernel only (next to MODE_ROLL / MODE_SPECTRUM / MODE_LOG / MODE_BG of kernels.h): two A-scans per transform.
+// Without dispersion compensation the FFT input is real: a wave transforms the PAIR z = x1 + i x2 and separates the spectra
+// afterwards, X1[k] = (Z[k] + conj Z[N - k]) / 2, X2[k] = (Z[k] - conj Z[N - k]) / (2i) -- the scheme of real2n_kernel.h.  Both rows
+// are staged interleaved, (row0[n], row1[n]) as one 8-byte LDS element, so every tap read and every interpolation instruction
+// serves both A-scans; the last pass keeps all N outputs and one more exchange brings Z[N - k] to the lane that holds Z[k].
+// (MODE_PAIR = 16: mixedn_static_plan.h)
 // MODE_ROLL: load m holds samples 128 m .. 128 m + 127; it can contain a clipped window (for some W <= ROLL_PAD) if it lies within
 // ROLL_PAD samples of either end of the row.  roll_edge_index(N, m) = how many such loads precede load m (m = LOADS: their number)
 constexpr bool roll_edge_load(int N, int m) { return 128 * m < ROLL_PAD - 1 || 128 * m + 127 > N - 1 - ROLL_PAD; }
@@ -54,24 +57,31 @@ OCT_DEV void buf_store64(f2 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vbase + (c & 4095), c & ~4095, 0);
 }
 
-// pass p of the plan on the wave's slice (xb = exchange buffer, row = the staged row at the same address)
-// (afterInputs: called once the pass has issued all its reads -- the first pass gives the prefetch of the next raw row its place there,
-// behind the LUT loads: vector-memory loads return in order, a row requested earlier would stand in front of them)
-template <class P, int p, int RS, int MODE, int MEANN, class F>
-OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, __amdgpu_buffer_rsrc_t lutR, __amdgpu_buffer_rsrc_t outR,
-                  __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane, F&& afterInputs) {
+// where the last pass delivers: the output row (PAIR: both rows) or the spectrum row of the current A-scan, the grey-scale mapping
+struct Sink {
+	__amdgpu_buffer_rsrc_t out0, out1, spec;
+	float sA, sB;  // out = sA f(P) + sB (PAIR: for P' = 4 P, see body)
+};
+
+// pass p of the plan on the wave's slice (xb = exchange buffer, row = the staged row(s) at the same address)
+template <class P, int p, int RS, int MODE, int MEANN>
+OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, R = D.radix[p], NB = N / R, NS = pd_ns(D, p), ITS = pd_its(D, p), PADP = pd_padp(D);
 	constexpr bool FIRST = p == 0, LAST = p == D.passes - 1;
-	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0;
+	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, PAIR = (MODE & MODE_PAIR) != 0;
 	f2 x[ITS][R];
 	// ---- inputs (all of them before the first output is written: the exchange is in place)
 	// (the last iteration of a pass whose NB is no multiple of 64: the idle lanes run butterfly NB - 1 again and keep its outputs to
 	// themselves.  Everything but the stores outside divergent control flow -- with the loads and the arithmetic inside an
 	// `if (b < NB)` the compiler spilled 200-300 registers per lane at N = 3000 / 4000)
 	int bIn[ITS];
+	bool active[ITS];
 #pragma unroll
-	for (int it = 0; it < ITS; it++) bIn[it] = ((it + 1) * 64 <= NB || lane + 64 * it < NB) ? lane + 64 * it : NB - 1;
+	for (int it = 0; it < ITS; it++) {
+		active[it] = (it + 1) * 64 <= NB || lane + 64 * it < NB;
+		bIn[it] = active[it] ? lane + 64 * it : NB - 1;
+	}
 	if constexpr (FIRST) {
 		// k-linearisation x window x dispersion phasor (cu:213-295, cu:341-489): sample b + t NB, its table entry through L1 / L2.  The
 		// lane's ITS x R samples as one software pipeline: the entry of sample s + AHEAD is requested before sample s is
@@ -86,7 +96,21 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 		for (int sIdx = 0; sIdx < S; sIdx++) {
 			const int it = sIdx / R, t = sIdx % R;
 			const f32x4 e = L[sIdx % AHEAD];
-			{
+			if constexpr (PAIR) {
+				// both rows at once: every tap is the pair (row0[n], row1[n]); the windowed pair IS the complex sample (no phasor on this route)
+				const f2* rp = reinterpret_cast<const f2*>(row);
+				f2 y;
+				if constexpr (RS == RS_CUBIC) {
+					const f2* tp = rp + ROW_OFF + (int)e.x - 1;
+					y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], __builtin_amdgcn_fractf(e.x));
+				} else if constexpr (RS == RS_LINEAR) {
+					const f2* tp = rp + ROW_OFF + (int)e.x;
+					y = tp[0] + (tp[1] - tp[0]) * __builtin_amdgcn_fractf(e.x);
+				} else {
+					y = rp[ROW_OFF + bIn[it] + t * NB];
+				}
+				x[it][t] = y * e.y;
+			} else {
 				float y;
 				if constexpr (RS == RS_CUBIC) {
 					const float* tp = row + ROW_OFF + (int)e.x - 1;  // tap 0 = sample n1 - 1 (the mirror tap of n1 = 0 sits at row[ROW_OFF - 1])
@@ -113,63 +137,91 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, const FusedArgs& a, _
 			for (int t = 0; t < R; t++) x[it][t] = src[t * TS];
 		}
 	}
-	afterInputs();
 	wave_sync_lds();
-	// ---- twiddles, butterflies, outputs
+	// ---- twiddles, butterflies
 #pragma unroll
 	for (int it = 0; it < ITS; it++) {
-		const bool active = (it + 1) * 64 <= NB || lane + 64 * it < NB;
-		const int b = active ? lane + 64 * it : NB - 1;
-		{
-			const int q = b / NS, k = b - q * NS;
-			if constexpr (!FIRST) {
-				const f2* tw = twL + pd_twoff(D, p) + k * pd_tws(D, p);
+		if constexpr (!FIRST) {
+			const int k = bIn[it] % NS;
+			const f2* tw = twL + pd_twoff(D, p) + k * pd_tws(D, p);
 #pragma unroll
-				for (int t = 1; t < R; t++) x[it][t] = octfft::cmul(x[it][t], tw[t - 1]);
-			}
-			mxn::dft<R>(x[it]);
-			if constexpr (!LAST) {
-				// element j0 + u NS, j0 = q NS R + k, at (j0 + j0 / R_0) + u (NS + NS / R_0); first pass: b (R_0 + 1) + u
-				const int j0 = q * (NS * R) + k;
-				f2* dst = xb + (FIRST ? (PADP ? b * (R + 1) : b * R) : (PADP ? j0 + j0 / PADP : j0));
-				constexpr int US = FIRST ? 1 : (PADP ? NS + NS / PADP : NS);
-				if (active) {
+			for (int t = 1; t < R; t++) x[it][t] = octfft::cmul(x[it][t], tw[t - 1]);
+		}
+		mxn::dft<R>(x[it]);
+	}
+	// ---- outputs
+	if constexpr (!LAST) {
 #pragma unroll
-					for (int u = 0; u < R; u++) dst[u * US] = x[it][u];
-				}
-			} else if constexpr (SPECTRUM) {
-				const int vb = active ? b * 8 : 0x40000000;  // (beyond the descriptor: dropped)
+		for (int it = 0; it < ITS; it++) {
+			// element j0 + u NS, j0 = q NS R + k, at (j0 + j0 / R_0) + u (NS + NS / R_0); first pass: b (R_0 + 1) + u
+			const int b = bIn[it], q = b / NS, k = b - q * NS, j0 = q * (NS * R) + k;
+			f2* dst = xb + (FIRST ? (PADP ? b * (R + 1) : b * R) : (PADP ? j0 + j0 / PADP : j0));
+			constexpr int US = FIRST ? 1 : (PADP ? NS + NS / PADP : NS);
+			if (active[it]) {
 #pragma unroll
-				for (int u = 0; u < R; u++) buf_store64(x[it][u], specR, vb, u * NB * 8);
-			} else {
-				// bins b + u NB below N / 2: mean A-line, |.|^2, log / lin, grey-scale mapping (cu:492-661); the descriptor of the output row ends
-				// at bin N / 2 (an odd last radix: the bins of its middle output beyond that are dropped by the bounds check)
-#pragma unroll
-				for (int u = 0; u < (R + 1) / 2; u++) {
-					f2 z = x[it][u] - mean[it * ((R + 1) / 2) + u];
-					const float pw = z.x * z.x + z.y * z.y;
-					const float s = LOGSCALE ? __builtin_amdgcn_logf(pw) : __builtin_amdgcn_sqrtf(pw);
-					store_image_masked<BG>(a.sA * s + a.sB, outR, termL, b * 4, u * NB * 4, active);
-				}
+				for (int u = 0; u < R; u++) dst[u * US] = x[it][u];
 			}
 		}
+		wave_sync_lds();
+	} else if constexpr (SPECTRUM) {
+#pragma unroll
+		for (int it = 0; it < ITS; it++) {
+			const int vb = active[it] ? bIn[it] * 8 : 0x40000000;  // (beyond the descriptor: dropped)
+#pragma unroll
+			for (int u = 0; u < R; u++) buf_store64(x[it][u], sink.spec, vb, u * NB * 8);
+		}
+	} else if constexpr (PAIR) {
+		static_assert(R % 2 == 0, "the last radix is even: its upper outputs are the bins from N / 2 on");
+		// mirror exchange: the upper half of the spectrum in bin order, slot = bin - N / 2 (plain layout; the idle lanes repeat the
+		// writes of lane NB - 1); Z[0] is its own partner (slot N / 2); Z[N - k] of the kept bin k = b + u NB sits in slot N / 2 - k
+		f2* mb = xb;
+#pragma unroll
+		for (int it = 0; it < ITS; it++)
+#pragma unroll
+			for (int u = R / 2; u < R; u++) mb[bIn[it] + (u - R / 2) * NB] = x[it][u];
+		if (lane == 0) mb[N / 2] = x[0][0];
+		wave_sync_lds();
+#pragma unroll
+		for (int it = 0; it < ITS; it++) {
+			const f2* mp = mb + (N / 2 - bIn[it]);
+#pragma unroll
+			for (int u = 0; u < R / 2; u++) {
+				const f2 z = x[it][u], c = mp[-u * NB], mm = mean[it * (R / 2) + u];
+				const f2 s1 = f2{z.x + c.x, z.y - c.y} - mm;  // 2 X1 - 2 mean
+				const f2 s2 = f2{z.y + c.y, c.x - z.x} - mm;  // 2 X2 - 2 mean,  X2 = (Z - conj Z') / (2i)
+				const float p1 = s1.x * s1.x + s1.y * s1.y, p2 = s2.x * s2.x + s2.y * s2.y;
+				const float f1 = LOGSCALE ? __builtin_amdgcn_logf(p1) : __builtin_amdgcn_sqrtf(p1);
+				const float f2v = LOGSCALE ? __builtin_amdgcn_logf(p2) : __builtin_amdgcn_sqrtf(p2);
+				store_image_masked<BG>(sink.sA * f1 + sink.sB, sink.out0, termL, bIn[it] * 4, u * NB * 4, active[it]);
+				store_image_masked<BG>(sink.sA * f2v + sink.sB, sink.out1, termL, bIn[it] * 4, u * NB * 4, active[it]);
+			}
+		}
+	} else {
+		// bins b + u NB below N / 2: mean A-line, |.|^2, log / lin, grey-scale mapping (cu:492-661); the descriptor of the output row ends
+		// at bin N / 2 (an odd last radix: the bins of its middle output beyond that are dropped by the bounds check)
+#pragma unroll
+		for (int it = 0; it < ITS; it++)
+#pragma unroll
+			for (int u = 0; u < (R + 1) / 2; u++) {
+				const f2 z = x[it][u] - mean[it * ((R + 1) / 2) + u];
+				const float pw = z.x * z.x + z.y * z.y;
+				const float s = LOGSCALE ? __builtin_amdgcn_logf(pw) : __builtin_amdgcn_sqrtf(pw);
+				store_image_masked<BG>(sink.sA * s + sink.sB, sink.out0, termL, bIn[it] * 4, u * NB * 4, active[it]);
+			}
 	}
-	if constexpr (!LAST) wave_sync_lds();
 }
 
-template <class P, int p, int RS, int MODE, int MEANN, class F>
-OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, const FusedArgs& a, __amdgpu_buffer_rsrc_t lutR, __amdgpu_buffer_rsrc_t outR,
-                         __amdgpu_buffer_rsrc_t specR, const f2 (&mean)[MEANN], const float* termL, int lane, F&& afterFirstInputs) {
-	if constexpr (p == 0) pass<P, p, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, afterFirstInputs);
-	else pass<P, p, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, [] {});
-	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, afterFirstInputs);
+template <class P, int p, int RS, int MODE, int MEANN>
+OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
+	pass<P, p, RS, MODE, MEANN>(row, xb, twL, lutR, sink, mean, termL, lane);
+	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN>(row, xb, twL, lutR, sink, mean, termL, lane);
 }
 
-// INTYPE: IN_U16 (raw rows, bitDepth 9..16) or IN_F32 (rows prepared by oct_prepare[_rows]_kernel: other containers, the rolling
-// average); RS: RS_NONE / RS_LINEAR / RS_CUBIC; MODE: MODE_SPECTRUM | MODE_LOG | MODE_BG.  a.twiddle: the tables of passes 1 ..
-// in the [k][t - 1] layout above (host: mixedn_static_twiddles).  W waves per workgroup, one workgroup per CU.
-// smem: the workgroup's LDS, pd_lds_bytes(P::D, W, BG) bytes (a static array in the run-time compiled wrapper: its size is a
-// compile-time constant there, and no per-kernel opt-in to more than 64 KiB of dynamic LDS is needed)
+// INTYPE: IN_U16 (raw rows, bitDepth 9..16) or IN_F32 (rows prepared by oct_prepare[_rows]_kernel: other containers, wide rolling-average
+// windows); RS: RS_NONE / RS_LINEAR / RS_CUBIC; MODE: MODE_ROLL | MODE_SPECTRUM | MODE_LOG | MODE_BG | MODE_PAIR.  a.twiddle: the tables
+// of passes 1 .. in the [k][t - 1] layout above (host: mixedn_static_twiddles).  W waves per workgroup, one workgroup per CU.
+// smem: the workgroup's LDS, pd_lds_bytes(P::D, W, BG, ROLL, PAIR) bytes (a static array in the run-time compiled wrapper: its size
+// is a compile-time constant there, and no per-kernel opt-in to more than 64 KiB of dynamic LDS is needed)
 template <class P, int W, int INTYPE, int RS, int MODE>
 OCT_DEV void body(const FusedArgs& a, char* smem) {
 	static_assert(INTYPE == IN_U16 || INTYPE == IN_F32, "raw uint16 rows or prepared float32 rows");
@@ -177,45 +229,40 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, HALF = N / 2, LP = D.passes - 1, RL = D.radix[LP], NBL = N / RL;
 	constexpr int MEANN = pd_its(D, LP) * ((RL + 1) / 2);
-	constexpr bool BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0;
+	constexpr bool BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0, PAIR = (MODE & MODE_PAIR) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	static_assert(!ROLL || INTYPE == IN_U16, "the rolling average inside the kernel works on the raw integers");
+	static_assert(!PAIR || (INTYPE == IN_U16 && !ROLL && !(MODE & MODE_SPECTRUM)), "two A-scans per transform: raw uint16 rows, image output");
 	f2* twL = reinterpret_cast<f2*>(smem);
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D, ROLL);
+	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D, ROLL, PAIR);
 	float* row = reinterpret_cast<float*>(slice);
 	f2* xb = reinterpret_cast<f2*>(slice);
-	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + W * pd_slice_bytes(D, ROLL));
+	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + W * pd_slice_bytes(D, ROLL, PAIR));
 	if constexpr (BG) fill_bg_term(termL, a.bgTerm, HALF, tid, W * 64);
 	for (int i = tid; i < pd_twelems(D); i += W * 64) twL[i] = a.twiddle[i];
-	// the lane's share of the mean A-line (cu:492-520) for the whole persistent loop: bins b + u NB of the last pass
+	// the lane's share of the mean A-line (cu:492-520) for the whole persistent loop: bins b + u NB of the last pass (PAIR: twice the
+	// mean -- the separated spectra come as 2 X1, 2 X2)
 	f2 mean[MEANN];
 #pragma unroll
 	for (int it = 0; it < pd_its(D, LP); it++)
 #pragma unroll
 		for (int u = 0; u < (RL + 1) / 2; u++) {
 			const int bin = lane + 64 * it + u * NBL;
-			mean[it * ((RL + 1) / 2) + u] = (a.subtractMean && bin < HALF) ? a.meanLine[bin] : f2{0.0f, 0.0f};
+			const f2 m = (a.subtractMean && bin < HALF) ? a.meanLine[bin] : f2{0.0f, 0.0f};
+			mean[it * ((RL + 1) / 2) + u] = PAIR ? m * 2.0f : m;
 		}
 	__syncthreads();
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16);
 	constexpr int IN_BYTES = INTYPE == IN_U16 ? 2 : 4;
+	Sink sink;
+	// PAIR: out = sA f(P) + sB with P = |S - 2 m|^2 / 4:  log2(P' / 4) = log2(P') - 2,  sqrt(P' / 4) = sqrt(P') / 2
+	sink.sA = PAIR && !LOGSCALE ? 0.5f * a.sA : a.sA;
+	sink.sB = PAIR && LOGSCALE ? a.sB - 2.0f * a.sA : a.sB;
 
-	// OCT_MXS_PREFETCH = 1: the raw row of a wave's NEXT A-scan is requested while the current one is transformed and held in N / 128
-	// (uint16) or N / 64 (float32) registers.  Measured (profiles/r4x_static_plan_tuning.txt): no gain -- the other waves of the
-	// SIMD cover the latency already -- and a loss where registers are short (N = 2000 cubic 170 -> 143 M A-scans/s, no resampling
-	// 201 -> 135 M): off
 	constexpr int LOADS = (HALF + 63) / 64;
 	typedef typename RawWord<INTYPE>::T RawT;
-	RawT w[LOADS];
-	auto fetch = [&](unsigned ln) {
-		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * N * IN_BYTES, N * IN_BYTES);
-#pragma unroll
-		for (int m = 0; m < LOADS; m++) {
-			if constexpr (INTYPE == IN_U16) w[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
-			else w[m] = buf_load64(rawR, lane * 8, m * 512);
-		}
-	};
+	RawT w[LOADS], w1[PAIR ? LOADS : 1];
 	// Rolling-average DC removal inside the kernel (MODE_ROLL; cu:165-211: mean over [j - W + 1, j + W] clipped to the A-scan), the scheme
 	// of the general kernel (kernels.h): integer window sums from one uint32 prefix-sum array per A-scan, built from the raw
 	// integers with a wave scan, padded by ROLL_PAD entries on both sides (0 in front, the total behind) so that the clipped
@@ -239,14 +286,32 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 				}
 			}
 	}
-	const unsigned first = blockIdx.x * W + wave, stride = gridDim.x * W;
-	if (OCT_MXS_PREFETCH && first < a.numLines) fetch(first);
-
-	for (unsigned line = first; line < a.numLines; line += stride) {
+	// one unit of work per wave and iteration: an A-scan, or (PAIR) the A-scans 2 i and 2 i + 1 (an odd last one: a row of zeros as partner)
+	const unsigned units = PAIR ? (a.numLines + 1u) / 2u : a.numLines;
+	for (unsigned unit = blockIdx.x * W + wave; unit < units; unit += gridDim.x * W) {
+		const unsigned line = PAIR ? 2u * unit : unit;
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141): 8 bytes of LDS per lane and instruction (the descriptor ends with the
 		// row: lanes beyond it read zeros and write nothing)
-		if (!OCT_MXS_PREFETCH) fetch(line);
-		if constexpr (ROLL) {
+		{
+			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * N * IN_BYTES, N * IN_BYTES);
+			const __amdgpu_buffer_rsrc_t rawR1 = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)(line + 1u) * N * IN_BYTES, (PAIR && line + 1u < a.numLines) ? N * IN_BYTES : 0);
+#pragma unroll
+			for (int m = 0; m < LOADS; m++) {
+				if constexpr (INTYPE == IN_U16) w[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
+				else w[m] = buf_load64(rawR, lane * 8, m * 512);
+				if constexpr (PAIR) w1[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR1, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
+			}
+		}
+		if constexpr (PAIR) {
+			f2* rp = reinterpret_cast<f2*>(row);
+#pragma unroll
+			for (int m = 0; m < LOADS; m++) {
+				const uint32_t u0 = __builtin_bit_cast(uint32_t, w[m]), u1 = __builtin_bit_cast(uint32_t, w1[m]);
+				const float4 v = float4{(float)((u0 & 0xffffu) >> shift), (float)((u1 & 0xffffu) >> shift), (float)((u0 >> 16) >> shift), (float)((u1 >> 16) >> shift)};
+				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<float4*>(&rp[ROW_OFF + 2 * (lane + 64 * m)]) = v;
+				if (RS == RS_CUBIC && m == 0 && lane == 0) rp[ROW_OFF - 1] = f2{v.z, v.w};  // n0 = |n1 - 1| mirror tap (cu:284): sample 1 of both rows
+			}
+		} else if constexpr (ROLL) {
 			uint32_t* pfx = reinterpret_cast<uint32_t*>(slice + pd_row_bytes(D));  // [ROLL_PAD | N | ROLL_PAD]
 			const int Wr = a.rollingW;
 			uint32_t base = 0;
@@ -294,16 +359,18 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 			}
 		}
 		wave_sync_lds();
-		unsigned orow = line;
+		unsigned orow[2] = {line, line + 1u};
 		if (a.flip) {
-			const unsigned bs = line / a.ascansPerBscan, as = line - bs * a.ascansPerBscan;
-			if ((bs & 1u) == 0u && (bs + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = bs * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
+#pragma unroll
+			for (int r = 0; r < (PAIR ? 2 : 1); r++) {
+				const unsigned ln = line + (unsigned)r, bs = ln / a.ascansPerBscan, as = ln - bs * a.ascansPerBscan;
+				if ((bs & 1u) == 0u && (bs + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow[r] = bs * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
+			}
 		}
-		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * HALF, HALF * 4);
-		const __amdgpu_buffer_rsrc_t specR = make_rsrc(a.spectrum + (size_t)line * N, (MODE & MODE_SPECTRUM) ? N * 8 : 0);
-		passes_from<P, 0, RS, MODE, MEANN>(row, xb, twL, a, lutR, outR, specR, mean, termL, lane, [&] {
-			if (OCT_MXS_PREFETCH) { const unsigned next = line + stride; fetch(next < a.numLines ? next : line); }  // (a wave's last A-scan: its own row again)
-		});
+		sink.out0 = make_rsrc(a.out + (size_t)orow[0] * HALF, HALF * 4);
+		sink.out1 = make_rsrc(a.out + (size_t)orow[1] * HALF, (PAIR && line + 1u < a.numLines) ? HALF * 4 : 0);
+		sink.spec = make_rsrc(a.spectrum + (size_t)line * N, (MODE & MODE_SPECTRUM) ? N * 8 : 0);
+		passes_from<P, 0, RS, MODE, MEANN>(row, xb, twL, lutR, sink, mean, termL, lane);
 		wave_sync_lds();  // the last pass' reads of the slice precede the next row
 	}
 }

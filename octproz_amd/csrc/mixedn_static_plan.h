@@ -7,6 +7,7 @@ namespace oct {
 namespace mxs {
 
 constexpr int MAXPASSES = 5;
+constexpr int MODE_PAIR = 16;        // MODE bit of the static-plan kernel only: two A-scans per transform (real FFT input; mixedn_static.h)
 constexpr int MXS_MAXN = 5120;       // longest length planned (N / 64 complex values per lane)
 constexpr int MXS_MAXVALUES = 80;    // values a lane may hold in a pass (idle butterfly slots included): 160 of its 256 registers
 struct PlanDesc {
@@ -21,28 +22,29 @@ constexpr int pd_twelems(const PlanDesc& d) { return pd_twoff(d, d.passes); }
 constexpr int pd_its(const PlanDesc& d, int p) { return (d.N / d.radix[p] + 63) / 64; }
 constexpr int pd_values(const PlanDesc& d) { int v = 0; for (int p = 0; p < d.passes; p++) { const int w = pd_its(d, p) * d.radix[p]; v = w > v ? w : v; } return v; }
 constexpr int pd_row_bytes(const PlanDesc& d) { return ((d.N + 2 * ROW_OFF) * 4 + 15) & ~15; }
-// (roll: the rolling average inside the kernel keeps a [ROLL_PAD | N | ROLL_PAD] array of prefix sums behind the staged row)
-constexpr int pd_slice_bytes(const PlanDesc& d, bool roll = false) {
-	const int x = pd_xelems(d) * 8, r = pd_row_bytes(d) + (roll ? (d.N + 2 * ROLL_PAD) * 4 : 0);
+// (roll: the rolling average inside the kernel keeps a [ROLL_PAD | N | ROLL_PAD] array of prefix sums behind the staged row;
+// pair: two rows staged interleaved, 8 bytes per sample)
+constexpr int pd_slice_bytes(const PlanDesc& d, bool roll = false, bool pair = false) {
+	const int x = pd_xelems(d) * 8, r = pair ? (d.N + 2 * ROW_OFF) * 8 : pd_row_bytes(d) + (roll ? (d.N + 2 * ROLL_PAD) * 4 : 0);
 	return ((x > r ? x : r) + 15) & ~15;
 }
 constexpr int pd_tw_bytes(const PlanDesc& d) { return (pd_twelems(d) * 8 + 15) & ~15; }
 // waves (= A-scans in flight) per workgroup, one workgroup per CU: as many as the LDS holds, capped by the register budget that
 // goes with them (16 waves = 128 registers, 12 = 168, 8 = 256, 4 = 512).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_waves_ab.jsonl):
 // cubic 16 waves 298 M A-scans/s (51 registers spilled), 12 waves 340 M, 8 waves 315 M; linear / none 464 / 420 / 362 M.
-constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false) {
+constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bool pair = false) {
 	const int room = 160 * 1024 - pd_tw_bytes(d) - (bg ? d.N * 2 : 0);
-	int w = room / pd_slice_bytes(d, roll);
+	int w = room / pd_slice_bytes(d, roll, pair);
 #ifdef OCT_MXS_WCAP
 	const int cap = OCT_MXS_WCAP;
 #else
-	const int v = pd_values(d) + (rs == RS_CUBIC ? 8 : 0) + (roll ? 4 : 0);
+	const int v = pd_values(d) + (rs == RS_CUBIC ? 8 : 0) + (roll ? 4 : 0) + (pair ? 4 : 0);
 	const int cap = v <= 24 ? 16 : v <= 40 ? 12 : v <= 52 ? 8 : 4;  // (4 waves: one per SIMD, 512 registers -- 60 values and more spill at 256)
 #endif
 	if (w > cap) w = cap;
 	return w;
 }
-constexpr int pd_lds_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false) { return pd_tw_bytes(d) + waves * pd_slice_bytes(d, roll) + (bg ? d.N * 2 : 0); }
+constexpr int pd_lds_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false, bool pair = false) { return pd_tw_bytes(d) + waves * pd_slice_bytes(d, roll, pair) + (bg ? d.N * 2 : 0); }
 
 }  // namespace mxs
 }  // namespace oct

@@ -655,7 +655,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_STATIC_PLAN;
 		std::string why;
 		if (roll) path |= OCTPIPE_PATH_ROLL_IN_KERNEL;
-		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, h->stream, &why, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0);
+		// without dispersion compensation the FFT input is real: two A-scans per transform (raw uint16 rows, image output, no rolling average)
+		const bool pair = intype == oct::IN_U16 && !roll && !spectrum && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT);
+		if (pair) path |= OCTPIPE_PATH_REAL_INPUT;
+		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, roll, pair, spectrum, p.signalLogScaling != 0, a, h->stream, &why, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0);
 		if (e == hipErrorNotSupported) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);
 		HIP_TRY(e);
 	} else if (mxn) {
@@ -1160,7 +1163,7 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 		std::string why;
 		const bool plain16 = h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO;
 		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, plain16 ? oct::IN_U16 : oct::IN_F32, h->params.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC : oct::RS_LINEAR,
-		                                            false, false, true, probe, h->stream, &why);
+		                                            false, false, false, true, probe, h->stream, &why);
 		if (e == hipSuccess) {
 			std::vector<f2> tw;
 			oct::mixedn_static_twiddles(h->mxsPlan, tw);

@@ -43,6 +43,33 @@ def test_group_on_one_device_equals_single_handle(members, B, flip):
     g.close()
 
 
+@pytest.mark.parametrize("threads", [False, True])
+def test_group_on_a_length_with_a_run_time_compiled_kernel(threads):
+    """samplesPerLine = 1000: every member runs the kernel hiprtc compiles for the length (csrc/mixedn_rtc.hip) -- one compilation per
+    process and device behind a mutex, one module launched from the members' own streams (and, with threads, from their own
+    submitting threads).  Same invariant: sharded == unsharded, bit for bit; the rolling average runs inside that kernel."""
+    N, A, B, members = 1000, 48, 8, 4
+    p = v180_benchmark_params(N, A, B)
+    p.bscanFlip = 1
+    p.backgroundRemoval, p.rollingAverageWindowSize = 1, 32
+    raws = [synthetic_raw(N, A, B, seed=70 + i) for i in range(3)]
+    want, _ = _single(p, raws)
+    keep = np.empty(raws[0].size + 4096, dtype=np.uint16)
+    ring = [keep[(-keep.ctypes.data % 4096) // 2:][:raws[0].size], None]
+    g = PipelineGroup(p, [0] * members, ring[0], None, flags=_lib.GROUP_SUBMIT_THREADS if threads else _lib.GROUP_NO_SUBMIT_THREADS)
+    for k, r in enumerate(raws):
+        ring[0][:] = r.reshape(-1)
+        g.octCudaPipeline(ring[0]); g.synchronize()
+        assert np.array_equal(g.processed_host().view(np.uint32), want[k].view(np.uint32)), "buffer %d" % k
+    L = _lib.lib()
+    import ctypes as C
+    path = C.c_uint(0)
+    for i in range(members):
+        _lib.check(L.octpipe_debug_last_path(C.c_void_p(L.octpipe_group_member(g.handle, i)), C.byref(path)))
+        assert path.value & _lib.PATH_STATIC_PLAN and path.value & _lib.PATH_ROLL_IN_KERNEL, hex(path.value)
+    g.close()
+
+
 def test_group_device_resident_slabs_and_continuous_fpn():
     import torch
     N, A, B = 512, 32, 8

@@ -395,6 +395,8 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
     rolling = case.startswith("rolling")
     assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (rolling and plan == "runtime")
     assert bool(pipe.last_path() & _lib.PATH_ROLL_IN_KERNEL) == (rolling and plan == "static")
+    # (without dispersion compensation the run-time compiled kernel transforms two A-scans at once: real FFT input)
+    assert bool(pipe.last_path() & _lib.PATH_REAL_INPUT) == (plan == "static" and not p.dispersionCompensation and not rolling), hex(pipe.last_path())
     p.postProcessBackgroundUpdated = True
     lib = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN)
     if p.fixedPatternNoiseRemoval:
@@ -416,6 +418,43 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
             ospec[:, :N // 2] += o.mean_line()[:N // 2]
         common.compare_spectra(spec, ospec, N, "N=%d %s" % (N, case))
     pipe.close(); lib.close(); o.close()
+
+
+@pytest.mark.parametrize("N,A,B", [(1000, 7, 3), (1000, 1, 1), (130, 33, 1), (3000, 5, 1), (48, 21, 3), (2000, 2, 1)])
+@pytest.mark.parametrize("variant", ["cubic", "linear_flip", "none_lin_bg"])
+def test_run_time_compiled_kernel_two_ascans_per_transform(N, A, B, variant):
+    """mixedn_static.h MODE_PAIR: without dispersion compensation a wave transforms the pair z = x1 + i x2 and separates the spectra
+    with one more exchange (the scheme of real2n_kernel.h).  Odd line counts (the last A-scan pairs with a row of zeros), the flip
+    rule per line, two workgroups (every wave loops); against the oracle and against the complex-input instance of the same
+    kernel (OCTPIPE_ROUTE_NO_REAL_INPUT)"""
+    p = v180_benchmark_params(N, A, B)
+    p.dispersionCompensation = 0
+    p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
+    if variant == "linear_flip":
+        p.resamplingInterpolation, p.bscanFlip = INTERPOLATION.LINEAR, 1
+    elif variant == "none_lin_bg":
+        p.resampling, p.signalLogScaling, p.signalGrayscaleMax, p.signalGrayscaleMin = 0, 0, 900.0, 0.0
+        p.postProcessBackgroundRemoval, p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 1, 0.8, 0.02
+        p.loadPostProcessingBackground(np.linspace(0.0, 0.3, N // 2, dtype=np.float32))
+    if A * B < 18:
+        p.fixedPatternNoiseRemoval = 0
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N + A)
+    o, pipe, d, want, got = run_both(p, raw, route=_lib.ROUTE_TINY_GRID)
+    assert pipe.last_path() & _lib.PATH_STATIC_PLAN and pipe.last_path() & _lib.PATH_REAL_INPUT, (hex(pipe.last_path()), pipe.rtc_status())
+    p.postProcessBackgroundUpdated = True
+    cx = Pipeline(p, device=0, route=_lib.ROUTE_NO_REAL_INPUT)
+    if p.fixedPatternNoiseRemoval:
+        cx.set_mean_line(o.mean_line(), pin=True)
+    cx.process_device(d.data_ptr()); cx.synchronize()
+    ref = cx.processed_host()
+    assert cx.last_path() & _lib.PATH_STATIC_PLAN and not cx.last_path() & _lib.PATH_REAL_INPUT
+    if p.postProcessBackgroundRemoval:
+        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - got).max() < 1e-3 and got.min() >= 0.0 and got.max() <= 1.0
+    else:
+        common.compare_images(got, want, p, "pair N=%d %dx%d %s" % (N, A, B, variant), mean_line=o.mean_line())
+        common.compare_images(got, ref, p, "pair vs complex input N=%d %dx%d %s" % (N, A, B, variant), mean_line=o.mean_line())
+    pipe.close(); cx.close(); o.close()
 
 
 @pytest.mark.parametrize("plan", ["static", "runtime"])

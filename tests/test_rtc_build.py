@@ -69,6 +69,16 @@ def test_rolling_average_instances_compile(n, rs):
     assert rc == 0 and waves >= 2, err
 
 
+@needs_hiprtc
+@pytest.mark.parametrize("n", [48, 1000, 2304, 5120])
+@pytest.mark.parametrize("rs", [RS_NONE, RS_LINEAR, RS_CUBIC])
+def test_two_ascans_per_transform_instances_compile(n, rs):
+    """MODE_PAIR = 16: real FFT input (no dispersion compensation), two raw uint16 rows staged interleaved"""
+    for mode in (MODE_LOG | 16, MODE_BG | 16):
+        rc, radices, waves, code, sec, err = _compile(n, IN_U16, rs, mode)
+        assert rc == 0 and waves >= 2, err
+
+
 @pytest.mark.parametrize("n", [1234, 4094, 1001, 6000, 8190, 7])
 def test_lengths_without_a_static_plan_are_refused(n):
     """2 x 617, 2 x 23 x 89: a prime factor above 13; odd lengths (N / 2 bins); beyond 5120 / the registers of one wave"""
