@@ -233,7 +233,8 @@ void mixedn_static_twiddles(const mxs::PlanDesc& d, std::vector<f2>& tw) {
 hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why, int maxBlocks) {
 	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (a.bgTerm ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0);
 	if (pair && (intype != IN_U16 || roll || spectrum)) return hipErrorInvalidValue;
-	if ((intype != IN_U16 && intype != IN_F32) || (rs != RS_NONE && rs != RS_LINEAR && rs != RS_CUBIC)) return hipErrorInvalidValue;
+	if ((intype != IN_U16 && intype != IN_F32) || rs < RS_NONE || rs > RS_LANCZOS) return hipErrorInvalidValue;
+	if (rs == RS_LANCZOS && (roll || pair || !a.lanczosW)) return hipErrorInvalidValue;
 	if (roll && (intype != IN_U16 || !roll_in_kernel_ok(a))) return hipErrorInvalidValue;
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);

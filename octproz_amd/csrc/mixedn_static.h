@@ -59,7 +59,7 @@ OCT_DEV void buf_store64(f2 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 
 // where the last pass delivers: the output row (PAIR: both rows) or the spectrum row of the current A-scan, the grey-scale mapping
 struct Sink {
-	__amdgpu_buffer_rsrc_t out0, out1, spec;
+	__amdgpu_buffer_rsrc_t out0, out1, spec, lanczos;
 	float sA, sB;  // out = sA f(P) + sB (PAIR: for P' = 4 P, see body)
 };
 
@@ -87,9 +87,17 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 		// lane's ITS x R samples as one software pipeline: the entry of sample s + AHEAD is requested before sample s is
 		// interpolated (a ring of AHEAD entries in registers; chunks that were loaded, awaited and consumed one after the other
 		// paid the L2 latency once per chunk)
-		constexpr int S = ITS * R, AHEAD = S < OCT_MXS_LUT_AHEAD ? S : OCT_MXS_LUT_AHEAD;
-		f32x4 L[AHEAD];
-		auto request = [&](int sIdx) { L[sIdx % AHEAD] = buf_load128(lutR, bIn[sIdx / R] * 16, (sIdx % R) * NB * 16); };
+		// (Lanczos: the 16 tap weights of a sample -- 64 B of the table the host computed, cu:297-326 -- travel with its entry: two samples in flight)
+		constexpr bool LZ = RS == RS_LANCZOS;
+		constexpr int S = ITS * R, WANT = LZ ? 2 : OCT_MXS_LUT_AHEAD, AHEAD = S < WANT ? S : WANT;
+		f32x4 L[AHEAD], LW[LZ ? AHEAD : 1][4];
+		auto request = [&](int sIdx) {
+			L[sIdx % AHEAD] = buf_load128(lutR, bIn[sIdx / R] * 16, (sIdx % R) * NB * 16);
+			if constexpr (LZ) {
+#pragma unroll
+				for (int c = 0; c < 4; c++) LW[sIdx % AHEAD][c] = buf_load128(sink.lanczos, bIn[sIdx / R] * 64, (sIdx % R) * NB * 64 + c * 16);
+			}
+		};
 #pragma unroll
 		for (int sIdx = 0; sIdx < AHEAD; sIdx++) request(sIdx);
 #pragma unroll
@@ -118,6 +126,13 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 				} else if constexpr (RS == RS_LINEAR) {
 					const float* tp = row + ROW_OFF + (int)e.x;
 					y = tp[0] + (tp[1] - tp[0]) * __builtin_amdgcn_fractf(e.x);
+				} else if constexpr (LZ) {
+					// taps n0 - 7 .. n0 + 8 of the staged window (which reaches 8 samples into the neighbour rows), summed in the order of cu:313-321
+					const float* tp = row + ROW_OFF + (int)e.x;
+					float sum = 0.0f;
+#pragma unroll
+					for (int i = -7; i <= 8; i++) sum += tp[i] * LW[sIdx % AHEAD][(i + 7) >> 2][(i + 7) & 3];
+					y = sum;
 				} else {
 					y = row[ROW_OFF + bIn[it] + t * NB];
 				}
@@ -225,13 +240,14 @@ OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, __amdgpu_buffe
 template <class P, int W, int INTYPE, int RS, int MODE>
 OCT_DEV void body(const FusedArgs& a, char* smem) {
 	static_assert(INTYPE == IN_U16 || INTYPE == IN_F32, "raw uint16 rows or prepared float32 rows");
-	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC, "resampling mode");
+	static_assert(RS == RS_NONE || RS == RS_LINEAR || RS == RS_CUBIC || RS == RS_LANCZOS, "resampling mode");
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, HALF = N / 2, LP = D.passes - 1, RL = D.radix[LP], NBL = N / RL;
 	constexpr int MEANN = pd_its(D, LP) * ((RL + 1) / 2);
 	constexpr bool BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0, PAIR = (MODE & MODE_PAIR) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
 	static_assert(!ROLL || INTYPE == IN_U16, "the rolling average inside the kernel works on the raw integers");
-	static_assert(!PAIR || (INTYPE == IN_U16 && !ROLL && !(MODE & MODE_SPECTRUM)), "two A-scans per transform: raw uint16 rows, image output");
+	static_assert(!PAIR || (INTYPE == IN_U16 && !ROLL && !(MODE & MODE_SPECTRUM) && RS != RS_LANCZOS), "two A-scans per transform: raw uint16 rows, image output");
+	static_assert(!(RS == RS_LANCZOS && ROLL), "Lanczos taps cross line borders: the rolling average of the neighbour rows comes prepared");
 	f2* twL = reinterpret_cast<f2*>(smem);
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D, ROLL, PAIR);
@@ -259,6 +275,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	// PAIR: out = sA f(P) + sB with P = |S - 2 m|^2 / 4:  log2(P' / 4) = log2(P') - 2,  sqrt(P' / 4) = sqrt(P') / 2
 	sink.sA = PAIR && !LOGSCALE ? 0.5f * a.sA : a.sA;
 	sink.sB = PAIR && LOGSCALE ? a.sB - 2.0f * a.sA : a.sB;
+	sink.lanczos = make_rsrc(a.lanczosW, RS == RS_LANCZOS ? N * 64 : 0);
 
 	constexpr int LOADS = (HALF + 63) / 64;
 	typedef typename RawWord<INTYPE>::T RawT;
@@ -290,6 +307,34 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	const unsigned units = PAIR ? (a.numLines + 1u) / 2u : a.numLines;
 	for (unsigned unit = blockIdx.x * W + wave; unit < units; unit += gridDim.x * W) {
 		const unsigned line = PAIR ? 2u * unit : unit;
+		if constexpr (RS == RS_LANCZOS) {
+			// Lanczos taps cross line borders (cu:313-321): stage [off - 8, off + N + 8) of the BUFFER, off = clamp(line N, 8, S - 9) (the
+			// reference's first-line quirk), zeros outside -- the staging of the general kernel (kernels.h), 8 samples per lane and load
+			// through a descriptor that ends with the window or the buffer (lanes beyond it write zeros into the dead part of the slice)
+			const long long S = (long long)a.linesInBuffer * N;
+			long long off = (long long)line * N;
+			if (off < 8) off = 8;
+			if (off > S - 9) off = S - 9;
+			const long long left = (S - (off - 8)) * IN_BYTES, want = (long long)(N + 16) * IN_BYTES;
+			const __amdgpu_buffer_rsrc_t haloR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (off - 8) * IN_BYTES, (uint32_t)(left < want ? left : want));
+			constexpr int PER = INTYPE == IN_U16 ? 8 : 4, UNITS = (N + 16 + PER - 1) / PER;
+#pragma unroll
+			for (int i = 0; i < (UNITS + 63) / 64; i++) {
+				const int u = lane + 64 * i;
+				if (u < UNITS) {
+					if constexpr (INTYPE == IN_U16) {
+						const u32x4 c = __builtin_bit_cast(u32x4, buf_load128(haloR, u * 16, 0));
+						const float4 lo = chunk_to_float<IN_U16>(c, 0, shift), hi = chunk_to_float<IN_U16>(c, 1, shift);
+						float* dst = &row[ROW_OFF - 8 + 8 * u];  // (8-byte aligned: ROW_OFF - 8 = 4 floats)
+						*reinterpret_cast<f2*>(dst) = f2{lo.x, lo.y}; *reinterpret_cast<f2*>(dst + 2) = f2{lo.z, lo.w};
+						*reinterpret_cast<f2*>(dst + 4) = f2{hi.x, hi.y}; *reinterpret_cast<f2*>(dst + 6) = f2{hi.z, hi.w};
+					} else {
+						const f32x4 f = buf_load128(haloR, u * 16, 0);
+						*reinterpret_cast<float4*>(&row[ROW_OFF - 8 + 4 * u]) = float4{f.x, f.y, f.z, f.w};
+					}
+				}
+			}
+		} else {
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141): 8 bytes of LDS per lane and instruction (the descriptor ends with the
 		// row: lanes beyond it read zeros and write nothing)
 		{
@@ -357,6 +402,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = v;
 				if (RS == RS_CUBIC && m == 0 && lane == 0) row[ROW_OFF - 1] = v.y;  // n0 = |n1 - 1| mirror tap (cu:284): sample 1
 			}
+		}
 		}
 		wave_sync_lds();
 		unsigned orow[2] = {line, line + 1u};

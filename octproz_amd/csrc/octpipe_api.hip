@@ -586,9 +586,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	// and the rolling average through the prepared float32 rows
 	// (mixedStatic: the kernel compiled for this length at run time, mixedn_static.h -- also for lengths beyond the run-time plan's 2304)
 	const bool mxnStatic = h->mixedStatic && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN_STATIC);
-	const bool mxn = (h->mixedN || mxnStatic) && rs != oct::RS_LANCZOS && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN);
+	// (Lanczos: the run-time compiled kernel only; the run-time plan's kernel leaves it to the library route)
+	const bool mxn = ((h->mixedN && rs != oct::RS_LANCZOS) || mxnStatic) && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN);
 	// (the kernel compiled for the length also runs the rolling average itself, under the rule of the general kernel: W <= ROLL_PAD, exact sums)
-	const bool mxnDirect = mxn && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && (!roll || (rollInKernel && mxnStatic));
+	const bool mxnDirect = mxn && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && (!roll || (rollInKernel && mxnStatic && rs != oct::RS_LANCZOS));
 	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect && !mxnDirect) {
 		int rc = ensure(h, (void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
@@ -656,7 +657,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		std::string why;
 		if (roll) path |= OCTPIPE_PATH_ROLL_IN_KERNEL;
 		// without dispersion compensation the FFT input is real: two A-scans per transform (raw uint16 rows, image output, no rolling average)
-		const bool pair = intype == oct::IN_U16 && !roll && !spectrum && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT);
+		const bool pair = intype == oct::IN_U16 && !roll && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT);
 		if (pair) path |= OCTPIPE_PATH_REAL_INPUT;
 		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, roll, pair, spectrum, p.signalLogScaling != 0, a, h->stream, &why, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0);
 		if (e == hipErrorNotSupported) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);

@@ -228,7 +228,9 @@ _ROUTING = [
     (1000, {"dispersionCompensation": 0}, 0, _P.ROUTE_NO_REAL_INPUT, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
     (1000, {"dispersionCompensation": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_ROLL_IN_KERNEL),
     (1000, {"dispersionCompensation": 0, "bitDepth": 8}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),
-    (1000, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),  # Lanczos stays on the library route
+    (1000, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),      # Lanczos: the run-time compiled kernel too
+    (1000, {"resamplingInterpolation": 2}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),  # ... not the run-time plan's
+    (1000, {"resamplingInterpolation": 2, "backgroundRemoval": 1, "rollingAverageWindowSize": 16}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),
     (1000, {}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_MIXED_RADIX),                             # the run-time-plan kernel (mixedn_kernel.h)
     (1000, {"postProcessBackgroundRemoval": 1}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_MIXED_RADIX | _P.PATH_FUSED_BG),
     (1000, {}, 0, _P.ROUTE_NO_MIXEDN, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),

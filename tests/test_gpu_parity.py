@@ -338,7 +338,8 @@ def test_non_power_of_two_lengths_bluestein(N, interp, route):
     o, pipe, d, want, got = run_both(p, raw, route=flags)
     if N != 1664:  # which implementation ran (a silent fall-back to another correct route would go unnoticed otherwise)
         lanczos = interp == INTERPOLATION.LANCZOS
-        expect = {"default": _lib.PATH_MIXED_RADIX if (N != 2046 and not lanczos) else _lib.PATH_LIBRARY_FFT,
+        # (Lanczos on these lengths: the run-time compiled kernel since round 4 -- the run-time plan's kernel leaves it to the library)
+        expect = {"default": _lib.PATH_MIXED_RADIX if N != 2046 else _lib.PATH_LIBRARY_FFT,
                   "library": _lib.PATH_LIBRARY_FFT, "bluestein": _lib.PATH_BLUESTEIN}[route]
         assert pipe.last_path() & (_lib.PATH_MIXED_RADIX | _lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN) == expect, hex(pipe.last_path())
     common.compare_images(got, want, p, "N=%d" % N, mean_line=o.mean_line())
@@ -358,6 +359,8 @@ MIXEDN_CASES = {
     "rolling8": mutate(backgroundRemoval=1, rollingAverageWindowSize=8),        # static plan: inside the kernel; run-time plan: prepared float32 rows in front of it
     "rolling256_linear": mutate(backgroundRemoval=1, rollingAverageWindowSize=256, resamplingInterpolation=INTERPOLATION.LINEAR),
     "bitshift": mutate(bitshift=1, bitDepth=16),
+    "lanczos": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS),            # static plan only (16 taps reaching into the neighbour rows)
+    "lanczos_rolling_flip": mutate(resamplingInterpolation=INTERPOLATION.LANCZOS, backgroundRemoval=1, rollingAverageWindowSize=16, bscanFlip=1),  # prepared rows
     "no_fpn_bg": mutate(fixedPatternNoiseRemoval=0, postProcessBackgroundRemoval=1, postProcessBackgroundWeight=0.8, postProcessBackgroundOffset=0.02,
                         signalGrayscaleMax=110.0, signalGrayscaleMin=20.0),       # background removal inside the store
 }
@@ -377,10 +380,12 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
     mixedn_kernel.h: one A-scan per workgroup, Stockham passes over a run-time plan of radices 16, 13, 11, 8, 7, 5, 4, 3, 2 (1000 = 8 x 5^3,
     2304 = 16 x 16 x 3 x 3, 2002 = 2 x 7 x 11 x 13, 1260 = 4 x 3 x 3 x 5 x 7, 182 = 2 x 7 x 13 ...; up to 2304, longer ones keep the library route), the whole chain on chip.  Against the oracle (image and
     spectrum) and against the library route (gather -> hipFFT -> epilogue), which is really different code."""
-    if N > 1600 and case not in ("v180", "lin_scale_flip", "no_fpn_bg", "rolling256_linear"):
+    if N > 1600 and case not in ("v180", "lin_scale_flip", "no_fpn_bg", "rolling256_linear", "lanczos"):
         pytest.skip("long lengths on four cases (the oracle's DFT is O(N^2))")
     if plan == "runtime" and N in MIXEDN_STATIC_ONLY:
         pytest.skip("the run-time plan stops at 2304")
+    if plan == "runtime" and case.startswith("lanczos"):
+        pytest.skip("Lanczos: the run-time plan's kernel leaves it to the library route")
     A, B = 20, 2
     p = v180_benchmark_params(N, A, B)
     p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
@@ -393,7 +398,7 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
     assert pipe.last_path() & _lib.PATH_MIXED_RADIX and not pipe.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN), hex(pipe.last_path())
     assert bool(pipe.last_path() & _lib.PATH_STATIC_PLAN) == (plan == "static"), (hex(pipe.last_path()), pipe.rtc_status())
     rolling = case.startswith("rolling")
-    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == (rolling and plan == "runtime")
+    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == ((rolling and plan == "runtime") or case == "lanczos_rolling_flip")
     assert bool(pipe.last_path() & _lib.PATH_ROLL_IN_KERNEL) == (rolling and plan == "static")
     # (without dispersion compensation the run-time compiled kernel transforms two A-scans at once: real FFT input)
     assert bool(pipe.last_path() & _lib.PATH_REAL_INPUT) == (plan == "static" and not p.dispersionCompensation and not rolling), hex(pipe.last_path())

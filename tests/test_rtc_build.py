@@ -70,6 +70,16 @@ def test_rolling_average_instances_compile(n, rs):
 
 
 @needs_hiprtc
+@pytest.mark.parametrize("n", [48, 130, 1000, 3000])
+@pytest.mark.parametrize("intype", [IN_U16, IN_F32])
+def test_lanczos_instances_compile(n, intype):
+    """RS_LANCZOS = 3: 16 taps per sample from a window that reaches 8 samples into the neighbour rows, weights from the host's table"""
+    for mode in (MODE_SPECTRUM, MODE_LOG, MODE_BG):
+        rc, radices, waves, code, sec, err = _compile(n, intype, 3, mode)
+        assert rc == 0 and waves >= 2, err
+
+
+@needs_hiprtc
 @pytest.mark.parametrize("n", [48, 1000, 2304, 5120])
 @pytest.mark.parametrize("rs", [RS_NONE, RS_LINEAR, RS_CUBIC])
 def test_two_ascans_per_transform_instances_compile(n, rs):
