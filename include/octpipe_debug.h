@@ -35,6 +35,7 @@ enum {
 	OCTPIPE_ROUTE_NO_MIXED      = 64,  /* creation: samplesPerLine = 1664 without the mixed-radix kernel */
 	OCTPIPE_ROUTE_NO_MIXEDN     = 128, /* lengths with a generic mixed-radix plan (1000, 1536, 2000 ...): keep the library route / Bluestein */
 	OCTPIPE_ROUTE_NO_MIXEDN_STATIC = 512, /* keep the run-time-plan kernel (mixedn_kernel.h) where a kernel compiled for the length exists (mixedn_static.h) */
+	OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT = 2048, /* creation: the run-time compiled kernel with its first plan order and exchange layout (largest radix first, always padded) */
 	OCTPIPE_ROUTE_TINY_GRID = 1024,    /* the run-time compiled kernel on TWO persistent workgroups: every wave loops over many A-scans even of a small test buffer */
 	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256 /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
 };

@@ -79,7 +79,7 @@ struct Instance {
 	std::string why;
 	double compileSeconds = 0.0;
 };
-typedef std::tuple<int, int, int, int, int, int, int, int, int, int, std::string> Key;  // device, N, five radices, intype, rs, mode, extra options
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, std::string> Key;  // device, N, pad, five radices, intype, rs, mode, extra options
 struct Cache {
 	std::mutex mtx;
 	std::map<Key, Instance> entries;
@@ -100,14 +100,14 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	char src[1024];
 	std::snprintf(src, sizeof src,
 	              "#include \"mixedn_static.h\"\n"
-	              "using P = oct::mxs::Plan<%d, %d, %d, %d, %d, %d>;\n"
+	              "using P = oct::mxs::Plan<%d, %d, %d, %d, %d, %d, %d>;\n"
 	              "constexpr int W = %d;\n"
 	              "static_assert(W == oct::mxs::pd_waves(P::D, %s, %d, %s, %s), \"host and kernel agree on the launch shape\");\n"
 	              "extern \"C\" __global__ __launch_bounds__(W * 64, (W + 3) / 4) void oct_mxs(const oct::FusedArgs a) {\n"
 	              "\t__shared__ __attribute__((aligned(16))) char smem[%d];\n"
 	              "\toct::mxs::body<P, W, %d, %d, %d>(a, smem);\n"
 	              "}\n",
-	              d.N, d.radix[0], d.passes > 1 ? d.radix[1] : 1, d.passes > 2 ? d.radix[2] : 1, d.passes > 3 ? d.radix[3] : 1, d.passes > 4 ? d.radix[4] : 1, W,
+	              d.N, d.padp, d.radix[0], d.passes > 1 ? d.radix[1] : 1, d.passes > 2 ? d.radix[2] : 1, d.passes > 3 ? d.radix[3] : 1, d.passes > 4 ? d.radix[4] : 1, W,
 	              bg ? "true" : "false", rs, roll ? "true" : "false", pair ? "true" : "false", mxs::pd_lds_bytes(d, W, bg, roll, pair), intype, rs, mode);
 	const char* names[] = {"kernels.h", "fft_regs.h", "mixedn_kernel.h", "mixedn_static.h", "mixedn_static_plan.h"};
 	const char* texts[] = {oct_rtc_src_kernels_h, oct_rtc_src_fft_regs_h, oct_rtc_src_mixedn_kernel_h, oct_rtc_src_mixedn_static_h, oct_rtc_src_mixedn_static_plan_h};
@@ -162,7 +162,7 @@ void compileInstance(const mxs::PlanDesc& d, int intype, int rs, int mode, int d
 // whose values fit a lane's registers (N / 64 complex values, pd_values <= MXS_MAXVALUES) and whose slices leave at least two
 // A-scans in flight per CU: fewest passes, then fewest values per lane (idle lanes in the last iteration of a pass count as
 // values), then the smallest sum of radices; largest radix first, an even radix last (its upper outputs are the dropped bins).
-bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out) {
+bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out, bool oldLayout) {
 	static const int kR[15] = {20, 16, 15, 14, 13, 12, 11, 10, 8, 7, 6, 5, 4, 3, 2};
 	if (n < 8 || n > (unsigned)mxs::MXS_MAXN || (n & 1u)) return false;
 	struct Search {
@@ -189,7 +189,9 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out) {
 	s.go(n, 0, 0, 0);
 	if (s.bestPasses > mxs::MAXPASSES) return false;
 	mxs::PlanDesc d = s.best;
-	// an even radix last (the smallest one), the others in descending order as found
+	// order: an even radix last (the smallest one: its upper outputs are the dropped bins); in front the radix whose contiguous outputs
+	// per lane the LDS takes best (mixedn_static_plan.h pd_first_radix_rank; oldLayout: the largest, always padded when even -- the
+	// layout of the first version, kept for the A/B); the others in descending order as found
 	int evenAt = -1;
 	for (int i = d.passes - 1; i >= 0; --i) if (d.radix[i] % 2 == 0) { evenAt = i; break; }
 	if (evenAt >= 0 && evenAt != d.passes - 1) {
@@ -197,6 +199,14 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out) {
 		for (int i = evenAt; i < d.passes - 1; ++i) d.radix[i] = d.radix[i + 1];
 		d.radix[d.passes - 1] = r;
 	}
+	if (!oldLayout && d.passes > 2) {
+		int best = 0;
+		for (int i = 1; i < d.passes - 1; ++i) if (mxs::pd_first_radix_rank(d.radix[i]) < mxs::pd_first_radix_rank(d.radix[best])) best = i;
+		const int r = d.radix[best];
+		for (int i = best; i > 0; --i) d.radix[i] = d.radix[i - 1];
+		d.radix[0] = r;
+	}
+	d.padp = oldLayout ? ((d.radix[0] % 2 == 0 && d.passes > 1) ? d.radix[0] : 0) : mxs::pd_pad_for(d.radix[0], d.passes);
 	if (mxs::pd_values(d) > mxs::MXS_MAXVALUES || mxs::pd_waves(d, true, RS_CUBIC, true, false) < 2 || mxs::pd_waves(d, true, RS_CUBIC, false, true) < 2) return false;
 	*out = d;
 	return true;
@@ -243,7 +253,7 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 	Instance* in = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(c.mtx);
-		const Key key{dev, d.N, d.radix[0], d.radix[1], d.radix[2], d.radix[3], d.radix[4], intype, rs, mode, c.extraOptions};
+		const Key key{dev, d.N, d.padp, d.radix[0], d.radix[1], d.radix[2], d.radix[3], d.radix[4], intype, rs, mode, c.extraOptions};
 		auto it = c.entries.find(key);
 		if (it == c.entries.end()) {
 			Instance fresh;

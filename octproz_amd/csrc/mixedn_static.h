@@ -10,9 +10,10 @@
 //   * the twiddles of pass p sit as [k][t - 1] (k < NS_p, row pitch odd): one base per butterfly, immediates for t.
 // Stockham autosort, pass p (radix R, NS = R_0 ... R_{p-1}, NB = N / R butterflies b = lane + 64 it):
 //   inputs b + t NB,  twiddle exp(+2 pi i t k / (NS R)) with k = b mod NS,  outputs (b / NS) NS R + k + u NS
-// Exchange layout: element j at j + j / R_0 when R_0 is even (the first pass writes a butterfly's R_0 outputs contiguously: the
-// lane stride R_0 + 1 is odd, conflict-free; NB_p and NS_p are multiples of R_0 for p >= 1, so j / R_0 splits into a per-lane
-// part and a constant).  The last pass' outputs are the bins b + u NB: those below N / 2 go through the epilogue to HBM.
+// Exchange layout: element j at j + j / R_0 when the plan starts with 8 or 16 (the first pass writes a butterfly's R_0 outputs
+// contiguously: the lane stride R_0 + 1 is odd, conflict-free; NB_p and NS_p are multiples of R_0 for p >= 1, so j / R_0 splits into a
+// per-lane part and a constant); plain j otherwise (mixedn_static_plan.h: the other radices write without or with two-way conflicts,
+// and the unit-stride reads of the later passes stay free of holes).  The last pass' outputs are the bins b + u NB: those below N / 2 go through the epilogue to HBM.
 #pragma once
 #include "mixedn_kernel.h"
 #include "mixedn_static_plan.h"
@@ -20,8 +21,9 @@
 namespace oct {
 namespace mxs {
 
-template <int N_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 = 1> struct Plan {
-	static constexpr PlanDesc D = {N_, (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1) + (R4 > 1), {R0, R1, R2, R3, R4}};
+template <int N_, int PADP_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 = 1> struct Plan {
+	static constexpr PlanDesc D = {N_, (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1) + (R4 > 1), {R0, R1, R2, R3, R4}, PADP_};
+	static_assert(PADP_ == 0 || PADP_ == R0, "the pad follows the first radix");
 	static constexpr int N = N_, PASSES = D.passes;
 	static_assert(pd_ns(D, D.passes) == N_, "the radices multiply to N (unused trailing radices are 1)");
 	static_assert(N_ % 2 == 0, "N / 2 bins");

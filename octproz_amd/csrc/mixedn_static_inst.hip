@@ -61,14 +61,14 @@ hipError_t launch_plan(int intype, int rs, bool spectrum, bool logScale, const F
 #endif
 
 bool mixedn_static_plan(unsigned n, mxs::PlanDesc* d) {
-#define MXS_LEN(N, A, B, C, E, F) if (n == N) { *d = mxs::Plan<N, A, B, C, E, F>::D; return true; }
+#define MXS_LEN(N, A, B, C, E, F) if (n == N) { *d = mxs::Plan<N, mxs::pd_pad_for(A, 3), A, B, C, E, F>::D; return true; }
 	OCT_MXS_LENGTHS
 #undef MXS_LEN
 	return false;
 }
 
 hipError_t launch_mixedn_static(unsigned n, int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream) {
-#define MXS_LEN(N, A, B, C, E, F) if (n == N) return launch_plan<mxs::Plan<N, A, B, C, E, F>>(intype, rs, spectrum, logScale, a, stream);
+#define MXS_LEN(N, A, B, C, E, F) if (n == N) return launch_plan<mxs::Plan<N, mxs::pd_pad_for(A, 3), A, B, C, E, F>>(intype, rs, spectrum, logScale, a, stream);
 	OCT_MXS_LENGTHS
 #undef MXS_LEN
 	return hipErrorInvalidValue;

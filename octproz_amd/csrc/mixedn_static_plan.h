@@ -12,9 +12,20 @@ constexpr int MXS_MAXN = 5120;       // longest length planned (N / 64 complex v
 constexpr int MXS_MAXVALUES = 80;    // values a lane may hold in a pass (idle butterfly slots included): 160 of its 256 registers
 struct PlanDesc {
 	int N, passes, radix[MAXPASSES];
+	int padp;  // exchange layout: element j at j + j / padp (0: no pad).  padp = R_0 where the first pass' contiguous R_0 outputs per lane need it
 };
+// The first pass writes a butterfly's R_0 outputs contiguously: lane stride R_0 elements = 2 R_0 dwords.  ds_write_b64 is served in
+// groups of 16 lanes: conflict-free when the 16 offsets 2 R_0 l mod 64 differ (R_0 odd, or 2, 6, 10, 14), two-way for R_0 = 4, 12, 20,
+// four- and eight-way for 8 and 16.  A pad element per R_0 (odd stride R_0 + 1) repairs the writes but puts holes into the unit-stride
+// reads of every later pass (a 32-lane window then spans more than 64 banks: one extra cycle per window -- 22 % of the LDS cycles
+// at N = 1000 with R_0 = 10 padded, profiles/r4aa_n1000_pmc_counters.csv).  So: the plan STARTS with the friendliest radix it has,
+// and only 8 and 16 in front get the pad.
+// (small radices in front make the second pass' runs of NS = R_0 consecutive elements short: N = 1200 as 3 x 20 x 20 was 3 % slower than
+// 20 x 3 x 20 -- they rank behind the two-way radices)
+constexpr int pd_first_radix_rank(int r) { return (r == 10 || r == 14 || r == 11 || r == 13 || r == 15) ? 0 : (r == 20 || r == 12 || r == 6 || r == 7 || r == 5) ? 1 : r == 16 ? 3 : 2; }
+constexpr int pd_pad_for(int r0, int passes) { return (passes > 1 && (r0 == 8 || r0 == 16)) ? r0 : 0; }
 constexpr int pd_ns(const PlanDesc& d, int p) { int s = 1; for (int i = 0; i < p; i++) s *= d.radix[i]; return s; }
-constexpr int pd_padp(const PlanDesc& d) { return (d.radix[0] % 2 == 0 && d.passes > 1) ? d.radix[0] : 0; }
+constexpr int pd_padp(const PlanDesc& d) { return d.padp; }
 constexpr int pd_xelems(const PlanDesc& d) { return d.N + (pd_padp(d) ? d.N / pd_padp(d) : 0); }
 constexpr int pd_tws(const PlanDesc& d, int p) { return (d.radix[p] - 1) | 1; }  // row pitch of pass p's twiddle table: odd
 constexpr int pd_twoff(const PlanDesc& d, int p) { int o = 0; for (int q = 1; q < p; q++) o += pd_ns(d, q) * pd_tws(d, q); return o; }
@@ -30,7 +41,7 @@ constexpr int pd_slice_bytes(const PlanDesc& d, bool roll = false, bool pair = f
 }
 constexpr int pd_tw_bytes(const PlanDesc& d) { return (pd_twelems(d) * 8 + 15) & ~15; }
 // waves (= A-scans in flight) per workgroup, one workgroup per CU: as many as the LDS holds, capped by the register budget that
-// goes with them (16 waves = 128 registers, 12 = 168, 8 = 256, 4 = 512).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_waves_ab.jsonl):
+// goes with them (16 waves = 128 registers, 9-12 = 168, 5-8 = 256, up to 4 = 512).  Measured at N = 1000 (values = 20; profiles/r4s_mxs_waves_ab.jsonl):
 // cubic 16 waves 298 M A-scans/s (51 registers spilled), 12 waves 340 M, 8 waves 315 M; linear / none 464 / 420 / 362 M.
 constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bool pair = false) {
 	const int room = 160 * 1024 - pd_tw_bytes(d) - (bg ? d.N * 2 : 0);
@@ -39,7 +50,8 @@ constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bo
 	const int cap = OCT_MXS_WCAP;
 #else
 	const int v = pd_values(d) + (rs == RS_CUBIC ? 8 : rs == RS_LANCZOS ? 16 : 0) + (roll ? 4 : 0) + (pair ? 4 : 0);
-	const int cap = v <= 24 ? 16 : v <= 40 ? 12 : v <= 52 ? 8 : 4;  // (4 waves: one per SIMD, 512 registers -- 60 values and more spill at 256)
+	// (N = 2000 linear, 40 values at 9 waves = 168 registers: 119 M against 201 M at 8 waves -- 12 waves only up to 32 values held)
+	const int cap = v <= 24 ? 16 : (v <= 40 && pd_values(d) <= 32) ? 12 : v <= 52 ? 8 : 4;  // (4 waves: one per SIMD, 512 registers -- 60 values and more spill at 256)
 #endif
 	if (w > cap) w = cap;
 	return w;

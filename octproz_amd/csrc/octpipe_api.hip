@@ -1159,7 +1159,7 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	// ... and, up to 4096, the static-plan kernel compiled for this very length at run time (mixedn_static.h, mixedn_rtc.hip), if hiprtc
 	// can be had in this process: a probe launch of zero A-scans compiles the most likely instance now, so that a process without a
 	// working hiprtc keeps its other route for the length and says why (octpipe_debug_rtc_status)
-	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT | OCTPIPE_ROUTE_NO_MIXEDN_STATIC)) && oct::mixedn_rtc_plan(acq->samplesPerLine, &h->mxsPlan)) {
+	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT | OCTPIPE_ROUTE_NO_MIXEDN_STATIC)) && oct::mixedn_rtc_plan(acq->samplesPerLine, &h->mxsPlan, (createRoute & OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT) != 0)) {
 		oct::FusedArgs probe{};
 		std::string why;
 		const bool plain16 = h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO;

@@ -265,6 +265,93 @@ def test_routing_table(N, settings, fmt, route, want):
     assert got == want, "N=%d %s: path bits %#x, expected %#x" % (N, settings, got, want)
 
 
+def test_handles_created_concurrently_share_one_run_time_compilation():
+    """four threads create a handle for the same (so far unseen) length at once and process a buffer: the instance cache of
+    csrc/mixedn_rtc.hip is behind one mutex, every (plan, container, resampling, mode) is compiled once per process and device"""
+    import threading
+    import torch
+    import common
+    N, A, B = 1820, 20, 2  # 13 x 7 x 20: no other test uses this length
+    p = v180_benchmark_params(N, A, B)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=5)
+    d = torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).to("cuda:0")
+    torch.cuda.synchronize()
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    mean = o.mean_line()
+    probe = Pipeline(v180_benchmark_params(1024, 8, 1), device=0)
+    before = probe.rtc_status()["compiled_in_process"]
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            q = Pipeline(p, device=0)
+            q.set_mean_line(mean, pin=True)
+            q.process_device(d.data_ptr()); q.synchronize()
+            assert q.last_path() & _lib.PATH_STATIC_PLAN, q.rtc_status()
+            out[i] = q.processed_host().copy()
+            q.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(out[i].view(np.uint32), out[0].view(np.uint32))
+    common.compare_images(out[0], want, p, "N=1820, four handles at once", mean_line=mean)
+    assert probe.rtc_status()["compiled_in_process"] - before == 1  # the probe instance IS the one the buffers ran (uint16, cubic, log)
+    probe.close(); o.close()
+
+
+def test_a_failed_run_time_compilation_is_reported_and_survivable():
+    """csrc/mixedn_rtc.hip: (1) a handle whose probe instance does not compile keeps its other HIP route for the length and says why
+    (octpipe_debug_rtc_status) -- its images are still the oracle's; (2) once a handle HAS a run-time compiled kernel, an instance that
+    fails later is an error of that call (OCTPIPE_ERR_DEVICE with the compiler's log), never a silent change of route; (3) the failure
+    is cached per option string: with the options gone the same process compiles and runs the instance."""
+    import ctypes as C
+    import torch
+    import common
+    L = _lib.lib()
+    N, A, B = 1200, 20, 2
+    p = v180_benchmark_params(N, A, B)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=12)
+    d = torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).to("cuda:0")
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    try:
+        L.octpipe_debug_rtc_set_options(b"-DOCT_MXS_LUT_AHEAD=not_a_number")
+        broken = Pipeline(p, device=0)  # (1)
+        broken.set_mean_line(o.mean_line(), pin=True)
+        broken.process_device(d.data_ptr()); broken.synchronize()
+        st = broken.rtc_status()
+        assert not st["uses_it"] and "hiprtcCompileProgram failed" in st["message"] and "not_a_number" in st["message"], st
+        assert broken.last_path() & _lib.PATH_MIXED_RADIX and not broken.last_path() & _lib.PATH_STATIC_PLAN
+        common.compare_images(broken.processed_host(), want, p, "N=1200 without its run-time compiled kernel", mean_line=o.mean_line())
+        broken.close()
+        L.octpipe_debug_rtc_set_options(None)
+        good = Pipeline(p, device=0)  # probe: cubic, log scale
+        good.set_mean_line(o.mean_line(), pin=True)
+        good.process_device(d.data_ptr()); good.synchronize()
+        assert good.last_path() & _lib.PATH_STATIC_PLAN, good.rtc_status()
+        L.octpipe_debug_rtc_set_options(b"-DOCT_MXS_LUT_AHEAD=not_a_number")
+        with pytest.raises(RuntimeError) as err:  # (2) every instance is looked up under the current options: this one cannot be built
+            good.process_device(d.data_ptr())
+        assert "run-time compilation" in str(err.value) and "not_a_number" in str(err.value), str(err.value)
+        L.octpipe_debug_rtc_set_options(None)
+        good.process_device(d.data_ptr()); good.synchronize()  # (3)
+        common.compare_images(good.processed_host(), want, p, "N=1200 after the failed call", mean_line=o.mean_line())
+        good.close()
+    finally:
+        L.octpipe_debug_rtc_set_options(None)
+    o.close()
+
+
 def test_device_work_inside_a_callback_is_refused_not_deadlocked():
     """callbacks run inside hipLaunchHostFunc: HIP calls are not allowed there and a wait for the stream that runs the callback would
     never return.  The library refuses every device-touching entry point on such a thread with OCTPIPE_ERR_IN_CALLBACK (7) -- found

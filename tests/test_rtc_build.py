@@ -36,7 +36,7 @@ needs_hiprtc = pytest.mark.skipif(not _hiprtc_present(), reason="libhiprtc.so is
 
 
 @needs_hiprtc
-@pytest.mark.parametrize("n,plan", [(1000, [10, 10, 10]), (2000, [20, 10, 10]), (1536, [16, 12, 8]), (3000, [20, 15, 10]), (4000, [20, 20, 10]),
+@pytest.mark.parametrize("n,plan", [(1000, [10, 10, 10]), (2000, [10, 20, 10]), (1536, [12, 16, 8]), (3000, [15, 20, 10]), (4000, [20, 20, 10]),
                                     (2500, [10, 5, 5, 10]), (2002, [13, 11, 14]), (130, [13, 10]), (24, [6, 4]), (5120, None), (5000, None)])
 def test_static_plan_kernel_compiles_for_gfx950_without_a_device(n, plan):
     rc, radices, waves, code, sec, err = _compile(n)
