@@ -212,8 +212,6 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out, bool oldLayout) {
 	return true;
 }
 
-bool mixedn_rtc_available(std::string* why) { return bindRtc(why); }
-
 // the build check of the run-time path, without a device: compile the instance of a length for `arch`
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why) {
 	std::vector<char> code;
