@@ -84,6 +84,15 @@ def draw(seed, lengths=LENGTHS, offset=1000):
     elif container == "u8":  # bitDepth <= 8: one byte per sample (cu:109-118)
         p.bitDepth = 8
         raw = (raw >> 4).astype(np.uint8)
+        if not p.signalLogScaling:
+            # 8-bit samples are 16 times smaller than the 12-bit ones the grey-scale range of the linear draws (0 .. 900) is chosen for.
+            # With an addend of -0.25 the float32 IMAGE then carries the amplitude in its last ~12 bits: one ulp of the image (3e-8
+            # at 0.25) is 3.5e-6 of the line's largest amplitude, and the two sides' grey-scale arithmetic (one FMA with folded
+            # constants here, the reference's four roundings in the oracle) legitimately differ by a few ulps -- 1.0e-5 and 1.4e-5 on two
+            # of 300 draws at N = 48 / 130, IDENTICAL on all four transform routes (static plan, run-time plan, hipFFT, Bluestein:
+            # profiles/r4ah_fuzz_image_quantisation.txt).  That is a property of the float32 image, not of a kernel: the draw scales
+            # the range with the samples so that the image resolves the amplitude like the other containers' do.
+            p.signalGrayscaleMax = 900.0 / 16.0
     elif container == "u32":  # bitDepth > 16: four bytes per sample
         p.bitDepth = 24
         raw = raw.astype(np.uint32) * 256
