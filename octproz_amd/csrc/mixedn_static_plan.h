@@ -49,7 +49,7 @@ constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bo
 #ifdef OCT_MXS_WCAP
 	const int cap = OCT_MXS_WCAP;
 #else
-	const int v = pd_values(d) + (rs == RS_CUBIC ? 8 : rs == RS_LANCZOS ? 16 : 0) + (roll ? 4 : 0) + (pair ? 4 : 0);
+	const int v = pd_values(d) + (rs == RS_CUBIC ? 8 : rs == RS_LANCZOS ? 8 : 0) + (roll ? 4 : 0) + (pair ? 4 : 0);
 	// (N = 2000 linear, 40 values at 9 waves = 168 registers: 119 M against 201 M at 8 waves -- 12 waves only up to 32 values held)
 	const int cap = v <= 24 ? 16 : (v <= 40 && pd_values(d) <= 32) ? 12 : v <= 52 ? 8 : 4;  // (4 waves: one per SIMD, 512 registers -- 60 values and more spill at 256)
 #endif
