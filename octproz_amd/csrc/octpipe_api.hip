@@ -1162,9 +1162,15 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT | OCTPIPE_ROUTE_NO_MIXEDN_STATIC)) && oct::mixedn_rtc_plan(acq->samplesPerLine, &h->mxsPlan, (createRoute & OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT) != 0)) {
 		oct::FusedArgs probe{};
 		std::string why;
+		// (the instance the first buffer will most likely run with the settings the handle is created with: resampling mode, scaling, two
+		// A-scans per transform without dispersion compensation; the rolling average and the background removal compile on first use)
+		const OctPipeParams& pp = h->params;
 		const bool plain16 = h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO;
-		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, plain16 ? oct::IN_U16 : oct::IN_F32, h->params.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC : oct::RS_LINEAR,
-		                                            false, false, false, true, probe, h->stream, &why);
+		const int prs = !pp.resampling ? oct::RS_NONE : pp.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC : pp.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS ? oct::RS_LANCZOS : oct::RS_LINEAR;
+		float lanczosDummy = 0.0f;
+		if (prs == oct::RS_LANCZOS) probe.lanczosW = &lanczosDummy;  // (a launch of zero A-scans: only its presence is checked)
+		const bool ppair = plain16 && !pp.dispersionCompensation && !pp.backgroundRemoval && prs != oct::RS_LANCZOS;
+		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, plain16 ? oct::IN_U16 : oct::IN_F32, prs, false, ppair, false, pp.signalLogScaling != 0, probe, h->stream, &why);
 		if (e == hipSuccess) {
 			std::vector<f2> tw;
 			oct::mixedn_static_twiddles(h->mxsPlan, tw);
