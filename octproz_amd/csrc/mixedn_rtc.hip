@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -94,7 +95,15 @@ Cache& cache() { static Cache c; return c; }
 bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, const std::string& extra, std::vector<char>& code, int* waves, double* seconds, std::string* why) {
 	if (!bindRtc(why)) return false;
 	const bool bg = (mode & MODE_BG) != 0, roll = (mode & MODE_ROLL) != 0, pair = (mode & mxs::MODE_PAIR) != 0;
-	const int W = mxs::pd_waves(d, bg, rs, roll, pair);
+	int W = mxs::pd_waves(d, bg, rs, roll, pair);
+	{   // (A/B switch -DOCT_MXS_WCAP=n among the extra options: the kernel's pd_waves then caps at n instead of the register rule; the host follows)
+		const size_t at = extra.find("-DOCT_MXS_WCAP=");
+		if (at != std::string::npos) {
+			const int cap = std::atoi(extra.c_str() + at + 15);
+			const int fit = (160 * 1024 - mxs::pd_tw_bytes(d) - (bg ? d.N * 2 : 0)) / mxs::pd_slice_bytes(d, roll, pair);
+			if (cap > 0) W = fit < cap ? fit : cap;
+		}
+	}
 	*waves = W;
 	if (W < 1) { *why = "one A-scan of this length does not fit the LDS"; return false; }
 	char src[1024];
