@@ -70,7 +70,7 @@ int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
  * seconds that took, and why the last attempt failed / why this handle keeps another route (empty: no failure). */
 int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int* compiledInProcess, double* compileSeconds, char* message, size_t messageBytes);
 /* Further compiler options for the instances compiled from now on (process-wide, blank-separated, NULL = none): the A/B switches
- * of csrc/mixedn_static.h, e.g. "-DOCT_MXS_PREFETCH=0 -DOCT_MXS_WCAP=8".  Instances are cached per option string. */
+ * of csrc/mixedn_static.h, e.g. "-DOCT_MXS_LUT_AHEAD=4 -DOCT_MXS_WCAP=8".  Instances are cached per option string. */
 int octpipe_debug_rtc_set_options(const char* extraOptions);
 /* The build check of that path without a device: plan samplesPerLine and compile the instance (intype 1 = uint16 rows, 3 = prepared
  * float32 rows; rs 0 none / 1 linear / 2 cubic; mode 2 spectrum, 4 log, 8 background removal in the store) for `arch` ("gfx950"). */

@@ -85,7 +85,7 @@ struct Cache {
 	std::mutex mtx;
 	std::map<Key, Instance> entries;
 	std::string lastMessage;
-	std::string extraOptions;  // octpipe_debug_rtc_set_options: further compiler options (A/B switches like -DOCT_MXS_PREFETCH=0), separated by blanks
+	std::string extraOptions;  // octpipe_debug_rtc_set_options: further compiler options (A/B switches like -DOCT_MXS_LUT_AHEAD=4), separated by blanks
 	int compiled = 0;
 	double compileSeconds = 0.0;
 };

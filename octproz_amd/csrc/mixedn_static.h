@@ -13,7 +13,11 @@
 // Exchange layout: element j at j + j / R_0 when the plan starts with 8 or 16 (the first pass writes a butterfly's R_0 outputs
 // contiguously: the lane stride R_0 + 1 is odd, conflict-free; NB_p and NS_p are multiples of R_0 for p >= 1, so j / R_0 splits into a
 // per-lane part and a constant); plain j otherwise (mixedn_static_plan.h: the other radices write without or with two-way conflicts,
-// and the unit-stride reads of the later passes stay free of holes).  The last pass' outputs are the bins b + u NB: those below N / 2 go through the epilogue to HBM.
+// and the unit-stride reads of the later passes stay free of holes).  The last pass' outputs are the bins b + u NB: those below N / 2
+// go through the epilogue to HBM.
+// Modes (template parameters, one run-time compiled instance each): raw uint16 or prepared float32 rows; no / linear / cubic /
+// Lanczos resampling; spectrum output; log / linear scaling; post-process background removal in the store; the rolling average
+// inside the kernel (MODE_ROLL); two A-scans per transform when the FFT input is real (MODE_PAIR).
 #pragma once
 #include "mixedn_kernel.h"
 #include "mixedn_static_plan.h"
