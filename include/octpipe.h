@@ -174,6 +174,12 @@ int octpipe_destroy(octpipe_t* h);
  * call destroys every idle set now -- e.g. before the host application resets the device.  Sets the runtime no longer
  * recognises (hipStreamQuery fails) are never handed out. */
 int octpipe_release_idle_streams(void);
+/* A-scan lengths without a dedicated kernel get a kernel compiled FOR the length at run time (0.5-1.2 s per variant, once per
+ * process and device).  By default nothing is written to disk.  With a directory set here the compiled code
+ * objects are also kept there -- one file per (kernel sources, options, architecture, plan, variant), written atomically,
+ * a few tens of KiB each -- and the next process loads them instead of compiling.  NULL or "" switches the directory off
+ * again.  Process-wide; the directory must exist.  (No reference counterpart: cufftPlan1d keeps its plans in memory.) */
+int octpipe_set_kernel_cache_dir(const char* directory);
 /* parameter snapshot taken per call in the reference (params-> reads in cu:1409-1604) */
 int octpipe_set_params(octpipe_t* h, const OctPipeParams* params);
 int octpipe_get_acquisition_params(const octpipe_t* h, OctPipeAcquisitionParams* out);

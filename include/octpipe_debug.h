@@ -69,6 +69,8 @@ int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
  * the handle's length does (h may be NULL), its plan (five radices, 0 = unused), how many instances the process has compiled, the
  * seconds that took, and why the last attempt failed / why this handle keeps another route (empty: no failure). */
 int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int* compiledInProcess, double* compileSeconds, char* message, size_t messageBytes);
+/* how many instances this process took from the directory of octpipe_set_kernel_cache_dir instead of compiling them */
+int octpipe_debug_rtc_disk_hits(int* hits);
 /* Further compiler options for the instances compiled from now on (process-wide, blank-separated, NULL = none): the A/B switches
  * of csrc/mixedn_static.h, e.g. "-DOCT_MXS_LUT_AHEAD=4 -DOCT_MXS_WCAP=8".  Instances are cached per option string. */
 int octpipe_debug_rtc_set_options(const char* extraOptions);

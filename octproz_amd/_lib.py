@@ -119,7 +119,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_calibration_size", "octpipe_export_calibration", "octpipe_import_calibration",
     "octpipe_process", "octpipe_process_async", "octpipe_wait_input", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
-    "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_release_idle_streams",
+    "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_release_idle_streams", "octpipe_set_kernel_cache_dir",
     "octpipe_register_streaming_buffers", "octpipe_unregister_streaming_buffers",
     "octpipe_register_float_streaming_buffers", "octpipe_unregister_float_streaming_buffers",
     "octpipe_set_callbacks",
@@ -136,7 +136,7 @@ OCTPIPE_SYMBOLS = [
 ]
 OCTPIPE_DEBUG_SYMBOLS = [
     "octpipe_debug_spectrum", "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_create",
-    "octpipe_debug_read_raw_slot", "octpipe_debug_last_grid", "octpipe_debug_last_path", "octpipe_debug_rtc_status", "octpipe_debug_rtc_compile", "octpipe_debug_rtc_set_options",
+    "octpipe_debug_read_raw_slot", "octpipe_debug_last_grid", "octpipe_debug_last_path", "octpipe_debug_rtc_status", "octpipe_debug_rtc_compile", "octpipe_debug_rtc_set_options", "octpipe_debug_rtc_disk_hits",
 ]
 OCTHOST_SYMBOLS = [
     "octhost_buffer_create", "octhost_buffer_destroy", "octhost_buffer_allocate", "octhost_buffer_release",

@@ -14,6 +14,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <unistd.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -85,6 +87,8 @@ struct Cache {
 	std::mutex mtx;
 	std::map<Key, Instance> entries;
 	std::string lastMessage;
+	std::string diskDir;       // octpipe_set_kernel_cache_dir: compiled code objects are kept here too ("" = nowhere)
+	int diskHits = 0;
 	std::string extraOptions;  // octpipe_debug_rtc_set_options: further compiler options (A/B switches like -DOCT_MXS_LUT_AHEAD=4), separated by blanks
 	int compiled = 0;
 	double compileSeconds = 0.0;
@@ -93,7 +97,6 @@ Cache& cache() { static Cache c; return c; }
 
 // source -> code object for `arch` (no device needed); waves = the launch shape compiled in
 bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, const std::string& extra, std::vector<char>& code, int* waves, double* seconds, std::string* why) {
-	if (!bindRtc(why)) return false;
 	const bool bg = (mode & MODE_BG) != 0, roll = (mode & MODE_ROLL) != 0, pair = (mode & mxs::MODE_PAIR) != 0;
 	int W = mxs::pd_waves(d, bg, rs, roll, pair);
 	{   // (A/B switch -DOCT_MXS_WCAP=n among the extra options: the kernel's pd_waves then caps at n instead of the register rule; the host follows)
@@ -120,6 +123,33 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	              bg ? "true" : "false", rs, roll ? "true" : "false", pair ? "true" : "false", mxs::pd_lds_bytes(d, W, bg, roll, pair), intype, rs, mode);
 	const char* names[] = {"kernels.h", "fft_regs.h", "mixedn_kernel.h", "mixedn_static.h", "mixedn_static_plan.h"};
 	const char* texts[] = {oct_rtc_src_kernels_h, oct_rtc_src_fft_regs_h, oct_rtc_src_mixedn_kernel_h, oct_rtc_src_mixedn_static_h, oct_rtc_src_mixedn_static_plan_h};
+	// on-disk cache (opt-in): the file name is a hash of everything the code object depends on
+	std::string diskFile;
+	if (!cache().diskDir.empty()) {
+		uint64_t hsh = 1469598103934665603ull;
+		auto mix = [&](const char* t) { for (; *t; ++t) { hsh ^= (unsigned char)*t; hsh *= 1099511628211ull; } hsh ^= 0xffu; hsh *= 1099511628211ull; };
+		mix(src); mix(arch); mix(extra.c_str());
+		for (const char* t : texts) mix(t);
+		char name[64];
+		std::snprintf(name, sizeof name, "/oct_mxs_%016llx.co", (unsigned long long)hsh);
+		diskFile = cache().diskDir + name;
+		if (FILE* f = std::fopen(diskFile.c_str(), "rb")) {
+			std::fseek(f, 0, SEEK_END);
+			const long n = std::ftell(f);
+			std::fseek(f, 0, SEEK_SET);
+			bool ok = n > 64;
+			if (ok) { code.resize((size_t)n); ok = std::fread(code.data(), 1, (size_t)n, f) == (size_t)n && std::memcmp(code.data(), "\x7f" "ELF", 4) == 0; }
+			if (ok) {  // whole: the ELF64 section header table (e_shoff, e_shentsize, e_shnum) lies inside the file
+				uint64_t shoff = 0; uint16_t shentsize = 0, shnum = 0;
+				std::memcpy(&shoff, code.data() + 0x28, 8); std::memcpy(&shentsize, code.data() + 0x3A, 2); std::memcpy(&shnum, code.data() + 0x3C, 2);
+				ok = shoff > 0 && shoff + (uint64_t)shentsize * shnum <= (uint64_t)n;
+			}
+			std::fclose(f);
+			if (ok) { cache().diskHits++; if (seconds) *seconds = 0.0; return true; }
+			code.clear();  // (a truncated or foreign file: compile, and overwrite it below)
+		}
+	}
+	if (!bindRtc(why)) return false;
 	Rtc& r = rtc();
 	rtcProgram prog = nullptr;
 	if (r.createProgram(&prog, src, "oct_mxs.hip", 5, texts, names) != 0) { *why = "hiprtcCreateProgram failed"; return false; }
@@ -151,6 +181,14 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	code.resize(cs);
 	r.getCode(prog, code.data());
 	r.destroyProgram(&prog);
+	if (!diskFile.empty()) {  // written under a temporary name and renamed: a reader never sees half a file
+		const std::string tmp = diskFile + ".tmp" + std::to_string((long long)getpid());
+		if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+			const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+			std::fclose(f);
+			if (!ok || std::rename(tmp.c_str(), diskFile.c_str()) != 0) std::remove(tmp.c_str());
+		}
+	}
 	return true;
 }
 
@@ -280,6 +318,18 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 	FusedArgs args = a;
 	void* params[] = {&args};
 	return hipModuleLaunchKernel(in->fn, blocks, 1, 1, (unsigned)in->waves * 64u, 1, 1, 0, stream, params, nullptr);
+}
+
+void mixedn_rtc_set_cache_dir(const char* dir) {
+	Cache& c = cache();
+	std::lock_guard<std::mutex> lock(c.mtx);
+	c.diskDir = dir ? dir : "";
+	while (c.diskDir.size() > 1 && c.diskDir.back() == '/') c.diskDir.pop_back();
+}
+int mixedn_rtc_disk_hits() {
+	Cache& c = cache();
+	std::lock_guard<std::mutex> lock(c.mtx);
+	return c.diskHits;
 }
 
 void mixedn_rtc_set_options(const char* extra) {

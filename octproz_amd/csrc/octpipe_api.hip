@@ -6,6 +6,7 @@
 // of exit(EXIT_FAILURE) (helper_cuda.h:583-590).  There is no CPU fallback: without a HIP device
 // octpipe_create fails with OCTPIPE_ERR_NO_DEVICE.
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -1567,6 +1568,19 @@ int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int
 		if (!h->mixedStatic && !h->rtcMessage.empty()) last = h->rtcMessage;
 	}
 	if (message && messageBytes) std::snprintf(message, messageBytes, "%s", last.c_str());
+	return OCTPIPE_OK;
+}
+int octpipe_set_kernel_cache_dir(const char* directory) {
+	if (directory && *directory) {
+		struct stat st;
+		if (stat(directory, &st) != 0 || !S_ISDIR(st.st_mode)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, std::string("not a directory: ") + directory);
+	}
+	oct::mixedn_rtc_set_cache_dir(directory);
+	return OCTPIPE_OK;
+}
+int octpipe_debug_rtc_disk_hits(int* hits) {
+	if (!hits) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	*hits = oct::mixedn_rtc_disk_hits();
 	return OCTPIPE_OK;
 }
 int octpipe_debug_rtc_set_options(const char* extraOptions) {

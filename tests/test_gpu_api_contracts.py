@@ -308,6 +308,38 @@ def test_handles_created_concurrently_share_one_run_time_compilation():
     probe.close(); o.close()
 
 
+def test_run_time_compiled_kernel_loaded_from_the_disk_cache_gives_the_same_image(tmp_path):
+    """octpipe_set_kernel_cache_dir on the GPU box: a child process compiles the instances of N = 1400 into the directory, a second
+    child loads them (no compilation) -- both images equal bit for bit"""
+    code = r"""
+import sys, ctypes as C, numpy as np, torch, zlib
+from octproz_amd import Pipeline, _lib, synthetic_raw, v180_benchmark_params
+L = _lib.lib()
+assert L.octpipe_set_kernel_cache_dir(sys.argv[1].encode()) == 0
+N, A, B = 1400, 20, 2
+p = v180_benchmark_params(N, A, B); p.update_all_curves()
+raw = synthetic_raw(N, A, B, seed=9)
+d = torch.from_numpy(raw.view(np.uint8).reshape(-1)).to("cuda:0"); torch.cuda.synchronize()
+q = Pipeline(p, device=0)
+q.process_device(d.data_ptr()); q.synchronize()
+assert q.last_path() & _lib.PATH_STATIC_PLAN, q.rtc_status()
+hits = C.c_int(0); L.octpipe_debug_rtc_disk_hits(C.byref(hits))
+st = q.rtc_status()
+print("RESULT", zlib.crc32(q.processed_host().tobytes()), hits.value, st["compiled_in_process"], "%.3f" % st["compile_seconds"])
+q.close()
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    runs = []
+    for k in range(2):
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+        runs.append((int(line[1]), int(line[2]), int(line[3]), float(line[4])))
+    (crc0, hits0, n0, sec0), (crc1, hits1, n1, sec1) = runs
+    assert crc0 == crc1 and hits0 == 0 and sec0 > 0.0 and hits1 == n1 >= 2 and sec1 == 0.0, runs
+    assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".co")]) == n0
+
+
 def test_a_failed_run_time_compilation_is_reported_and_survivable():
     """csrc/mixedn_rtc.hip: (1) a handle whose probe instance does not compile keeps its other HIP route for the length and says why
     (octpipe_debug_rtc_status) -- its images are still the oracle's; (2) once a handle HAS a run-time compiled kernel, an instance that

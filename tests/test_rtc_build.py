@@ -94,3 +94,42 @@ def test_lengths_without_a_static_plan_are_refused(n):
     """2 x 617, 2 x 23 x 89: a prime factor above 13; odd lengths (N / 2 bins); beyond 5120 / the registers of one wave"""
     rc, radices, waves, code, sec, err = _compile(n)
     assert rc == 5 and "no static plan" in err, (rc, err)  # OCTPIPE_ERR_UNSUPPORTED
+
+
+@needs_hiprtc
+def test_opt_in_disk_cache_of_compiled_kernels(tmp_path):
+    """octpipe_set_kernel_cache_dir: off by default (nothing is written anywhere); with a directory the code object of an instance
+    is written there atomically under a name that hashes everything it depends on (kernel sources, options, architecture, plan,
+    variant) and the next compilation of the same instance -- here: the device-less build check, which has no in-memory cache --
+    loads it; a truncated file is recompiled and overwritten; a different variant gets its own file"""
+    import os
+    L = _lib.lib()
+    L.octpipe_last_error.restype = C.c_char_p
+    hits = C.c_int(0)
+
+    def nhits():
+        assert L.octpipe_debug_rtc_disk_hits(C.byref(hits)) == 0
+        return hits.value
+
+    assert L.octpipe_set_kernel_cache_dir(b"/nonexistent/dir") == 1 and b"not a directory" in L.octpipe_last_error()
+    d = str(tmp_path)
+    try:
+        assert L.octpipe_set_kernel_cache_dir(d.encode()) == 0
+        h0 = nhits()
+        rc, radices, waves, code, sec, err = _compile(1260)
+        assert rc == 0 and sec > 0.0, err
+        files = os.listdir(d)
+        assert len(files) == 1 and files[0].startswith("oct_mxs_") and files[0].endswith(".co") and os.path.getsize(os.path.join(d, files[0])) == code
+        rc, radices, waves, code2, sec2, err = _compile(1260)
+        assert rc == 0 and code2 == code and sec2 == 0.0 and nhits() == h0 + 1  # loaded, not compiled
+        with open(os.path.join(d, files[0]), "r+b") as f:
+            f.truncate(100)
+        rc, radices, waves, code3, sec3, err = _compile(1260)
+        assert rc == 0 and code3 == code and sec3 > 0.0 and nhits() == h0 + 1 and os.path.getsize(os.path.join(d, files[0])) == code
+        rc, radices, waves, code4, sec4, err = _compile(1260, IN_U16, RS_LINEAR, MODE_LOG)
+        assert rc == 0 and sec4 > 0.0 and len(os.listdir(d)) == 2
+    finally:
+        assert L.octpipe_set_kernel_cache_dir(None) == 0
+    n = len(os.listdir(d))
+    _compile(1260, IN_U16, RS_NONE, MODE_LOG)
+    assert len(os.listdir(d)) == n  # switched off again: nothing is written
