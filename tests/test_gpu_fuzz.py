@@ -114,7 +114,11 @@ def test_random_setting_combination_matches_oracle(seed):
     _check_draw(*draw(seed))
 
 
-RTC_LENGTHS = [1000, 1200, 1536, 2000, 130, 48, 1000, 2500]  # no dedicated kernel: compiled at run time (mixedn_static.h), or the run-time plan
+# no dedicated kernel: compiled at run time (mixedn_static.h), or the run-time plan.  (N = 48 -- 24 bins per line -- was drawn here at
+# first: one depth bin that the mean-line subtraction cancels on most lines is 3-4 % of such a buffer, over the 2 % the 'cancelled'
+# rule allows (seed 426 of a 1500-seed run, profiles/r4ap_fuzz_1500.txt); the rule's fraction presumes hundreds of bins per line.
+# The short lengths have their deterministic cases in test_gpu_parity.py.)
+RTC_LENGTHS = [1000, 1200, 1536, 2000, 130, 182, 1000, 2500]
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SEEDS", "96")) // 3))
