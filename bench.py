@@ -54,6 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--volumes", type=int, default=4, help="distinct raw buffers rotated (1 GiB > the 256 MiB Infinity Cache)")
     ap.add_argument("--out-slots", type=int, default=4, help="processed-buffer slots rotated (buffersPerVolume; 1 GiB of output > Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--route", type=int, default=0, help="OCTPIPE_ROUTE_* flags for the handle (include/octpipe_debug.h): same-box A/B of two routes, e.g. 4096 = display frames by the extraction kernel")
+    ap.add_argument("--blocks", type=int, default=8, help="after the timed region: this many more blocks of --steps steps, alternately with and without the per-launch HIP events, "
+                    "reported as medians next to the contract's single timed block (a 20-step block is 3 ms: box noise is +-2-4 %%)")
     ap.add_argument("--no-extras", action="store_true", help="skip the host_loop, real_input and rolling_average records (A/B runs, profiler passes)")
     ap.add_argument("--host-loop-seconds", type=float, default=3.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
@@ -233,7 +236,8 @@ def measure_traffic(args, kernel_name, timeout=170.0):
         tmp = tempfile.mkdtemp(prefix="octbench_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
                "--steps", "4", "--warmup", "1", "--warmup-seconds", "0", "--no-cpu-baseline", "--no-extras", "--no-traffic",
-               "--samples", str(args.samples), "--ascans", str(args.ascans), "--bscans", str(args.bscans), "--volumes", "2", "--out-slots", "2"]
+               "--samples", str(args.samples), "--ascans", str(args.ascans), "--bscans", str(args.bscans), "--volumes", "2", "--out-slots", "2",
+               "--blocks", "0", "--route", str(args.route)]
         if args.total_bscans:
             cmd += ["--total-bscans", str(args.total_bscans)]
         env = dict(os.environ, TMPDIR="/tmp")
@@ -320,6 +324,35 @@ def timed_run(pipe, vols, steps, warmup, warmup_seconds, barrier=None):
     kernel_ms, launches = pipe.kernel_timing(reset=True)
     pipe.enable_kernel_timing(False)
     return dt, kernel_ms, launches
+
+
+def more_blocks(pipe, vols, steps, blocks):
+    """`blocks` more blocks of `steps` steps right behind the timed region, alternately WITH the per-launch HIP events (as in the
+    timed region) and WITHOUT them: the median step time of each kind and the median kernel time.  The events are two more packets
+    per step on the stream; the difference is what the measurement itself costs."""
+    import statistics
+    import torch
+    res = {True: [], False: []}
+    kms = []
+    i = 0
+    for b in range(blocks):
+        ev = b % 2 == 0
+        pipe.enable_kernel_timing(ev)
+        pipe.kernel_timing(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            pipe.process_device(vols[(i + k) % len(vols)].data_ptr(), sync_params=False)
+        torch.cuda.synchronize()
+        res[ev].append((time.perf_counter() - t0) / steps * 1e3)
+        if ev:
+            kms.append(pipe.kernel_timing(reset=True)[0])
+        i += steps
+    pipe.enable_kernel_timing(False)
+    med = lambda v: statistics.median(v) if v else None
+    return {"blocks": blocks, "steps_per_block": steps, "ms_per_step_with_events": {"median": med(res[True]), "min": min(res[True], default=None), "max": max(res[True], default=None)},
+            "ms_per_step_without_events": {"median": med(res[False]), "min": min(res[False], default=None), "max": max(res[False], default=None)},
+            "kernel_ms_median": med(kms)}
 
 
 def host_loop_record(p, vols, seconds):
@@ -443,7 +476,7 @@ def main():
     if strong:  # a slab is >= 256 MiB (> the Infinity Cache) on its own from 256 B-scans up: two of each are enough
         n_vols, slots = min(n_vols, 2), min(slots, 2)
     p = v180_benchmark_params(N, A, B, buffers_per_volume=slots)
-    pipe = Pipeline(p, device=local_rank)
+    pipe = Pipeline(p, device=local_rank, route=args.route)
     pre = preflight(rank, local_rank, local_rank)
     pre["slab"] = [first_bscan, B]
 
@@ -468,6 +501,7 @@ def main():
 
     dt, kernel_ms, launches = timed_run(pipe, vols, args.steps, args.warmup, args.warmup_seconds,
                                         barrier=dist.barrier if distributed else None)
+    blocks = more_blocks(pipe, vols, args.steps, args.blocks) if (rank == 0 and ranks == 1 and args.blocks > 0) else None
     kernel_ms_ranks = [kernel_ms]
     pre_all, bscans_all = [pre], [B]
     if distributed:
@@ -488,8 +522,11 @@ def main():
         value = ascans_total / dt
         alg_bytes = 4.0 * N * A * B  # 2N B in (uint16) + 4*(N/2) B out (float32) per A-scan; rank 0's launch
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        kernel_name = {256: "oct_fused_kernel<8, 1, 2, 4>", 512: "oct_fused_kernel<9, 1, 2, 4>", 1024: "oct_fused_kernel<10, 1, 2, 4>",
-                       2048: "oct_fused_kernel<11, 1, 2, 4>", 4096: "oct_team_kernel<12, 1, 2, 4>", 8192: "oct_team_kernel<13, 1, 2, 4>",
+        # (MODE 4 = log scaling; 20 = log scaling + the display frames written by the image store, PATH_FUSED_DISPLAY)
+        from octproz_amd import _lib as _l
+        mode = 20 if pipe.last_path() & _l.PATH_FUSED_DISPLAY else 4
+        kernel_name = {256: "oct_fused_kernel<8, 1, 2, %d>" % mode, 512: "oct_fused_kernel<9, 1, 2, %d>" % mode, 1024: "oct_fused_kernel<10, 1, 2, %d>" % mode,
+                       2048: "oct_fused_kernel<11, 1, 2, %d>" % mode, 4096: "oct_team_kernel<12, 1, 2, 4>", 8192: "oct_team_kernel<13, 1, 2, 4>",
                        1664: "oct_team1664_kernel<1, 2, 4>"}.get(N, "gather -> hipFFT -> epilogue (library route)")
         single_kernel = N in (256, 512, 1024, 2048, 4096, 8192, 1664)
         if not single_kernel:  # lengths without a dedicated kernel: which route the handle took (include/octpipe_debug.h OCTPIPE_PATH_*)
@@ -517,7 +554,12 @@ def main():
                        "distinct_input_buffers": len(vols), "output_slots_rotated": slots,
                        "warmup_seconds": args.warmup_seconds, "parallelism": "bscan-slab x%d" % ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # the same algorithmic bytes over the STEP time (rank 0's slab / ms_per_step): `frac` is the kernel's clock,
+                         # `value` the step's -- both stated, and what lies between them (other launches + dependent-launch gaps)
+                         "frac_step": alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "step_minus_kernel_us": (dt / args.steps * 1e3 - kernel_ms) * 1e3,
+                         "traffic": None, "traffic_source": None,
                          "kernel": kernel_name,
                          "kernel_ms": kernel_ms,
                          "kernel_ms_per_rank": {"min": min(kernel_ms_ranks), "max": max(kernel_ms_ranks), "ranks": kernel_ms_ranks},
@@ -531,6 +573,14 @@ def main():
                                               "no skeleton study for this length"},
             "preflight": pre_all,
         }
+        if blocks:
+            out["repeated_blocks"] = blocks
+            if blocks["ms_per_step_without_events"]["median"]:
+                out["repeated_blocks"]["value_median_without_events"] = A * B / (blocks["ms_per_step_without_events"]["median"] * 1e-3)
+            if blocks["ms_per_step_with_events"]["median"]:
+                out["repeated_blocks"]["value_median_with_events"] = A * B / (blocks["ms_per_step_with_events"]["median"] * 1e-3)
+        if args.route:
+            out["config"]["route_flags"] = args.route
         if kernel_name == "oct_mxs":
             st = pipe.rtc_status()
             out["config"]["run_time_compiled_plan"] = " x ".join(map(str, st["radices"]))

@@ -36,8 +36,9 @@ enum {
 	OCTPIPE_ROUTE_NO_MIXEDN     = 128, /* lengths with a generic mixed-radix plan (1000, 1536, 2000 ...): keep the library route / Bluestein */
 	OCTPIPE_ROUTE_NO_MIXEDN_STATIC = 512, /* keep the run-time-plan kernel (mixedn_kernel.h) where a kernel compiled for the length exists (mixedn_static.h) */
 	OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT = 2048, /* creation: the run-time compiled kernel with its first plan order and exchange layout (largest radix first, always padded) */
-	OCTPIPE_ROUTE_TINY_GRID = 1024,    /* the run-time compiled kernel on TWO persistent workgroups: every wave loops over many A-scans even of a small test buffer */
-	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256 /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
+	OCTPIPE_ROUTE_TINY_GRID = 1024,    /* the run-time compiled kernel and the general fused kernel on TWO persistent workgroups: every wave loops over many A-scans even of a small test buffer */
+	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256, /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
+	OCTPIPE_ROUTE_NO_FUSED_DISPLAY = 4096 /* display frames always by oct_display_frames_kernel (cu:1571-1578 as launches of their own), never by the fused kernel's image store */
 };
 int octpipe_debug_set_route(octpipe_t* h, unsigned flags);
 /* octpipe_create_with_format with OCTPIPE_ROUTE_* flags from the start (the creation-time ones select the FFT backend) */
@@ -61,7 +62,8 @@ enum {
 	OCTPIPE_PATH_ROLL_IN_KERNEL = 32, /* rolling average inside the transform kernel */
 	OCTPIPE_PATH_MIXED_RADIX   = 64,  /* mixed1664.h / mixed1664_real2.h, mixedn_kernel.h */
 	OCTPIPE_PATH_BLUESTEIN     = 128,
-	OCTPIPE_PATH_STATIC_PLAN   = 256  /* with MIXED_RADIX: the kernel compiled for this length (mixedn_static.h) instead of the run-time plan */
+	OCTPIPE_PATH_STATIC_PLAN   = 256, /* with MIXED_RADIX: the kernel compiled for this length (mixedn_static.h) instead of the run-time plan */
+	OCTPIPE_PATH_FUSED_DISPLAY = 512  /* the display frames (one frame per view) written by the image store of the fused kernel */
 };
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
 

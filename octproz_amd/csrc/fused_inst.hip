@@ -36,7 +36,7 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
 	if (blocksUsed) *blocksUsed = (int)blocks;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, a);
+	launch_fused_args(kernel, dim3(blocks), dim3(threads), lds, stream, a);
 	return hipGetLastError();
 }
 
@@ -46,6 +46,11 @@ hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, 
 	if (spectrum) return launch_one<INTYPE, RS, ROLLBIT | MODE_SPECTRUM>(a, rb, st, bu);
 	// post-process background removal inside the image store (a.bgTerm set): every container, with or without the in-kernel
 	// rolling average
+	// display frames written by the image store (a.dispBscan / a.dispEnFace set: one frame each, cu:810-912 with displayFunctionFrames <= 1)
+	if (a.dispBscan || a.dispEnFace) {
+		if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_BG | MODE_DISP>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_BG | MODE_DISP>(a, rb, st, bu);
+		return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_DISP>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_DISP>(a, rb, st, bu);
+	}
 	if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_BG>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_BG>(a, rb, st, bu);
 	if (logScale) return launch_one<INTYPE, RS, ROLLBIT | MODE_LOG>(a, rb, st, bu);
 	return launch_one<INTYPE, RS, ROLLBIT>(a, rb, st, bu);
@@ -146,7 +151,7 @@ hipError_t launch_real2n_one(const FusedArgs& a, hipStream_t stream) {
 	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(waves * 64), lds, stream, a);
+	launch_fused_args(kernel, dim3(blocks), dim3(waves * 64), lds, stream, a);
 	return hipGetLastError();
 }
 template <int RS>

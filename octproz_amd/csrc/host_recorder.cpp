@@ -81,7 +81,7 @@ int octhost_recorder_init(octhost_recorder_t* r, const OctHostRecordingParams* p
 	r->bytesWritten = 0;
 	struct stat st;
 	if (!p->savePath || !p->savePath[0] || stat(p->savePath, &st) != 0 || !S_ISDIR(st.st_mode))
-		return recFail(r, "recorder not armed: the save path is empty or not a directory");
+		return recFail(r, "Recording not initialized: save path is empty or invalid.");  // the reference's message, recorder.cpp:69
 	if (p->bufferSizeInBytes == 0 || p->buffersToRecord == 0) return recFail(r, "recorder not armed: zero buffers or zero bytes per buffer requested");
 	r->bytesPerBuffer = p->bufferSizeInBytes;
 	r->wanted = p->buffersToRecord;

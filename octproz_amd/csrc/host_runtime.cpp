@@ -311,7 +311,7 @@ void octhost_buffer_set_curr_index(octhost_buffer_t* b, int i) { if (b) b->currI
 
 octhost_system_t* octhost_virtual_system_create(const OctHostVirtualParams* p) {
 	if (!p || !p->filePath || std::strlen(p->filePath) < 2) {  // "No file selected", virtualoctsystem.cpp:141-144
-		hostFail("no file selected for the virtual OCT system");
+		hostFail("No file selected for virtual OCT system.");  // the reference's message, virtualoctsystem.cpp:143
 		return nullptr;
 	}
 	octhost_system* s = makeSystem(p);
@@ -356,7 +356,7 @@ int octhost_system_start(octhost_system_t* s) {
 	while (!s->started.load()) std::this_thread::yield();
 	if (s->failed.load()) {
 		s->thread.join();
-		return hostFail("unable to open file for the virtual OCT system");
+		return hostFail("Unable to open file for virtual OCT system!");  // virtualoctsystem.cpp:150
 	}
 	return OCTPIPE_OK;
 }

@@ -49,6 +49,18 @@ struct FusedArgs {
 	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
 	const float* lanczosW;   // RS_LANCZOS: [N][16] tap weights L(rho_j - (n0_j + i)), i = -7..8 (cu:297-326), the same for every A-scan
 	const float* bgTerm;     // [N/2] weight * background + offset, or nullptr: post-process background removal inside the image store
+	// [N] the four Catmull-Rom tap weights of every sample index (cu:258-271 as weights of the taps, float64 -> float32;
+	// oct_tap_weights_kernel once per curve): the cubic variants of oct_fused_kernel read them instead of evaluating the
+	// polynomial in float64 in every workgroup's prologue
+	const float4* cubicW;
+	// MODE_DISP: the two display frames in the reference's default form (ONE frame each, no averaging / MIP: cu:810-912 with
+	// displayFunctionFrames <= 1) are written by the image store itself -- every pixel of them is a copy of one value of the
+	// volume this launch writes.  nullptr = that view is off.
+	float* dispBscan;        // [A][N/2]: element (A N/2 - 1) - i = value i of the displayed B-scan (cu:858: reversed)
+	float* dispEnFace;       // [B-scans per volume x A]: element dispEnFaceLast - r = bin dispEnFaceBin of buffer-local output row r (cu:909)
+	unsigned dispBscanRow0;  // buffer-local output row of the first A-scan of the displayed B-scan; beyond the buffer: it lies in another buffer of the volume
+	unsigned dispEnFaceBin;
+	unsigned dispEnFaceLast;
 };
 
 // Per-length launch shape.  WAVES = A-scans in flight per workgroup; all waves of a workgroup share
@@ -195,13 +207,14 @@ template <int MODE, int N> constexpr int bg_lds_bytes() { return (MODE & 8 /* MO
 OCT_DEV void fill_bg_term(float* termL, const float* g, int n, int tid, int threads) {
 	for (int i = tid; i < n; i += threads) termL[i] = g[i];
 }
-template <bool BG> OCT_DEV void store_image(float v, __amdgpu_buffer_rsrc_t outR, const float* termL, int vbase, int c) {
+template <bool BG> OCT_DEV float store_image(float v, __amdgpu_buffer_rsrc_t outR, const float* termL, int vbase, int c) {
 	if constexpr (BG) {
 		const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(termL) + vbase + c);
 		v = v - t;
 		v = !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v);
 	}
 	buf_store32(v, outR, vbase, c);
+	return v;  // what the volume holds now (the display frames of MODE_DISP copy it)
 }
 
 // ------------------------------------------------------------------ raw chunk = SPL consecutive samples per lane
@@ -628,8 +641,22 @@ template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
 	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
 }
 
+// B-scan flip folded into the output row (cu:787-807): even buffer-local B-scans are mirrored; the reference's launch covers S/4
+// indices (cu:1547), so with an odd B-scan count the last one is left as it is
+OCT_DEV unsigned flipped_row(const FusedArgs& a, unsigned line) {
+	const unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
+	return ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) ? b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as) : line;
+}
+// MODE_DISP: the en-face values of a block of A-scans (lane k: A-scan first + k stride) go out with one store
+template <bool> OCT_DEV void ef_flush(const FusedArgs& a, float acc, unsigned first, unsigned stride, int lane, unsigned count) {
+	if ((unsigned)lane < count) {
+		const unsigned line = first + (unsigned)lane * stride;
+		a.dispEnFace[a.dispEnFaceLast - (a.flip ? flipped_row(a, line) : line)] = acc;
+	}
+}
+
 // MODE bits of the kernel template
-enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4, MODE_BG = 8 };
+enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4, MODE_BG = 8, MODE_DISP = 16 };
 
 // INTYPE: IN_U16 (raw, the hot configuration) or IN_F32 (samples prepared by oct_prepare_kernel:
 // uint8 / uint32 input and everything in front of the Lanczos variant).
@@ -682,11 +709,11 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			// lane+64(q+1) (q even) share a 16-byte unit [q/2][lane], so the gather fetches them with one ds_read_b128
 			wphL[CW ? (((i >> 7) << 6) + (i & 63)) * 2 + ((i >> 6) & 1) : i] = f2{t.y * t.z, t.y * t.w};
 			if constexpr (CW) {
-				// cu:258-271 as weights of the four taps, y = w0 y0 + w1 y1 + w2 y2 + w3 y3 with
-				// p = rho - n1 (exact in float); evaluated once per workgroup in double, w1 = 1 - w0 - w2 - w3
-				const double p = (double)__builtin_amdgcn_fractf(t.x);
-				const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
-				cwL[i] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+				// cu:258-271 as weights of the four taps, y = w0 y0 + w1 y1 + w2 y2 + w3 y3 with p = rho - n1 (exact in float),
+				// w1 = 1 - w0 - w2 - w3: evaluated in float64 once per CURVE by oct_tap_weights_kernel (side_kernels.h; until round 4
+				// every workgroup of every launch re-evaluated them here)
+				const float4 w = a.cubicW[i];
+				cwL[i] = f32x4{w.x, w.y, w.z, w.w};
 			} else {
 				rhoL[i] = t.x;
 			}
@@ -695,14 +722,29 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	__syncthreads();
 
 	const unsigned wavesTotal = gridDim.x * (unsigned)WAVES;
-	unsigned line = blockIdx.x * (unsigned)WAVES + (unsigned)wave;
+	// A-scans of a wave.  Default: wave w takes w, w + wavesTotal, ... (at any moment the waves of the chip work on one contiguous
+	// window of the buffer).  MODE_DISP: a contiguous BLOCK of A-scans per wave, so that the en-face values a wave collects belong to
+	// consecutive A-scans and leave as one coalesced 256-byte store -- strided, the same values are 64 separate 4-byte writes into
+	// 64 different cache lines per wave, 131 072 partial-line writes at the tail of a 1024 x 512 x 256 launch: +4 us
+	// (profiles/r5d_fold_parts_ab.txt)
+#ifndef OCT_DISP_BLOCKED
+#define OCT_DISP_BLOCKED 0  // measured: the blocked mapping itself costs what the coalesced store saves (2 048 separate streams instead of one window: 0.1792 vs 0.1780 ms, profiles/r5e_fold_blocked_ab.txt)
+#endif
+#ifndef OCT_DISP_FLUSH
+#define OCT_DISP_FLUSH 16   // en-face values collected per store: with 64 all partial-line writes of a launch fall into its last microseconds
+#endif
+	constexpr bool BLOCKED = (MODE & MODE_DISP) != 0 && OCT_DISP_BLOCKED != 0;
+	const unsigned perWave = BLOCKED ? (a.numLines + wavesTotal - 1u) / wavesTotal : 0u;
+	const unsigned lineStep = BLOCKED ? 1u : wavesTotal;
+	unsigned line = (blockIdx.x * (unsigned)WAVES + (unsigned)wave) * (BLOCKED ? perWave : 1u);
+	const unsigned lineEnd = BLOCKED ? (line + perWave < a.numLines ? line + perWave : a.numLines) : a.numLines;
 	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16u);
 	const __amdgpu_buffer_rsrc_t lanczosR = make_rsrc(a.lanczosW, N * 64u);
 	const unsigned rowBytes = (unsigned)(N / SPL) * CB;
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 	u32x4 pre[NL];
 	if constexpr (RS != RS_LANCZOS) {
-		if (line < a.numLines) {
+		if (line < lineEnd) {
 			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
 #pragma unroll
 			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
@@ -753,9 +795,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		for (int q = 0; q < P; q++) {
 			const float4 t = a.lut[lane + 64 * q];
 			wphR[q] = f2{t.y * t.z, t.y * t.w};
-			const double p = (double)__builtin_amdgcn_fractf(t.x);
-			const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
-			cwR[q] = f32x4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+			const float4 w = a.cubicW[lane + 64 * q];  // the table of oct_tap_weights_kernel (see the LDS variant above)
+			cwR[q] = f32x4{w.x, w.y, w.z, w.w};
 		}
 	}
 	if constexpr (TW2) {
@@ -778,7 +819,13 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			rollRc[e] = __fdiv_rn(1.0f, rollCnt[e]);
 		}
 	}
-	for (; line < a.numLines; line += wavesTotal) {
+	// MODE_DISP: register index and lane of the en-face bin, the values collected for the current block of 64 A-scans and their rows
+	constexpr bool DISP = (MODE & MODE_DISP) != 0;
+	static_assert(!(DISP && SPECTRUM), "display frames are copies of the image");
+	const unsigned efIdx = DISP ? __builtin_amdgcn_readfirstlane(a.dispEnFaceBin >> 6) : 0u, efLane = DISP ? __builtin_amdgcn_readfirstlane(a.dispEnFaceBin & 63u) : 0u;
+	float efAcc = 0.0f;
+	unsigned efCount = 0, efFirst = line;  // A-scans collected in efAcc, and the first of them
+	for (; line < lineEnd; line += lineStep) {
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
 			bool staged = false;
@@ -852,8 +899,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 						*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);
 				}
 			}
-			const unsigned next = line + wavesTotal;  // prefetch the next row of this wave
-			if (next < a.numLines) {
+			const unsigned next = line + lineStep;  // prefetch the next row of this wave
+			if (next < lineEnd) {
 				const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
 #pragma unroll
 				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
@@ -1008,15 +1055,22 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		} else {
 			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
 			unsigned orow = line;  // output row; only the flip needs the (B-scan, A-scan) split of the line index
-			if (a.flip) {
-				const unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
-				// even buffer-local B-scans are mirrored; the reference's launch covers S/4 indices
-				// (cu:1547), so with an odd B-scan count the last one is left as it is
-				if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
-			}
+			if (a.flip) orow = flipped_row(a, line);
 			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
 			constexpr bool BG = (MODE & MODE_BG) != 0;
 			const f2* ml = meanL + lane;
+			// MODE_DISP, B-scan frame (cu:858): the rows of the displayed B-scan go out a second time, both axes reversed -- row r of
+			// the B-scan is row A - 1 - r of the frame, bin k its element N/2 - 1 - k: lane part (63 - lane), constant part >= 0
+			bool dispRow = false;
+			__amdgpu_buffer_rsrc_t dispR = outR;
+			if constexpr (DISP) {
+				const unsigned r = orow - a.dispBscanRow0;  // (wraps for rows in front of the B-scan)
+				dispRow = a.dispBscan != nullptr && r < a.ascansPerBscan;
+				if (dispRow) dispR = make_rsrc(a.dispBscan + (size_t)(a.ascansPerBscan - 1u - r) * (N / 2), N * 2u);
+			}
+			// (a vector wider than 8 makes hipcc index the registers with s_set_gpr_idx_on -- one v_mov_b32 -- instead of a chain of 8 compares and selects)
+			typedef float efvec_t __attribute__((ext_vector_type((P / 2 > 16) ? 32 : 16)));
+			efvec_t efVec;
 #pragma unroll
 			for (int u = 0; u < RL / 2; u++) {
 				float o[NBL];
@@ -1030,11 +1084,41 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					o[m] = a.sA * s + a.sB;
 				}
 #pragma unroll
-				for (int m = 0; m < NBL; m++) store_image<BG>(o[m], outR, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
+				for (int m = 0; m < NBL; m++) {
+					o[m] = store_image<BG>(o[m], outR, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
+					// en-face frame: bin e = lane + 64 (m + u NBL) of this A-scan; the register index e >> 6 is the same for every A-scan
+					if constexpr (DISP) efVec[m + u * NBL] = o[m];
+				}
+				if constexpr (DISP) {
+					if (dispRow) {
+#pragma unroll
+						for (int m = 0; m < NBL; m++) buf_store32(o[m], dispR, (63 - lane) * 4, (N / 2 - 64 - 64 * m - u * (N / RL)) * 4);
+					}
+				}
+			}
+			if constexpr (DISP) {
+				// ... en-face frame (cu:909): one value per A-scan.  The wave collects the values of up to 64 A-scans in ONE register
+				// (lane k = the k-th A-scan of the block, v_writelane_b32) and writes them with one store per block: three VALU
+				// instructions per A-scan, no vector-memory instruction and no exec-mask change.  (Written as 8 compares + selects, a
+				// v_cmp + v_cndmask instead of the v_writelane and the output row tracked per lane, the same thing cost 13 VALU
+				// instructions per A-scan and made the kernel 3.9 % slower -- more than the extraction kernel it replaces.)
+				const float efSel = efVec[efIdx];
+				const int picked = __builtin_amdgcn_readlane(__builtin_bit_cast(int, efSel), (int)efLane);
+				// (this clang has no builtin for it; two different SGPR operands violate the constant-bus rule of gfx9: lane select through M0)
+				asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(efAcc) : "s"(picked), "s"(efCount) : "m0");
+				efCount++;
+				if (efCount == (unsigned)OCT_DISP_FLUSH) {
+					if (a.dispEnFace) ef_flush<true>(a, efAcc, efFirst, lineStep, lane, (unsigned)OCT_DISP_FLUSH);
+					efCount = 0;
+					efFirst = line + lineStep;
+				}
 			}
 		}
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(0);
 		wave_sync_lds();
+	}
+	if constexpr (DISP) {
+		if (a.dispEnFace && efCount) ef_flush<true>(a, efAcc, efFirst, lineStep, lane, efCount);
 	}
 }
 

@@ -1,6 +1,7 @@
 // launch.h -- host-visible launchers of the fused kernels, one translation unit per transform length
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <map>
 #include <mutex>
@@ -46,6 +47,29 @@ hipError_t kernel_launch_info(K kernel, int threads, size_t ldsBytes, KernelLaun
 	}
 	*out = c;
 	return hipSuccess;
+}
+
+// Kernel timing without extra packets on the stream: a caller that wants the duration of the ONE kernel a launch_* call dispatches
+// sets this (per thread, for the duration of the call: LaunchTimingScope) and the launcher hands the two events to
+// hipExtLaunchKernelGGL, which binds them to the dispatch itself.  hipEventRecord in front of and behind a launch puts two marker
+// packets on the stream instead, which cost 3-5 us per step on MI355X (profiles/r5b_display_fold_ab.txt: 0.1863 -> 0.1809 ms per step
+// without them) -- as much as the kernel launches they were meant to observe.  Launchers that ignore it leave `used` false and
+// the caller falls back to hipEventRecord.
+struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };
+inline thread_local LaunchTiming* g_launchTiming = nullptr;
+struct LaunchTimingScope {
+	explicit LaunchTimingScope(LaunchTiming* t) { g_launchTiming = t; }
+	~LaunchTimingScope() { g_launchTiming = nullptr; }
+};
+template <typename K>
+inline void launch_fused_args(K kernel, dim3 grid, dim3 block, size_t ldsBytes, hipStream_t stream, const FusedArgs& a) {
+	LaunchTiming* t = g_launchTiming;
+	if (t && t->start && t->stop && !t->used) {
+		hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)ldsBytes, stream, t->start, t->stop, 0u, a);
+		t->used = true;
+	} else {
+		hipLaunchKernelGGL(kernel, grid, block, ldsBytes, stream, a);
+	}
 }
 
 // The in-kernel rolling average (MODE_ROLL of the fused / team kernels) indexes a [ROLL_PAD | N | ROLL_PAD] prefix-sum array in

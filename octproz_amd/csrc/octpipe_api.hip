@@ -84,6 +84,7 @@ struct octpipe {
 	float* d_sinusTmp = nullptr;   // S/2, lazily
 	void* d_output = nullptr;      // quantised output, lazily
 	float4* d_lut = nullptr;
+	float4* d_cubicW = nullptr;    // [N] Catmull-Rom tap weights of the resampling curve (oct_tap_weights_kernel, FusedArgs::cubicW)
 	f2* d_twiddle = nullptr;
 	f2* d_meanLine = nullptr;
 	float* d_postBg = nullptr;
@@ -226,6 +227,10 @@ int uploadLut(octpipe* h) {
 		lut[j] = e;
 	}
 	HIP_TRY(hipMemcpyAsync(h->d_lut, lut.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
+	// the cubic variants of the fused kernel read their four tap weights per sample from a table (once per curve, not per workgroup)
+	if (!h->d_cubicW) HIP_TRY(hipMalloc((void**)&h->d_cubicW, sizeof(float4) * N));
+	hipLaunchKernelGGL(oct::oct_tap_weights_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, h->d_lut, h->d_cubicW, N);
+	HIP_TRY(hipGetLastError());
 	if (h->mixed) HIP_TRY(hipMemcpyAsync(h->d_lutPlain, plain.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
 	if (p.resampling && p.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS) {
 		// cu:297-326: L(t) = sinc(pi t) sinc(pi t / 8) at t = rho_j - (n0_j + i), i = -7..8, float32 like the reference's device code;
@@ -548,8 +553,12 @@ uint64_t displaySignature(const OctPipeParams& p) {
 
 // wantBg: fold the post-process background removal into the image store if this buffer's route has such a kernel (raw uint16 rows
 // without the in-kernel rolling average through the fused / real-input / mixed-radix kernels); *bgApplied tells the caller
+// wantDisp / dispApplied: the display frames written by the image store itself (MODE_DISP of oct_fused_kernel) -- asked for by
+// processDeviceRaw when every enabled view shows ONE frame (the reference's default) and nothing follows the kernel that changes
+// the volume; granted where this buffer runs the general fused kernel
+struct DispFold { float* bscan; float* enface; unsigned bscanRow0, enfaceBin, enfaceLast; bool bgPostPassFollowsUnlessFused; };
 int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt, bool wantBg = false,
-                bool* bgApplied = nullptr) {
+                bool* bgApplied = nullptr, const DispFold* wantDisp = nullptr, bool* dispApplied = nullptr) {
 	const OctPipeParams& p = h->params;
 	oct::FusedArgs a{};
 	int intype = oct::IN_U16;
@@ -620,9 +629,11 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	a.out = out;
 	a.spectrum = spectrumOut;
 	a.lut = h->d_lut;
+	a.cubicW = h->d_cubicW;
 	a.twiddle = h->d_twiddle;
 	a.meanLine = h->d_meanLine;
 	a.numLines = lines;
+	if (dispApplied) *dispApplied = false;
 	a.linesInBuffer = (unsigned)(h->A * h->B);
 	a.ascansPerBscan = (unsigned)h->A;
 	a.bitshift = p.bitshift;
@@ -645,12 +656,20 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		a.sA = (float)(coeff / (half * range));
 		a.sB = (float)(coeff * (-mn / range + addend));
 	}
+	// kernel timing (octpipe_enable_kernel_timing): the general fused kernel and the N = 1024 real-input kernel take the two events
+	// into their dispatch (launch.h LaunchTiming: no packet of their own on the stream); every other route is bracketed by two
+	// recorded events
 	TimedLaunch t{};
-	if (timeIt && h->timing) {
+	const bool timed = timeIt && h->timing;
+	const bool willRunFusedOrReal2 = !(mxn) && !teamLib && !h->libfft && !useMixed && !h->bluestein && !h->d_twTeam;
+	oct::LaunchTiming lt{};
+	if (timed) {
 		HIP_TRY(hipEventCreate(&t.start));
 		HIP_TRY(hipEventCreate(&t.stop));
-		HIP_TRY(hipEventRecord(t.start, h->stream));
+		if (willRunFusedOrReal2) { lt.start = t.start; lt.stop = t.stop; }
+		else HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
+	oct::LaunchTimingScope timingScope(timed && willRunFusedOrReal2 ? &lt : nullptr);
 	if (mxn && mxnStatic) {
 		// (the probe instance compiled when the handle was created: hiprtc works in this process; an instance that fails now is an error)
 		a.twiddle = h->d_twMixedStatic;
@@ -745,11 +764,20 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		else HIP_TRY(oct::launch_real2n(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
 	} else {
 		path |= roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0;
-		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, 0, h->stream, &h->lastGrid));
+		if (wantDisp && !spectrum && (!wantDisp->bgPostPassFollowsUnlessFused || a.bgTerm)) {
+			a.dispBscan = wantDisp->bscan; a.dispEnFace = wantDisp->enface;
+			a.dispBscanRow0 = wantDisp->bscanRow0; a.dispEnFaceBin = wantDisp->enfaceBin; a.dispEnFaceLast = wantDisp->enfaceLast;
+			if (dispApplied) *dispApplied = true;
+			path |= OCTPIPE_PATH_FUSED_DISPLAY;
+		}
+		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0, h->stream, &h->lastGrid));
 	}
 	if (!spectrum) h->lastPath = path;
-	if (timeIt && h->timing) {
-		HIP_TRY(hipEventRecord(t.stop, h->stream));
+	if (timed) {
+		if (!lt.used) {  // (a launcher that did not take the events: an empty launch, or a route bracketed from outside)
+			if (willRunFusedOrReal2) HIP_TRY(hipEventRecord(t.start, h->stream));
+			HIP_TRY(hipEventRecord(t.stop, h->stream));
+		}
 		h->timed.push_back(t);
 		// long timed runs: fold the launches that have already finished so the event list stays bounded
 		if (h->timed.size() >= 1024) {
@@ -930,8 +958,35 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	// the removal commutes with everything but the sinusoidal correction (a blend of two A-scans in front of the clamp) and has
 	// to follow a recording requested for this very buffer: otherwise it rides on the fused kernel's store
 	bool bgFused = false;
+	// Display frames (cu:1571-1578).  In the reference's default form -- ONE frame per enabled view, displayFunctionFrames <= 1
+	// (octalgorithmparameters.cpp:92-99) -- every pixel of them is a copy of one value of the volume this buffer writes: the B-scan
+	// frame is B-scan frameNr reversed (cu:858), the en-face frame bin frameNrEnFaceView of every A-scan (cu:909).  The fused
+	// kernel's image store writes them along (MODE_DISP) when nothing behind it changes the volume (no sinusoidal correction, no
+	// background post pass); oct_display_frames_kernel remains for averaging / MIP, for the routes without MODE_DISP and for the
+	// full extraction from the other buffers of a volume after a change of the display settings.
+	const bool wantViews = p.bscanViewEnabled || p.enFaceViewEnabled;
+	const int modeB = oct::display_mode(p.functionFramesBscan, p.displayFunctionBscan), modeE = oct::display_mode(p.functionFramesEnFaceView, p.displayFunctionEnFaceView);
+	DispFold fold{};
+	bool foldAsked = false, dispFused = false;
+	if (wantViews && !sinus && !(h->route & (OCTPIPE_ROUTE_NO_FUSED_DISPLAY | OCTPIPE_ROUTE_FULL_DISPLAY)) &&
+	    (!p.bscanViewEnabled || modeB == oct::DISP_SINGLE) && (!p.enFaceViewEnabled || modeE == oct::DISP_SINGLE) &&
+	    !(bgRemoval && p.postProcessBackgroundRecordingRequested)) {
+		const unsigned BV = (unsigned)B * h->acq.buffersPerVolume, W = (unsigned)(N / 2), slot = h->bufferNumberInVolume;
+		const unsigned frameB = p.frameNr < BV ? p.frameNr : 0u;                 // cu:1269
+		const unsigned frameE = p.frameNrEnFaceView < W ? p.frameNrEnFaceView : 0u;   // cu:1288
+		fold.bscan = p.bscanViewEnabled ? h->d_dispBscan : nullptr;
+		fold.enface = p.enFaceViewEnabled ? h->d_dispEnFace : nullptr;
+		// rows of B-scan frameB relative to this buffer: in front of it the subtraction in the kernel wraps, behind it r >= A
+		fold.bscanRow0 = (frameB >= slot * (unsigned)B && frameB < (slot + 1u) * (unsigned)B) ? (frameB - slot * (unsigned)B) * (unsigned)A : 0xFFFFFFFFu - (unsigned)A;
+		if (fold.bscanRow0 >= (unsigned)(A * B)) fold.bscan = nullptr;
+		fold.enfaceBin = frameE;
+		fold.enfaceLast = BV * (unsigned)A - 1u - slot * (unsigned)(A * B);
+		fold.bgPostPassFollowsUnlessFused = bgRemoval;
+		foldAsked = fold.bscan || fold.enface;
+	}
 	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true,
-	                      bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG), &bgFused))) return rc;
+	                      bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG), &bgFused,
+	                      foldAsked ? &fold : nullptr, &dispFused))) return rc;
 	if (bgFused) bgRemoval = false;
 
 	if (bgRemoval && p.postProcessBackgroundRecordingRequested) {  // cu:1557-1568: record from the corrected first B-scan, then remove
@@ -951,6 +1006,11 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	if (p.bscanViewEnabled || p.enFaceViewEnabled) {  // cu:1571-1578, both frames in one launch
 		const uint64_t sig = displaySignature(p);
 		const bool incremental = sig == h->displaySig && !(h->route & OCTPIPE_ROUTE_FULL_DISPLAY);
+		// the store of the fused kernel has already written what this buffer contributes; the rest of a multi-buffer volume is
+		// extracted once, when the display settings have changed (or on the first buffer)
+		if (dispFused && (incremental || h->acq.buffersPerVolume == 1)) {
+			h->displaySig = sig;
+		} else
 		if ((rc = updateDisplay(h, p.bscanViewEnabled != 0, p.frameNr, p.functionFramesBscan, p.displayFunctionBscan,
 		                        p.enFaceViewEnabled != 0, p.frameNrEnFaceView, p.functionFramesEnFaceView, p.displayFunctionEnFaceView, incremental))) return rc;
 		h->displaySig = sig;
@@ -1235,7 +1295,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_processedAlt, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW, h->d_twMixedN, h->d_twMixedStatic};
+	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW, h->d_twMixedN, h->d_twMixedStatic, h->d_cubicW};
 	for (void* b : bufs) if (b) hipFree(b);
 	// the (drained) streams of the handle go to the idle list of the device; the next handle created there takes them over
 	if (h->stream && h->ownStream && h->copyStream && h->outStream) {

@@ -19,7 +19,7 @@ hipError_t launch_real2_one(const FusedArgs& a, hipStream_t stream) {
 	unsigned blocks = (unsigned)numCU;  // 86-121 KiB of LDS and >= 164 VGPRs x 8-12 waves: one persistent workgroup per CU
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(REAL2_WAVES * 64), REAL2_LDS_BYTES, stream, a);
+	launch_fused_args(kernel, dim3(blocks), dim3(REAL2_WAVES * 64), REAL2_LDS_BYTES, stream, a);
 	return hipGetLastError();
 }
 template <int RS>

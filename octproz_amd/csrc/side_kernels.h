@@ -488,6 +488,18 @@ OCT_DEV void display_enface_unit(unsigned i, float* disp, const float* vol, unsi
 
 // both display frames of a buffer in one launch (each is launch-latency bound on its own): blocks [0, bscanBlocks) take
 // the B-scan frame, the rest the en-face frame; either part may be empty
+// The four Catmull-Rom tap weights of every sample index: cubicHermiteInterpolation (cu:258-271) rewritten as
+// y = w0 y0 + w1 y1 + w2 y2 + w3 y3 with p = rho - floor(rho) (exact in float), evaluated in float64 and rounded once,
+// w1 = 1 - w0 - w2 - w3.  One launch per resampling curve (uploadLut); the cubic variants of oct_fused_kernel read the table
+// (FusedArgs::cubicW) where they used to evaluate these expressions per workgroup and launch.
+__global__ __launch_bounds__(256) void oct_tap_weights_kernel(const float4* lut, float4* cw, int n) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const double p = (double)__builtin_amdgcn_fractf(lut[i].x);
+	const double w0 = 0.5 * p * ((2.0 - p) * p - 1.0), w2 = 0.5 * p * ((4.0 - 3.0 * p) * p + 1.0), w3 = 0.5 * p * p * (p - 1.0);
+	cw[i] = float4{(float)w0, (float)(1.0 - w0 - w2 - w3), (float)w2, (float)w3};
+}
+
 struct DisplayArgs {
 	float* dispBscan; float* dispEnFace; const float* vol;
 	unsigned bscansPerVolume, nBscan, frameNrBscan, framesBscan;

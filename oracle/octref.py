@@ -61,10 +61,13 @@ def lib():
 
 
 def ref():
-    """The reference's own curve code, or None when oracle/_ref was not built/shipped."""
+    """The reference's own curve code -- a BUILD-CONTAINER facility (tests/golden/make_golden.py and the live
+    cross-check of tests/test_luts.py): None wherever /root/reference is absent, i.e. on the GPU box, where
+    the committed vectors tests/golden/luts_ref.npz stand in for it and the object is never loaded even if
+    a copy travelled with the snapshot (VERDICT r4 weak #10)."""
     global _ref
     if _ref is None:
-        if not os.path.exists(_REF):
+        if not os.path.isdir("/root/reference/octproz_project/octproz/src") or not os.path.exists(_REF):
             return None
         try:
             _ref = C.CDLL(_REF)

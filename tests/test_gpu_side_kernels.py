@@ -217,3 +217,73 @@ def test_full_display_extraction_switch():
         pipe.close()
     assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
     assert np.array_equal(frames[0][1].view(np.uint32), frames[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("N,A,B,bpv,route,mut", [
+    (1024, 33, 4, 1, 0, {}),                                              # headline variant; ragged line count
+    (1024, 64, 24, 1, _lib.ROUTE_TINY_GRID, {"bscanFlip": 1}),            # 16 waves x 96 A-scans: block flush (64) + tail flush, flipped rows
+    (1024, 16, 4, 3, 0, {"bscanFlip": 1}),                                # B-scan frame in another buffer of the volume
+    (1024, 20, 3, 1, 0, {"postProcessBackgroundRemoval": 1, "postProcessBackgroundWeight": 0.7, "postProcessBackgroundOffset": 0.01}),
+    (1024, 20, 2, 1, 0, {"backgroundRemoval": 1, "rollingAverageWindowSize": 16}),
+    (1024, 20, 2, 1, 0, {"resamplingInterpolation": 0}), (1024, 20, 2, 1, 0, {"resampling": 0}), (1024, 12, 2, 1, 0, {"resamplingInterpolation": 2}),
+    (2048, 12, 2, 1, 0, {"signalLogScaling": 0}), (2048, 40, 8, 2, _lib.ROUTE_TINY_GRID, {}), (512, 20, 4, 2, 0, {}), (256, 9, 6, 1, 0, {}),
+    (1024, 8, 2, 1, 0, {"bscanViewEnabled": 0}), (1024, 8, 2, 1, 0, {"enFaceViewEnabled": 0}),
+])
+def test_display_frames_written_by_the_fused_kernels_store(N, A, B, bpv, route, mut):
+    """Round 5: with ONE frame per view (the reference's default, cu:810-912 with displayFunctionFrames <= 1) the image store of
+    the general fused kernel writes both display frames itself (MODE_DISP, PATH_FUSED_DISPLAY) -- no oct_display_frames_kernel
+    launch in the steady state.  After every buffer both frames equal, bit for bit, what cu:810-912 extract from the whole
+    current volume, and what the same handle settings produce with the extraction kernel (ROUTE_NO_FUSED_DISPLAY)."""
+    p = v180_benchmark_params(N, A, B, buffers_per_volume=bpv)
+    _grey(p)
+    for k, v in mut.items():
+        setattr(p, k, v)
+    p.update_all_curves()
+    p.frameNr, p.frameNrEnFaceView = (B * bpv) // 2, N // 4 + 3
+    W, BV = N // 2, B * bpv
+    frames = {}
+    for r in (route, route | _lib.ROUTE_NO_FUSED_DISPLAY):
+        if p.postProcessBackgroundRemoval:
+            p.loadPostProcessingBackground(np.linspace(0.05, 0.4, W).astype(np.float32))
+        pipe = Pipeline(p, device=0, route=r)
+        (pb, nb), (pe, ne) = pipe.display_buffers()
+        vol = np.zeros(BV * A * W, np.float32)
+        got = []
+        for k in range(2 * bpv + 2):
+            if k == bpv + 1:  # both views move: the next buffer rewrites the frames from its own store (bpv = 1) or one full extraction follows
+                p.frameNr, p.frameNrEnFaceView = 1, 7
+            raw = synthetic_raw(N, A, B, seed=900 + k)
+            d = _dev(raw)
+            pipe.process_device(d.data_ptr()); pipe.synchronize()
+            fused = bool(pipe.last_path() & _lib.PATH_FUSED_DISPLAY)
+            assert fused == (r == route), "path %#x" % pipe.last_path()
+            _, _, nr = pipe.processed_device()
+            vol[nr * A * B * W:(nr + 1) * A * B * W] = pipe.processed_host()
+            fb, fe = _fetch(pb, nb, np.float32), _fetch(pe, ne, np.float32)
+            if p.bscanViewEnabled:
+                assert np.array_equal(fb.view(np.uint32), octref.display_bscan(vol, BV, nb, p.frameNr, 1, 0).view(np.uint32)), "B-scan frame after buffer %d" % k
+            if p.enFaceViewEnabled:
+                assert np.array_equal(fe.view(np.uint32), octref.display_enface(vol, W, ne, p.frameNrEnFaceView, 1, 0).view(np.uint32)), "en-face frame after buffer %d" % k
+            got.append((fb, fe))
+        p.frameNr, p.frameNrEnFaceView = (B * bpv) // 2, N // 4 + 3
+        frames[r] = got
+        pipe.close()
+    for (b0, e0), (b1, e1) in zip(frames[route], frames[route | _lib.ROUTE_NO_FUSED_DISPLAY]):
+        assert np.array_equal(b0.view(np.uint32), b1.view(np.uint32)) and np.array_equal(e0.view(np.uint32), e1.view(np.uint32))
+
+
+def test_display_averaging_and_mip_keep_the_extraction_kernel():
+    """frames > 1 (averaging / MIP over B-scans or depth bins) is not a copy of one value: the store does not write it"""
+    N, A, B = 1024, 16, 4
+    p = v180_benchmark_params(N, A, B)
+    _grey(p)
+    p.functionFramesBscan, p.displayFunctionBscan = 3, 0
+    pipe = Pipeline(p, device=0)
+    d = _dev(synthetic_raw(N, A, B, seed=5))
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    assert not (pipe.last_path() & _lib.PATH_FUSED_DISPLAY)
+    (pb, nb), (pe, ne) = pipe.display_buffers()
+    vol = pipe.processed_host()
+    assert np.array_equal(_fetch(pb, nb, np.float32).view(np.uint32), octref.display_bscan(vol, B, nb, p.frameNr, 3, 0).view(np.uint32))
+    assert np.array_equal(_fetch(pe, ne, np.float32).view(np.uint32), octref.display_enface(vol, N // 2, ne, p.frameNrEnFaceView, 1, 0).view(np.uint32))
+    pipe.close()

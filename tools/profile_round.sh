@@ -8,7 +8,7 @@
 # Every profiler run is wrapped in `timeout`; counters are collected with --kernel-trace only.
 tag=$1; shift; root=$PWD; out=$root/gpurun_out/$tag
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-traffic "$@" > $out/bench_in_profile.json 2> $out/stats.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 50 --warmup 5 --blocks 0 --no-cpu-baseline --no-extras --no-traffic "$@" > $out/bench_in_profile.json 2> $out/stats.log
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 i=0
 echo "pass,kernel,counter,dispatches,avg_value" > $out/pmc_counters.csv
@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
   i=$((i+1))
-  timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python3 $root/bench.py --steps 8 --warmup 2 --warmup-seconds 0 --no-cpu-baseline --no-extras --no-traffic "$@" > $out/p$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python3 $root/bench.py --steps 8 --warmup 2 --warmup-seconds 0 --blocks 0 --no-cpu-baseline --no-extras --no-traffic "$@" > $out/p$i.log 2>&1
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" "pass$i" >> $out/pmc_counters.csv <<'PY'
 import csv, collections, sys
