@@ -54,7 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--volumes", type=int, default=4, help="distinct raw buffers rotated (1 GiB > the 256 MiB Infinity Cache)")
     ap.add_argument("--out-slots", type=int, default=4, help="processed-buffer slots rotated (buffersPerVolume; 1 GiB of output > Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--route", type=int, default=0, help="OCTPIPE_ROUTE_* flags for the handle (include/octpipe_debug.h): same-box A/B of two routes, e.g. 4096 = display frames by the extraction kernel")
+    ap.add_argument("--route", type=int, default=0, help="OCTPIPE_ROUTE_* flags for the handle (include/octpipe_debug.h): same-box A/B of two routes, e.g. 4096 = display frames by the fused kernel's store")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP events around the dominant kernel of every n-th launch of the timed region (1 = every launch): a timed "
+                    "launch costs the stream 2-4 us, i.e. the measurement itself would take 2 %% off the step rate it is reported next to")
     ap.add_argument("--blocks", type=int, default=8, help="after the timed region: this many more blocks of --steps steps, alternately with and without the per-launch HIP events, "
                     "reported as medians next to the contract's single timed block (a 20-step block is 3 ms: box noise is +-2-4 %%)")
     ap.add_argument("--no-extras", action="store_true", help="skip the host_loop, real_input and rolling_average records (A/B runs, profiler passes)")
@@ -292,7 +294,7 @@ def preflight(rank, local_rank, dev_index):
 
 
 # ------------------------------------------------------------------------------------------------ one rank
-def timed_run(pipe, vols, steps, warmup, warmup_seconds, barrier=None):
+def timed_run(pipe, vols, steps, warmup, warmup_seconds, barrier=None, time_every=1):
     """W warm-up steps (+ time-based ramp), then exactly `steps` timed steps; returns (seconds, kernel_ms, launches)."""
     import torch
 
@@ -309,7 +311,7 @@ def timed_run(pipe, vols, steps, warmup, warmup_seconds, barrier=None):
         for _ in range(64):
             step(i); i += 1
         pipe.synchronize()
-    pipe.enable_kernel_timing(True)
+    pipe.enable_kernel_timing(True, every=max(1, min(time_every, steps)))
     pipe.kernel_timing(reset=True)
     if barrier:
         barrier()
@@ -326,7 +328,7 @@ def timed_run(pipe, vols, steps, warmup, warmup_seconds, barrier=None):
     return dt, kernel_ms, launches
 
 
-def more_blocks(pipe, vols, steps, blocks):
+def more_blocks(pipe, vols, steps, blocks, time_every=1):
     """`blocks` more blocks of `steps` steps right behind the timed region, alternately WITH the per-launch HIP events (as in the
     timed region) and WITHOUT them: the median step time of each kind and the median kernel time.  The events are two more packets
     per step on the stream; the difference is what the measurement itself costs."""
@@ -337,7 +339,7 @@ def more_blocks(pipe, vols, steps, blocks):
     i = 0
     for b in range(blocks):
         ev = b % 2 == 0
-        pipe.enable_kernel_timing(ev)
+        pipe.enable_kernel_timing(ev, every=max(1, min(time_every, steps)))
         pipe.kernel_timing(reset=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -500,8 +502,8 @@ def main():
         odist.share_calibration(pipe, device=comm_dev, src=0)  # RCCL broadcast over xGMI: ~23 KB, latency bound
 
     dt, kernel_ms, launches = timed_run(pipe, vols, args.steps, args.warmup, args.warmup_seconds,
-                                        barrier=dist.barrier if distributed else None)
-    blocks = more_blocks(pipe, vols, args.steps, args.blocks) if (rank == 0 and ranks == 1 and args.blocks > 0) else None
+                                        barrier=dist.barrier if distributed else None, time_every=args.time_every)
+    blocks = more_blocks(pipe, vols, args.steps, args.blocks, args.time_every) if (rank == 0 and ranks == 1 and args.blocks > 0) else None
     kernel_ms_ranks = [kernel_ms]
     pre_all, bscans_all = [pre], [B]
     if distributed:
@@ -563,7 +565,9 @@ def main():
                          "kernel": kernel_name,
                          "kernel_ms": kernel_ms,
                          "kernel_ms_per_rank": {"min": min(kernel_ms_ranks), "max": max(kernel_ms_ranks), "ranks": kernel_ms_ranks},
-                         "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
+                         "launches": launches, "kernel_timing": "HIP events bound to the dispatch of every %d-th launch of the timed region (hipExtLaunchKernelGGL; %d launches timed)"
+                                                              % (max(1, min(args.time_every, args.steps)), launches),
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          # the honest second axis of a kernel on the ridge: FP32 rate against the vector peak, and the measured
                          # VALU-only floor of this instruction mix where one exists
                          "flops_per_ascan": flops_fft + flops_other, "flops_convention": "5 N log2 N (transform) + 30 N (unpack, cubic taps, window x phasor, |z|^2, log)",

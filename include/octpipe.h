@@ -329,7 +329,8 @@ int octpipe_group_copy_processed_to_host(octpipe_group_t* g, float* dst /* S/2 f
 
 /* ------------------------------------------------------------------ measurement helper
  * Average duration in ms of the dominant (fused) kernel since the last reset, measured with HIP
- * events recorded on the handle's own stream around each launch when timing is enabled. */
+ * events on the handle's own stream around each launch when timing is enabled (enable = 1), or around every n-th
+ * launch (enable = n > 1: a timed launch costs the stream 2-4 us on MI355X, profiles/r5f_fold_flush16_ab.txt). */
 int octpipe_enable_kernel_timing(octpipe_t* h, int enable);
 int octpipe_kernel_timing(octpipe_t* h, double* avgMs, unsigned* launches, int reset);
 

@@ -38,7 +38,9 @@ enum {
 	OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT = 2048, /* creation: the run-time compiled kernel with its first plan order and exchange layout (largest radix first, always padded) */
 	OCTPIPE_ROUTE_TINY_GRID = 1024,    /* the run-time compiled kernel and the general fused kernel on TWO persistent workgroups: every wave loops over many A-scans even of a small test buffer */
 	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256, /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
-	OCTPIPE_ROUTE_NO_FUSED_DISPLAY = 4096 /* display frames always by oct_display_frames_kernel (cu:1571-1578 as launches of their own), never by the fused kernel's image store */
+	OCTPIPE_ROUTE_FUSED_DISPLAY = 4096 /* display frames (one frame per view) written by the general fused kernel's image store (MODE_DISP) instead of by oct_display_frames_kernel.
+	                                      Opt-in: bit-identical frames, one launch per buffer instead of two, but not faster -- the store side costs the kernel what the extraction kernel
+	                                      cost (profiles/r5b..r5f_*_ab.txt) */
 };
 int octpipe_debug_set_route(octpipe_t* h, unsigned flags);
 /* octpipe_create_with_format with OCTPIPE_ROUTE_* flags from the start (the creation-time ones select the FFT backend) */
@@ -66,6 +68,14 @@ enum {
 	OCTPIPE_PATH_FUSED_DISPLAY = 512  /* the display frames (one frame per view) written by the image store of the fused kernel */
 };
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
+/* The same decision WITHOUT a device (csrc/route.h: derive_route_facts + choose_route, the pure functions octpipe_debug_create and
+ * every image launch go through): the OCTPIPE_PATH_* bits, the kernel family (route.h RouteKind), the sample container the transform
+ * kernel reads (0 uint8, 1 uint16, 3 prepared float32 rows, 4 / 5 packed 12 bit, 6 int16) and the rolling-average window handed to the
+ * prepare kernel in front (-1: no prepare kernel) that a buffer with these acquisition parameters, settings, sample format and route
+ * flags runs on.  assumeFftLibrary / assumeRtc: libhipfft.so / hiprtc taken to be usable in the process.  spectrum = 1: the launch of
+ * the mean-line estimate instead of the image launch.  tests/test_route.py holds the routing table against it in the CPU suite. */
+int octpipe_debug_route(const OctPipeAcquisitionParams* acq, const OctPipeParams* params, int sampleFormat, unsigned routeFlags, int assumeFftLibrary, int assumeRtc,
+                        int spectrum, unsigned* path, int* kind, int* intype, int* preparedRollW);
 
 /* Lengths without a dedicated kernel run a kernel compiled for them at run time (hiprtc; csrc/mixedn_rtc.hip).  Status: whether
  * the handle's length does (h may be NULL), its plan (five radices, 0 = unused), how many instances the process has compiled, the

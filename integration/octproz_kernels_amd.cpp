@@ -73,6 +73,13 @@ OctPipeParams toPod(const OctAlgorithmParameters* p) {
 	return o;
 }
 
+}  // namespace
+
+// test hook (integration/adapter_link_check.cpp): what toPod makes of a parameter object
+extern "C" void octpipe_adapter_debug_to_pod(const OctAlgorithmParameters* p, OctPipeParams* out) { if (p && out) *out = toPod(p); }
+
+namespace {
+
 #ifndef OCTPIPE_ADAPTER_NO_NOTIFIER
 void onStreaming(void* buf, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned nr, void*) {
 	if (g_params) g_params->currentBufferNr = nr;                      // cu:1602

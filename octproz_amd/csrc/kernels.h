@@ -1105,7 +1105,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				const float efSel = efVec[efIdx];
 				const int picked = __builtin_amdgcn_readlane(__builtin_bit_cast(int, efSel), (int)efLane);
 				// (this clang has no builtin for it; two different SGPR operands violate the constant-bus rule of gfx9: lane select through M0)
-				asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(efAcc) : "s"(picked), "s"(efCount) : "m0");
+				// (readfirstlane: where the loop's exit is not provably wave-uniform the counter lives in a VGPR and an "s" operand would get it as such)
+				asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(efAcc) : "s"(picked), "s"(__builtin_amdgcn_readfirstlane(efCount)) : "m0");
 				efCount++;
 				if (efCount == (unsigned)OCT_DISP_FLUSH) {
 					if (a.dispEnFace) ef_flush<true>(a, efAcc, efFirst, lineStep, lane, (unsigned)OCT_DISP_FLUSH);

@@ -2,23 +2,41 @@
 // the reference hands any length to cuFFT (cu:1140), which plans -- and on current versions compiles -- at run time too.  The kernel
 // headers travel as text inside this library (rtc_sources.S); hiprtc (bound with dlopen, the copy the process already holds
 // first) compiles  body<Plan<N, R0, ...>, W, INTYPE, RS, MODE>  for the device's architecture in ~0.5 s; the code object is
-// loaded as a module and launched with hipModuleLaunchKernel.  One instance per (device, plan, container, resampling mode, output
-// mode), compiled when a buffer first needs it and kept for the life of the process.  Nothing is written to disk.
-// A length whose compilation fails (no hiprtc in the process' library path) keeps its previous route -- the run-time-plan kernel
-// up to 2304, the library route beyond -- and the reason is kept for octpipe_debug_rtc_status.
+// loaded as a module and launched with hipModuleLaunchKernel.
+// Two caches, both for the life of the process (round 5):
+//   code objects  per (architecture, plan, container, resampling mode, output mode, options): compiled ONCE per process whatever the
+//                 number of devices, OUTSIDE the cache's lock -- the first thread that needs a variant compiles it, the others that
+//                 need the same one wait for exactly that variant, everything else goes on; octpipe_create / octpipe_set_params
+//                 start the variants a handle can reach next on a background thread (mixedn_rtc_prefetch), so that toggling a
+//                 setting in the middle of an acquisition finds its kernel compiled;
+//   modules       per (device, code object): hipModuleLoadData only.  A module whose launch reports a stale handle (the host
+//                 application reset the device) is dropped and loaded again.
+// Only successes are cached: a failed compilation or load is reported to the caller, which keeps the length's other route
+// (the run-time-plan kernel up to 2304, the library route / Bluestein), and is tried again by the next handle.
+// By default nothing is written to disk.  octpipe_set_kernel_cache_dir(dir) (opt-in) keeps the code objects in a directory the
+// caller owns: see the rules at disk_dir_ok / read_disk / write_disk below.
 #include "launch.h"
 
 #include <dlfcn.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <unistd.h>
+#include <deque>
+#include <functional>
+#include <future>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -40,6 +58,9 @@ struct Rtc {
 	int (*getCodeSize)(rtcProgram, size_t*) = nullptr;
 	int (*getCode)(rtcProgram, char*) = nullptr;
 	int (*destroyProgram)(rtcProgram*) = nullptr;
+	int (*version)(int*, int*) = nullptr;
+	int major = 0, minor = 0;
+	std::once_flag once;
 	bool tried = false;
 	std::string why;
 };
@@ -47,7 +68,7 @@ Rtc& rtc() { static Rtc r; return r; }
 
 bool bindRtc(std::string* err) {
 	Rtc& r = rtc();
-	if (!r.tried) {
+	std::call_once(r.once, [&r]() {
 		r.tried = true;
 		const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"};
 		for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
@@ -63,41 +84,103 @@ bool bindRtc(std::string* err) {
 			OCT_RTC_SYM(getCodeSize, "hiprtcGetCodeSize");
 			OCT_RTC_SYM(getCode, "hiprtcGetCode");
 			OCT_RTC_SYM(destroyProgram, "hiprtcDestroyProgram");
+			OCT_RTC_SYM(version, "hiprtcVersion");
 #undef OCT_RTC_SYM
+			if (r.version) r.version(&r.major, &r.minor);
 			if (!r.createProgram || !r.compileProgram || !r.getProgramLogSize || !r.getProgramLog || !r.getCodeSize || !r.getCode || !r.destroyProgram) {
 				r.why = "libhiprtc.so lacks the hiprtc entry points";
 				r.lib = nullptr;
 			}
 		}
-	}
+	});
 	if (!r.lib && err) *err = r.why;
 	return r.lib != nullptr;
 }
 
-struct Instance {
+// ---- code objects: per (architecture, plan, variant, options), shared by every device of that architecture
+struct Code {
+	std::vector<char> bytes;
+	int waves = 0;
+	double seconds = 0.0;   // 0: taken from the disk cache
+	bool ok = false;
+	std::string why;
+};
+typedef std::shared_ptr<const Code> CodePtr;
+typedef std::tuple<std::string, int, int, int, int, int, int, int, int, int, int, std::string> CodeKey;  // arch, N, pad, five radices, intype, rs, mode, extra options
+struct Module {
 	hipModule_t module = nullptr;
 	hipFunction_t fn = nullptr;
 	int waves = 0, numCU = 0;
-	bool failed = false;
-	std::string why;
-	double compileSeconds = 0.0;
 };
-typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, std::string> Key;  // device, N, pad, five radices, intype, rs, mode, extra options
+typedef std::pair<int, CodeKey> ModuleKey;  // device
 struct Cache {
-	std::mutex mtx;
-	std::map<Key, Instance> entries;
+	std::mutex mtx;                                        // guards the maps and the counters below, never held while compiling or loading
+	std::map<CodeKey, std::shared_future<CodePtr>> code;   // (an entry whose compilation failed is removed again)
+	std::map<ModuleKey, Module> modules;
 	std::string lastMessage;
 	std::string diskDir;       // octpipe_set_kernel_cache_dir: compiled code objects are kept here too ("" = nowhere)
 	int diskHits = 0;
 	std::string extraOptions;  // octpipe_debug_rtc_set_options: further compiler options (A/B switches like -DOCT_MXS_LUT_AHEAD=4), separated by blanks
 	int compiled = 0;
 	double compileSeconds = 0.0;
+	// background compilation of the variants a handle can reach next
+	std::mutex qmtx;
+	std::condition_variable qcv;
+	std::deque<std::function<void()>> queue;
+	bool workerRunning = false;
 };
-Cache& cache() { static Cache c; return c; }
+Cache& cache() { static Cache* c = new Cache; return *c; }  // (never destroyed: a detached worker may outlive static destruction)
 
-// source -> code object for `arch` (no device needed); waves = the launch shape compiled in
-bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, const std::string& extra, std::vector<char>& code, int* waves, double* seconds, std::string* why) {
+// ---- opt-in disk cache.  A code object read from disk RUNS on the device inside this process, so the directory is held to the
+// rules of a private key: it must belong to the calling user and be writable by nobody else, the file likewise, neither may be a
+// symbolic link; files are created with mkstemp (O_EXCL, mode 0600) and renamed into place; every file carries a header with the
+// hiprtc version it was compiled by, its payload length and a checksum, and is ignored (and rewritten) when any of them is off.
+// The file name hashes the kernel sources, the options, the architecture, the plan, the variant AND the hiprtc version.
+struct DiskHeader { char magic[8]; int32_t rtcMajor, rtcMinor; uint64_t payloadBytes, checksum; };
+const char kDiskMagic[8] = {'O', 'C', 'T', 'M', 'X', 'S', '2', 0};
+uint64_t fnv64(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+	const unsigned char* b = static_cast<const unsigned char*>(p);
+	for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+	return h;
+}
+bool private_to_user(const struct stat& st) { return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0; }
+bool read_disk(const std::string& file, int rtcMajor, int rtcMinor, std::vector<char>& code) {
+	const int fd = open(file.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+	if (fd < 0) return false;
+	struct stat st;
+	bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && private_to_user(st) && st.st_size > (off_t)sizeof(DiskHeader) + 64;
+	DiskHeader hd{};
+	if (ok) ok = read(fd, &hd, sizeof hd) == (ssize_t)sizeof hd && std::memcmp(hd.magic, kDiskMagic, 8) == 0 && hd.rtcMajor == rtcMajor && hd.rtcMinor == rtcMinor &&
+	             hd.payloadBytes == (uint64_t)st.st_size - sizeof hd;
+	if (ok) {
+		code.resize((size_t)hd.payloadBytes);
+		size_t got = 0;
+		while (got < code.size()) { const ssize_t r = read(fd, code.data() + got, code.size() - got); if (r <= 0) break; got += (size_t)r; }
+		ok = got == code.size() && fnv64(code.data(), code.size()) == hd.checksum && std::memcmp(code.data(), "\x7f" "ELF", 4) == 0;
+	}
+	close(fd);
+	if (!ok) code.clear();
+	return ok;
+}
+void write_disk(const std::string& dir, const std::string& file, int rtcMajor, int rtcMinor, const std::vector<char>& code) {
+	std::string tmp = dir + "/oct_mxs_XXXXXX";
+	const int fd = mkstemp(&tmp[0]);  // O_CREAT | O_EXCL, mode 0600: never follows or reuses an existing name
+	if (fd < 0) return;
+	DiskHeader hd{};
+	std::memcpy(hd.magic, kDiskMagic, 8);
+	hd.rtcMajor = rtcMajor; hd.rtcMinor = rtcMinor; hd.payloadBytes = code.size(); hd.checksum = fnv64(code.data(), code.size());
+	bool ok = write(fd, &hd, sizeof hd) == (ssize_t)sizeof hd;
+	size_t put = 0;
+	while (ok && put < code.size()) { const ssize_t w = write(fd, code.data() + put, code.size() - put); if (w <= 0) ok = false; else put += (size_t)w; }
+	ok = (close(fd) == 0) && ok;
+	if (!ok || std::rename(tmp.c_str(), file.c_str()) != 0) unlink(tmp.c_str());
+}
+
+// source -> code object for `arch` (no device needed); waves = the launch shape compiled in.  Takes no lock.
+bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, const std::string& extra, const std::string& diskDir, std::vector<char>& code, int* waves,
+                 double* seconds, std::string* why, bool* fromDisk) {
 	const bool bg = (mode & MODE_BG) != 0, roll = (mode & MODE_ROLL) != 0, pair = (mode & mxs::MODE_PAIR) != 0;
+	if (fromDisk) *fromDisk = false;
 	int W = mxs::pd_waves(d, bg, rs, roll, pair);
 	{   // (A/B switch -DOCT_MXS_WCAP=n among the extra options: the kernel's pd_waves then caps at n instead of the register rule; the host follows)
 		const size_t at = extra.find("-DOCT_MXS_WCAP=");
@@ -123,34 +206,26 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	              bg ? "true" : "false", rs, roll ? "true" : "false", pair ? "true" : "false", mxs::pd_lds_bytes(d, W, bg, roll, pair), intype, rs, mode);
 	const char* names[] = {"kernels.h", "fft_regs.h", "mixedn_kernel.h", "mixedn_static.h", "mixedn_static_plan.h"};
 	const char* texts[] = {oct_rtc_src_kernels_h, oct_rtc_src_fft_regs_h, oct_rtc_src_mixedn_kernel_h, oct_rtc_src_mixedn_static_h, oct_rtc_src_mixedn_static_plan_h};
-	// on-disk cache (opt-in): the file name is a hash of everything the code object depends on
-	std::string diskFile;
-	if (!cache().diskDir.empty()) {
-		uint64_t hsh = 1469598103934665603ull;
-		auto mix = [&](const char* t) { for (; *t; ++t) { hsh ^= (unsigned char)*t; hsh *= 1099511628211ull; } hsh ^= 0xffu; hsh *= 1099511628211ull; };
-		mix(src); mix(arch); mix(extra.c_str());
-		for (const char* t : texts) mix(t);
-		char name[64];
-		std::snprintf(name, sizeof name, "/oct_mxs_%016llx.co", (unsigned long long)hsh);
-		diskFile = cache().diskDir + name;
-		if (FILE* f = std::fopen(diskFile.c_str(), "rb")) {
-			std::fseek(f, 0, SEEK_END);
-			const long n = std::ftell(f);
-			std::fseek(f, 0, SEEK_SET);
-			bool ok = n > 64;
-			if (ok) { code.resize((size_t)n); ok = std::fread(code.data(), 1, (size_t)n, f) == (size_t)n && std::memcmp(code.data(), "\x7f" "ELF", 4) == 0; }
-			if (ok) {  // whole: the ELF64 section header table (e_shoff, e_shentsize, e_shnum) lies inside the file
-				uint64_t shoff = 0; uint16_t shentsize = 0, shnum = 0;
-				std::memcpy(&shoff, code.data() + 0x28, 8); std::memcpy(&shentsize, code.data() + 0x3A, 2); std::memcpy(&shnum, code.data() + 0x3C, 2);
-				ok = shoff > 0 && shoff + (uint64_t)shentsize * shnum <= (uint64_t)n;
-			}
-			std::fclose(f);
-			if (ok) { cache().diskHits++; if (seconds) *seconds = 0.0; return true; }
-			code.clear();  // (a truncated or foreign file: compile, and overwrite it below)
-		}
-	}
 	if (!bindRtc(why)) return false;
 	Rtc& r = rtc();
+	// on-disk cache (opt-in): the file name is a hash of everything the code object depends on
+	std::string diskFile;
+	if (!diskDir.empty()) {
+		uint64_t hsh = 1469598103934665603ull;
+		auto mix = [&](const char* t) { hsh = fnv64(t, std::strlen(t), hsh); hsh ^= 0xffu; hsh *= 1099511628211ull; };
+		mix(src); mix(arch); mix(extra.c_str());
+		for (const char* t : texts) mix(t);
+		const std::string ver = std::to_string(r.major) + "." + std::to_string(r.minor);
+		mix(ver.c_str());
+		char name[64];
+		std::snprintf(name, sizeof name, "/oct_mxs_%016llx.co", (unsigned long long)hsh);
+		diskFile = diskDir + name;
+		if (read_disk(diskFile, r.major, r.minor, code)) {
+			if (seconds) *seconds = 0.0;
+			if (fromDisk) *fromDisk = true;
+			return true;
+		}
+	}
 	rtcProgram prog = nullptr;
 	if (r.createProgram(&prog, src, "oct_mxs.hip", 5, texts, names) != 0) { *why = "hiprtcCreateProgram failed"; return false; }
 	const std::string archOpt = std::string("--offload-arch=") + arch;
@@ -161,7 +236,7 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 		if (j == std::string::npos) break;
 		i = j + 1;
 	}
-	std::vector<const char*> opts = {archOpt.c_str(), "-std=c++17", "-O3", "-Wno-pass-failed"};
+	std::vector<const char*> opts = {archOpt.c_str(), "-std=c++17", "-O3", "-Wno-pass-failed", "-Wno-inline-asm"};
 	for (const std::string& e : extras) opts.push_back(e.c_str());
 	const auto t0 = std::chrono::steady_clock::now();
 	const int rc = r.compileProgram(prog, (int)opts.size(), opts.data());
@@ -181,26 +256,78 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	code.resize(cs);
 	r.getCode(prog, code.data());
 	r.destroyProgram(&prog);
-	if (!diskFile.empty()) {  // written under a temporary name and renamed: a reader never sees half a file
-		const std::string tmp = diskFile + ".tmp" + std::to_string((long long)getpid());
-		if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
-			const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
-			std::fclose(f);
-			if (!ok || std::rename(tmp.c_str(), diskFile.c_str()) != 0) std::remove(tmp.c_str());
-		}
-	}
+	if (!diskFile.empty()) write_disk(diskDir, diskFile, r.major, r.minor, code);
 	return true;
 }
 
-void compileInstance(const mxs::PlanDesc& d, int intype, int rs, int mode, int dev, const std::string& extra, Instance& in) {
-	hipDeviceProp_t prop;
-	if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); in.failed = true; in.why = "hipGetDeviceProperties failed"; return; }
-	in.numCU = prop.multiProcessorCount;
-	std::vector<char> code;
-	if (!compileCode(d, intype, rs, mode, prop.gcnArchName, extra, code, &in.waves, &in.compileSeconds, &in.why)) { in.failed = true; return; }
-	hipError_t e = hipModuleLoadData(&in.module, code.data());
-	if (e == hipSuccess) e = hipModuleGetFunction(&in.fn, in.module, "oct_mxs");
-	if (e != hipSuccess) { (void)hipGetLastError(); in.failed = true; in.why = std::string("loading the compiled kernel failed: ") + hipGetErrorString(e); }
+CodeKey code_key(const mxs::PlanDesc& d, int intype, int rs, int mode, const std::string& arch, const std::string& extra) {
+	return CodeKey{arch, d.N, d.padp, d.radix[0], d.radix[1], d.radix[2], d.radix[3], d.radix[4], intype, rs, mode, extra};
+}
+
+// The code object of a variant: from the cache, or compiled now by THIS thread (outside the lock) while every other thread that asks
+// for the same variant waits on its future; a failure is handed to everyone who waited and then forgotten.
+CodePtr get_code(const mxs::PlanDesc& d, int intype, int rs, int mode, const std::string& arch) {
+	Cache& c = cache();
+	std::promise<CodePtr> mine;
+	std::shared_future<CodePtr> fut;
+	bool compileHere = false;
+	std::string extra, diskDir;
+	CodeKey key;
+	{
+		std::lock_guard<std::mutex> lock(c.mtx);
+		extra = c.extraOptions;
+		diskDir = c.diskDir;
+		key = code_key(d, intype, rs, mode, arch, extra);
+		auto it = c.code.find(key);
+		if (it == c.code.end()) {
+			fut = mine.get_future().share();
+			c.code.emplace(key, fut);
+			compileHere = true;
+		} else {
+			fut = it->second;
+		}
+	}
+	if (compileHere) {
+		std::shared_ptr<Code> code = std::make_shared<Code>();
+		bool fromDisk = false;
+		code->ok = compileCode(d, intype, rs, mode, arch.c_str(), extra, diskDir, code->bytes, &code->waves, &code->seconds, &code->why, &fromDisk);
+		{
+			std::lock_guard<std::mutex> lock(c.mtx);
+			if (code->ok) { if (fromDisk) c.diskHits++; else { c.compiled++; c.compileSeconds += code->seconds; } }
+			else { c.lastMessage = code->why; c.code.erase(key); }
+		}
+		mine.set_value(code);
+	}
+	return fut.get();
+}
+
+// one background thread works the prefetch queue off (started with the first request, asleep when the queue is empty)
+void enqueue_background(std::function<void()> job) {
+	Cache& c = cache();
+	std::lock_guard<std::mutex> lock(c.qmtx);
+	c.queue.push_back(std::move(job));
+	if (!c.workerRunning) {
+		c.workerRunning = true;
+		std::thread([&c]() {
+			for (;;) {
+				std::function<void()> next;
+				{
+					std::unique_lock<std::mutex> l(c.qmtx);
+					if (!c.qcv.wait_for(l, std::chrono::seconds(2), [&c] { return !c.queue.empty(); })) { c.workerRunning = false; return; }
+					next = std::move(c.queue.front());
+					c.queue.pop_front();
+				}
+				next();
+			}
+		}).detach();
+	} else {
+		c.qcv.notify_one();
+	}
+}
+
+bool stale_module_error(hipError_t e) {
+	return e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle || e == hipErrorContextIsDestroyed || e == hipErrorInvalidContext || e == hipErrorInvalidImage ||
+	       e == hipErrorNotFound;
 }
 
 }  // namespace
@@ -261,11 +388,12 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out, bool oldLayout) {
 
 // the build check of the run-time path, without a device: compile the instance of a length for `arch`
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why) {
-	std::vector<char> code;
-	std::lock_guard<std::mutex> lock(cache().mtx);
-	const bool ok = compileCode(d, intype, rs, mode, arch, cache().extraOptions, code, waves, seconds, why);
-	if (codeBytes) *codeBytes = code.size();
-	return ok;
+	const CodePtr code = get_code(d, intype, rs, mode, arch ? arch : "");
+	if (codeBytes) *codeBytes = code->bytes.size();
+	if (waves) *waves = code->waves;
+	if (seconds) *seconds = code->seconds;
+	if (!code->ok && why) *why = code->why;
+	return code->ok;
 }
 
 // the tables of passes 1 .. as [k][t - 1], k < NS_p, row pitch pd_tws: exp(+2 pi i t k / (NS_p R_p))
@@ -295,36 +423,102 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
 	Cache& c = cache();
-	Instance* in = nullptr;
-	{
-		std::lock_guard<std::mutex> lock(c.mtx);
-		const Key key{dev, d.N, d.padp, d.radix[0], d.radix[1], d.radix[2], d.radix[3], d.radix[4], intype, rs, mode, c.extraOptions};
-		auto it = c.entries.find(key);
-		if (it == c.entries.end()) {
-			Instance fresh;
-			compileInstance(d, intype, rs, mode, dev, c.extraOptions, fresh);
-			if (fresh.failed) c.lastMessage = fresh.why; else { c.compiled++; c.compileSeconds += fresh.compileSeconds; }
-			it = c.entries.emplace(key, fresh).first;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		Module m;
+		bool have = false;
+		std::string arch;
+		{
+			std::lock_guard<std::mutex> lock(c.mtx);
+			// (the architecture name of the device is part of the key: found through any module already loaded for it, else asked below)
+			for (auto& kv : c.modules) if (kv.first.first == dev) { arch = std::get<0>(kv.first.second); break; }
 		}
-		in = &it->second;  // (std::map: the entry stays where it is)
+		if (arch.empty()) {
+			hipDeviceProp_t prop;
+			if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+			arch = prop.gcnArchName;
+		}
+		ModuleKey mkey;
+		{
+			std::lock_guard<std::mutex> lock(c.mtx);
+			mkey = ModuleKey{dev, code_key(d, intype, rs, mode, arch, c.extraOptions)};
+			auto it = c.modules.find(mkey);
+			if (it != c.modules.end()) { m = it->second; have = true; }
+		}
+		if (!have) {
+			const CodePtr code = get_code(d, intype, rs, mode, arch);   // compiles at most once per process, outside every lock
+			if (!code->ok) { if (why) *why = code->why; return hipErrorNotSupported; }
+			int numCU = 0;
+			if ((e = hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+			Module fresh;
+			fresh.waves = code->waves;
+			fresh.numCU = numCU;
+			e = hipModuleLoadData(&fresh.module, code->bytes.data());
+			if (e == hipSuccess) e = hipModuleGetFunction(&fresh.fn, fresh.module, "oct_mxs");
+			if (e != hipSuccess) {  // not cached: the next buffer (or handle) tries again; the caller keeps its other route meanwhile
+				(void)hipGetLastError();
+				if (fresh.module) (void)hipModuleUnload(fresh.module);
+				const std::string msg = std::string("loading the compiled kernel failed: ") + hipGetErrorString(e);
+				{ std::lock_guard<std::mutex> lock(c.mtx); c.lastMessage = msg; }
+				if (why) *why = msg;
+				return hipErrorNotSupported;
+			}
+			std::lock_guard<std::mutex> lock(c.mtx);
+			auto ins = c.modules.emplace(mkey, fresh);
+			if (!ins.second) { (void)hipModuleUnload(fresh.module); }  // another thread loaded the same module meanwhile: keep that one
+			m = ins.first->second;
+		}
+		unsigned blocks = (unsigned)m.numCU;
+		const unsigned units = pair ? (a.numLines + 1u) / 2u : a.numLines;
+		const unsigned need = (units + (unsigned)m.waves - 1u) / (unsigned)m.waves;
+		if (blocks > need) blocks = need;
+		if (maxBlocks > 0 && blocks > (unsigned)maxBlocks) blocks = (unsigned)maxBlocks;
+		if (blocks == 0) return hipSuccess;
+		FusedArgs args = a;
+		void* params[] = {&args};
+		e = hipModuleLaunchKernel(m.fn, blocks, 1, 1, (unsigned)m.waves * 64u, 1, 1, 0, stream, params, nullptr);
+		if (e == hipSuccess || !stale_module_error(e) || attempt == 1) return e;
+		// the module no longer exists for the runtime (the host reset the device): forget it and load it again, once
+		(void)hipGetLastError();
+		std::lock_guard<std::mutex> lock(c.mtx);
+		c.modules.erase(mkey);
 	}
-	if (in->failed) { if (why) *why = in->why; return hipErrorNotSupported; }
-	unsigned blocks = (unsigned)in->numCU;
-	const unsigned units = pair ? (a.numLines + 1u) / 2u : a.numLines;
-	const unsigned need = (units + (unsigned)in->waves - 1u) / (unsigned)in->waves;
-	if (blocks > need) blocks = need;
-	if (maxBlocks > 0 && blocks > (unsigned)maxBlocks) blocks = (unsigned)maxBlocks;
-	if (blocks == 0) return hipSuccess;
-	FusedArgs args = a;
-	void* params[] = {&args};
-	return hipModuleLaunchKernel(in->fn, blocks, 1, 1, (unsigned)in->waves * 64u, 1, 1, 0, stream, params, nullptr);
+	return e;
 }
 
-void mixedn_rtc_set_cache_dir(const char* dir) {
+// Start compiling a variant in the background (octpipe_create / octpipe_set_params: the variants one setting away from the
+// current one), so that the buffer that first needs it does not wait 0.5-1.2 s for the compiler.  Returns at once; a variant that
+// is already there or already being compiled costs a map lookup.
+void mixedn_rtc_prefetch(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, bool bg, const char* arch) {
+	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (bg ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0);
+	if (pair && (intype != IN_U16 || roll || spectrum)) return;
+	if ((intype != IN_U16 && intype != IN_F32) || rs < RS_NONE || rs > RS_LANCZOS || (rs == RS_LANCZOS && (roll || pair)) || (roll && intype != IN_U16)) return;
 	Cache& c = cache();
+	const std::string a = arch ? arch : "";
+	{
+		std::lock_guard<std::mutex> lock(c.mtx);
+		if (c.code.count(code_key(d, intype, rs, mode, a, c.extraOptions))) return;
+	}
+	const mxs::PlanDesc plan = d;
+	enqueue_background([plan, intype, rs, mode, a]() { (void)get_code(plan, intype, rs, mode, a); });
+}
+
+// false (and *why) when the directory is not one this process may trust code from: not a directory, a symbolic link, owned by
+// somebody else, or writable by group / others
+bool mixedn_rtc_set_cache_dir(const char* dir, std::string* why) {
+	Cache& c = cache();
+	std::string d = dir ? dir : "";
+	while (d.size() > 1 && d.back() == '/') d.pop_back();
+	if (!d.empty()) {
+		struct stat st;
+		if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) { if (why) *why = "not a directory (or a symbolic link to one): " + d; return false; }
+		if (!private_to_user(st)) {
+			if (why) *why = "the kernel cache directory must belong to the calling user and must not be writable by group or others (code objects read from it run on the device): " + d;
+			return false;
+		}
+	}
 	std::lock_guard<std::mutex> lock(c.mtx);
-	c.diskDir = dir ? dir : "";
-	while (c.diskDir.size() > 1 && c.diskDir.back() == '/') c.diskDir.pop_back();
+	c.diskDir = d;
+	return true;
 }
 int mixedn_rtc_disk_hits() {
 	Cache& c = cache();

@@ -22,6 +22,7 @@
 #include "../../include/octpipe_debug.h"
 #include "host_luts.h"
 #include "launch.h"
+#include "route.h"
 #include "side_kernels.h"
 
 namespace {
@@ -117,6 +118,7 @@ struct octpipe {
 	bool mixedStatic = false;      // ... and a static-plan instance of it (mixedn_static.h, one wave per A-scan) for this length
 	oct::mxs::PlanDesc mxsPlan{};
 	std::string rtcMessage;        // why this length has no static-plan kernel although a plan exists (hiprtc not loadable ...)
+	std::string arch;              // gcnArchName of the device (key of the run-time compiled code objects)
 	f2* d_twMixedStatic = nullptr;
 	f2* d_twMixedN = nullptr;      // W_N^j, j < N
 	f2* d_twTeam = nullptr;        // N = 4096: twiddles of the 16 x 16 x 16 plan of the one-A-scan-per-team kernel (team_kernel.h)
@@ -146,6 +148,7 @@ struct octpipe {
 	void* user = nullptr;
 
 	bool timing = false;
+	unsigned timingStride = 1, timingCounter = 0;  // every timingStride-th launch of the dominant kernel is timed
 	std::vector<TimedLaunch> timed;
 	double timedMs = 0.0;
 	unsigned timedLaunches = 0;
@@ -502,6 +505,43 @@ bool needsPrepared(const octpipe* h) {
 	       (lanczos && h->params.backgroundRemoval != 0) || wideRoll;
 }
 
+// Lengths that run a kernel compiled for them at run time (mixedn_rtc.hip): start the variants this handle can reach from the
+// parameter set `q` on the library's background thread -- the one `q` itself runs first, then everything ONE setting away
+// (resampling mode, dispersion compensation = one or two A-scans per transform, scaling, rolling average, background removal in
+// the store, the spectrum output of the mean-line estimate).  A variant costs hiprtc 0.5-1.2 s; compiled by the buffer that first
+// needs it, that is a second during which the processing thread stands still.  The variant rule mirrors launchFused.
+void prefetchRunTimeVariants(const octpipe* h, const OctPipeParams& q0) {
+	if (!h->mixedStatic || h->arch.empty() || (h->route & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_NO_MIXEDN_STATIC))) return;
+	auto one = [h](const OctPipeParams& q) {
+		const bool plain16 = h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !h->forcePrepared;
+		const int rs = !q.resampling ? oct::RS_NONE : q.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC
+		             : q.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS ? oct::RS_LANCZOS : oct::RS_LINEAR;
+		const bool rollOn = q.backgroundRemoval != 0;
+		const unsigned bits = h->acq.bitDepth > 16 ? 16 : h->acq.bitDepth;
+		const uint64_t maxSample = ((1ull << bits) - 1ull) >> (q.bitshift ? 4 : 0);
+		const bool rollIn = rollOn && q.rollingAverageWindowSize > 0 && q.rollingAverageWindowSize <= oct::ROLL_PAD && 2ull * (uint64_t)q.rollingAverageWindowSize * maxSample < (1ull << 24);
+		const bool u16 = plain16 && (!rollOn || (rollIn && rs != oct::RS_LANCZOS));
+		const int intype = u16 ? oct::IN_U16 : oct::IN_F32;
+		const bool roll = u16 && rollOn;
+		const bool pair = u16 && !roll && rs != oct::RS_LANCZOS && !q.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT);
+		const bool bg = q.postProcessBackgroundRemoval && !q.sinusoidalScanCorrection && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG);
+		oct::mixedn_rtc_prefetch(h->mxsPlan, intype, rs, roll, pair, false, q.signalLogScaling != 0, bg, h->arch.c_str());
+		if (q.fixedPatternNoiseRemoval) oct::mixedn_rtc_prefetch(h->mxsPlan, intype, rs, roll, false, true, false, false, h->arch.c_str());
+	};
+	one(q0);
+	OctPipeParams q = q0;
+	q.dispersionCompensation = !q0.dispersionCompensation; one(q); q = q0;
+	q.signalLogScaling = !q0.signalLogScaling; one(q); q = q0;
+	q.backgroundRemoval = !q0.backgroundRemoval; if (q.backgroundRemoval && q.rollingAverageWindowSize <= 0) q.rollingAverageWindowSize = 64; one(q); q = q0;
+	q.postProcessBackgroundRemoval = !q0.postProcessBackgroundRemoval; one(q); q = q0;
+	q.fixedPatternNoiseRemoval = 1; one(q); q = q0;
+	for (int mode = 0; mode < 4; ++mode) {  // off, linear, cubic, Lanczos
+		q.resampling = mode != 0;
+		q.resamplingInterpolation = mode == 2 ? OCTPIPE_INTERP_CUBIC : mode == 3 ? OCTPIPE_INTERP_LANCZOS : OCTPIPE_INTERP_LINEAR;
+		one(q);
+	}
+}
+
 // unpack (+ rolling average) of `count` samples (whole lines) into a float32 buffer: the "prepared" route and octpipe_debug_unpack
 int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int rollingW) {
 	const OctPipeParams& p = h->params;
@@ -557,63 +597,36 @@ uint64_t displaySignature(const OctPipeParams& p) {
 // processDeviceRaw when every enabled view shows ONE frame (the reference's default) and nothing follows the kernel that changes
 // the volume; granted where this buffer runs the general fused kernel
 struct DispFold { float* bscan; float* enface; unsigned bscanRow0, enfaceBin, enfaceLast; bool bgPostPassFollowsUnlessFused; };
+// the facts of route.h for a live handle (kept in step with what octpipe_debug_create built: tables, plans, bound libraries)
+oct::RouteFacts routeFacts(const octpipe* h) {
+	oct::RouteFacts f;
+	f.N = h->N; f.log2n = h->log2n; f.bytesPerSample = h->bytesPerSample; f.sampleFormat = h->sampleFormat;
+	f.bitDepth = h->acq.bitDepth; f.route = h->route; f.S = h->S;
+	f.libfft = h->libfft; f.fftLibBound = h->fftExecC2C != nullptr; f.bluestein = h->bluestein; f.mixed = h->mixed;
+	f.mixedN = h->mixedN; f.mixedStatic = h->mixedStatic; f.teamTables = h->d_twTeam != nullptr && !h->mixed; f.forcePrepared = h->forcePrepared;
+	f.rowsLds = rowsKernelLds(h);
+	return f;
+}
+
 int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt, bool wantBg = false,
                 bool* bgApplied = nullptr, const DispFold* wantDisp = nullptr, bool* dispApplied = nullptr) {
 	const OctPipeParams& p = h->params;
+	// WHICH implementation: route.h (a pure function of the handle's facts and the parameter snapshot; tests/test_route.py)
+	const oct::RoutePlan plan = oct::choose_route(routeFacts(h), p, spectrum, wantBg, wantDisp != nullptr, wantDisp && wantDisp->bgPostPassFollowsUnlessFused);
+	if (plan.error) return fail(OCTPIPE_ERR_UNSUPPORTED, plan.error);
 	oct::FusedArgs a{};
-	int intype = oct::IN_U16;
-	unsigned path = 0;  // OCTPIPE_PATH_* (octpipe_debug_last_path)
-	bool roll = p.backgroundRemoval != 0;
-	int rs = oct::RS_NONE;
-	if (p.resampling) {
-		rs = p.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC
-		   : p.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS ? oct::RS_LANCZOS : oct::RS_LINEAR;
-	}
+	const int intype = plan.intype, rs = plan.rs;
+	const bool roll = plan.roll, logScale = p.signalLogScaling != 0;
 	a.raw = d_raw;
-	// N = 1664: the mixed-radix kernel takes uint16 directly; other containers / formats and the rolling average come prepared
-	const bool useMixed = h->mixed;
-	// (with the rolling average inside the two-wave team kernel, under the rule of the general kernel: W <= ROLL_PAD, exact sums)
-	const bool rollInKernel = roll && p.rollingAverageWindowSize <= oct::ROLL_PAD && rowsKernelApplies(h, p.rollingAverageWindowSize, h->S);
-	const bool mixedDirect = useMixed && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO &&
-	                         (!roll || (rollInKernel && rs != oct::RS_LANCZOS && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM)));
-	// packed 12-bit rows are decoded inside the fused kernel (1.5 B per sample from HBM) wherever the general kernel runs on
-	// raw rows; the prepared float32 route remains for N = 256, the rolling average, Lanczos and the non-power-of-two lengths
-	const bool packed = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED || h->sampleFormat == OCTPIPE_FORMAT_INT12_PACKED;
-	const bool packedDirect = packed && !h->bluestein && !h->libfft && !h->forcePrepared && h->log2n >= 9 && !roll && rs != oct::RS_LANCZOS;
-	if (packedDirect) intype = h->sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED ? oct::IN_P12U : oct::IN_P12S;
-	// likewise 8-bit containers (bitDepth <= 8, the reference's own rule cu:109-118; N >= 512) and two's complement 16 bit
-	const bool plainFused = !h->bluestein && !h->libfft && !h->forcePrepared && !roll && rs != oct::RS_LANCZOS;
-	const bool u8Direct = plainFused && h->sampleFormat == OCTPIPE_FORMAT_AUTO && h->bytesPerSample == 1 && h->log2n >= 9;
-	const bool i16Direct = plainFused && h->sampleFormat == OCTPIPE_FORMAT_INT16;
-	if (u8Direct) intype = oct::IN_U8;
-	if (i16Direct) intype = oct::IN_I16;
-	// lengths on the library route that also have a team kernel (N = 8192): everything but the spectrum output runs on it, plain
-	// uint16 rows directly, other containers (and the rolling average in front of Lanczos) through the prepared float32 rows
-	const bool teamLib = h->libfft && h->d_twTeam && !spectrum && !(h->route & OCTPIPE_ROUTE_NO_TEAM);
-	const bool teamDirect = teamLib && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO &&
-	                        (!roll || (rollInKernel && rs != oct::RS_LANCZOS));  // (rolling average in front of Lanczos: prepared rows)
-	// lengths with a generic mixed-radix plan (mixedn_kernel.h): everything but Lanczos; plain uint16 rows directly, other containers
-	// and the rolling average through the prepared float32 rows
-	// (mixedStatic: the kernel compiled for this length at run time, mixedn_static.h -- also for lengths beyond the run-time plan's 2304)
-	const bool mxnStatic = h->mixedStatic && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN_STATIC);
-	// (Lanczos: the run-time compiled kernel only; the run-time plan's kernel leaves it to the library route)
-	const bool mxn = ((h->mixedN && rs != oct::RS_LANCZOS) || mxnStatic) && !(h->route & OCTPIPE_ROUTE_NO_MIXEDN);
-	// (the kernel compiled for the length also runs the rolling average itself, under the rule of the general kernel: W <= ROLL_PAD, exact sums)
-	const bool mxnDirect = mxn && !h->forcePrepared && h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && (!roll || (rollInKernel && mxnStatic && rs != oct::RS_LANCZOS));
-	if (needsPrepared(h) && !mixedDirect && !packedDirect && !u8Direct && !i16Direct && !teamDirect && !mxnDirect) {
+	if (plan.prepared) {
 		int rc = ensure(h, (void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
-		if ((rc = launchPrepare(h, d_raw, h->d_prepared, h->S, roll ? p.rollingAverageWindowSize : 0))) return rc;
+		if ((rc = launchPrepare(h, d_raw, h->d_prepared, h->S, plan.prepareRollW))) return rc;
 		a.raw = h->d_prepared;
-		intype = oct::IN_F32;
-		roll = false;
-		path |= OCTPIPE_PATH_PREPARED_ROWS;
 	}
-	if (bgApplied) *bgApplied = false;
-	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
-	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
-	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
-	if (wantBg && !spectrum && (!h->libfft || teamLib || mxn) && (useMixed || !h->bluestein || mxn)) {
+	if (bgApplied) *bgApplied = plan.bgFused;
+	if (dispApplied) *dispApplied = plan.dispFused;
+	if (plan.bgFused) {
 		int rc = ensure(h, (void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
 		if (h->bgTermVersion != h->bgVersion || h->bgTermWeight != p.postProcessBackgroundWeight || h->bgTermOffset != p.postProcessBackgroundOffset) {
@@ -623,8 +636,10 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 			h->bgTermVersion = h->bgVersion; h->bgTermWeight = p.postProcessBackgroundWeight; h->bgTermOffset = p.postProcessBackgroundOffset;
 		}
 		a.bgTerm = h->d_bgTerm;
-		if (bgApplied) *bgApplied = true;
-		path |= OCTPIPE_PATH_FUSED_BG;
+	}
+	if (plan.dispFused) {
+		a.dispBscan = wantDisp->bscan; a.dispEnFace = wantDisp->enface;
+		a.dispBscanRow0 = wantDisp->bscanRow0; a.dispEnFaceBin = wantDisp->enfaceBin; a.dispEnFaceLast = wantDisp->enfaceLast;
 	}
 	a.out = out;
 	a.spectrum = spectrumOut;
@@ -633,7 +648,6 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	a.twiddle = h->d_twiddle;
 	a.meanLine = h->d_meanLine;
 	a.numLines = lines;
-	if (dispApplied) *dispApplied = false;
 	a.linesInBuffer = (unsigned)(h->A * h->B);
 	a.ascansPerBscan = (unsigned)h->A;
 	a.bitshift = p.bitshift;
@@ -656,73 +670,72 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		a.sA = (float)(coeff / (half * range));
 		a.sB = (float)(coeff * (-mn / range + addend));
 	}
-	// kernel timing (octpipe_enable_kernel_timing): the general fused kernel and the N = 1024 real-input kernel take the two events
-	// into their dispatch (launch.h LaunchTiming: no packet of their own on the stream); every other route is bracketed by two
+	// kernel timing (octpipe_enable_kernel_timing): the general fused kernel and the real-input kernels take the two events into
+	// their dispatch (launch.h LaunchTiming: no packet of their own on the stream); every other route is bracketed by two
 	// recorded events
 	TimedLaunch t{};
-	const bool timed = timeIt && h->timing;
-	const bool willRunFusedOrReal2 = !(mxn) && !teamLib && !h->libfft && !useMixed && !h->bluestein && !h->d_twTeam;
+	const bool timed = timeIt && h->timing && (h->timingCounter++ % h->timingStride) == 0;
 	oct::LaunchTiming lt{};
 	if (timed) {
 		HIP_TRY(hipEventCreate(&t.start));
 		HIP_TRY(hipEventCreate(&t.stop));
-		if (willRunFusedOrReal2) { lt.start = t.start; lt.stop = t.stop; }
+		if (plan.launcherTimes) { lt.start = t.start; lt.stop = t.stop; }
 		else HIP_TRY(hipEventRecord(t.start, h->stream));
 	}
-	oct::LaunchTimingScope timingScope(timed && willRunFusedOrReal2 ? &lt : nullptr);
-	if (mxn && mxnStatic) {
-		// (the probe instance compiled when the handle was created: hiprtc works in this process; an instance that fails now is an error)
+	oct::LaunchTimingScope timingScope(timed && plan.launcherTimes ? &lt : nullptr);
+	switch (plan.kind) {
+	case oct::ROUTE_KIND_MXS: {
+		// (the probe instance compiled when the handle was created: hiprtc works in this process)
 		a.twiddle = h->d_twMixedStatic;
-		path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_STATIC_PLAN;
 		std::string why;
-		if (roll) path |= OCTPIPE_PATH_ROLL_IN_KERNEL;
-		// without dispersion compensation the FFT input is real: two A-scans per transform (raw uint16 rows, image output, no rolling average)
-		const bool pair = intype == oct::IN_U16 && !roll && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT);
-		if (pair) path |= OCTPIPE_PATH_REAL_INPUT;
-		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, roll, pair, spectrum, p.signalLogScaling != 0, a, h->stream, &why, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0);
-		if (e == hipErrorNotSupported) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);
+		const hipError_t e = oct::launch_mixedn_rtc(h->mxsPlan, intype, rs, roll, plan.pair, spectrum, logScale, a, h->stream, &why, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0);
+		if (e == hipErrorNotSupported) {
+			// this variant cannot be had now (the compiler or the module loader failed: nothing of it is cached).  A handle with
+			// another route for the length -- the run-time-plan kernel, the library FFT, Bluestein -- takes that one from here on and
+			// says why (octpipe_debug_rtc_status); only a handle without any fails the buffer
+			const bool otherRoute = h->mixedN || (h->libfft && h->fftExecC2C) || h->bluestein;
+			if (timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+			if (!otherRoute) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);
+			h->mixedStatic = false;
+			h->rtcMessage = "left the run-time compiled kernel after a failure: " + why;
+			return launchFused(h, d_raw, lines, spectrum, spectrumOut, out, timeIt, wantBg, bgApplied, wantDisp, dispApplied);
+		}
 		HIP_TRY(e);
-	} else if (mxn) {
+		break;
+	}
+	case oct::ROUTE_KIND_MXN:
 		a.twiddle = h->d_twMixedN;
-		path |= OCTPIPE_PATH_MIXED_RADIX;
-		HIP_TRY(oct::launch_mixedn((unsigned)h->N, h->mxnPasses, h->mxnRadix, intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
-	} else if (teamLib && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !p.dispersionCompensation &&
-	    !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
-		// N = 8192, real FFT input (no dispersion compensation): two A-scans per team transform
+		HIP_TRY(oct::launch_mixedn((unsigned)h->N, h->mxnPasses, h->mxnRadix, intype, rs, spectrum, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_TEAM_REAL2:  // N = 4096 / 8192, real FFT input (no dispersion compensation): two A-scans per team transform
 		a.twiddle = h->d_twTeam;
-		path |= OCTPIPE_PATH_TEAM | OCTPIPE_PATH_REAL_INPUT;
-		HIP_TRY(oct::launch_team_real2(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
-	} else if (teamLib) {
+		HIP_TRY(oct::launch_team_real2(h->log2n, rs, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_TEAM:        // one A-scan per team of four / eight waves, lane-invariant tables in registers (team_kernel.h)
 		a.twiddle = h->d_twTeam;
-		path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
-		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
-	} else if (h->libfft) {
-		path |= OCTPIPE_PATH_LIBRARY_FFT;
-		if (!h->fftExecC2C) return fail(OCTPIPE_ERR_UNSUPPORTED, "this variant of this samplesPerLine needs libhipfft.so, which could not be loaded");
-		int rc = launchLibFft(h, a, rs, spectrum, p.signalLogScaling != 0);
+		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_LIBFFT: {
+		int rc = launchLibFft(h, a, rs, spectrum, logScale);
 		if (rc) return rc;
-	} else if (useMixed) {
+		break;
+	}
+	case oct::ROUTE_KIND_MIXED1664_REAL2:
 		a.lut = h->d_lutPlain;
 		a.twiddle = h->d_twMixed;
-		if (intype == oct::IN_U16 && !roll && !spectrum && rs != oct::RS_LANCZOS && !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {  // real FFT input: two A-scans per transform
-			path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_REAL_INPUT;
-			HIP_TRY(oct::launch_mixed1664_real2(rs, p.signalLogScaling != 0, a, h->stream));
-		}
-		else if (!spectrum && (rs == oct::RS_CUBIC || (roll && rs != oct::RS_LANCZOS)) && !(h->route & OCTPIPE_ROUTE_NO_TEAM)) {
-			// cubic: two waves per A-scan, the tap weights of all 13 samples of a lane in registers (team1664_kernel.h; +5 %).  Linear
-			// and no resampling are faster on the one-wave kernel (its 32 fractions per lane fit in registers): measured 354 vs 390 M
-			// and 366 vs 398 M A-scans/s
-			a.twiddle = h->d_twTeam;
-			// (`roll` still set: uint16 rows whose rolling average runs inside the team -- every resampling mode then, the one-wave
-			// kernel would need the row kernel in front of it)
-			path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
-			HIP_TRY(oct::launch_team1664(intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
-		} else {
-			path |= OCTPIPE_PATH_MIXED_RADIX;
-			HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, p.signalLogScaling != 0, a, h->stream));
-		}
-	} else if (h->bluestein) {
-		path |= OCTPIPE_PATH_BLUESTEIN;
+		HIP_TRY(oct::launch_mixed1664_real2(rs, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_TEAM1664:
+		a.lut = h->d_lutPlain;
+		a.twiddle = h->d_twTeam;
+		HIP_TRY(oct::launch_team1664(intype, rs, roll, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_MIXED1664:
+		a.lut = h->d_lutPlain;
+		a.twiddle = h->d_twMixed;
+		HIP_TRY(oct::launch_mixed1664(intype, rs, spectrum, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_BLUESTEIN: {
 		oct::BluesteinArgs b{};
 		b.samples = h->d_prepared;
 		b.out = out;
@@ -740,42 +753,25 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 		b.subtractMean = a.subtractMean;
 		b.sA = a.sA;
 		b.sB = a.sB;
-		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, p.signalLogScaling != 0, b, h->stream));
-	} else if (h->d_twTeam && oct::team_real2_supported(h->log2n) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
-	           !p.dispersionCompensation && !(h->route & (OCTPIPE_ROUTE_NO_TEAM | OCTPIPE_ROUTE_NO_REAL_INPUT))) {
-		// N = 4096, real FFT input (the reference's default: no dispersion compensation): two A-scans per team transform
-		a.twiddle = h->d_twTeam;
-		path |= OCTPIPE_PATH_TEAM | OCTPIPE_PATH_REAL_INPUT;
-		HIP_TRY(oct::launch_team_real2(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
-	} else if (h->d_twTeam && intype != oct::IN_U32 && (rs != oct::RS_LANCZOS || ((intype == oct::IN_U16 || intype == oct::IN_F32) && !roll)) &&
-	           (!roll || intype == oct::IN_U16) && !spectrum &&
-	           !(h->route & OCTPIPE_ROUTE_NO_TEAM) && (p.dispersionCompensation || intype != oct::IN_U16 || !oct::real2n_supported(h->log2n))) {
-		// N = 4096: one A-scan per team of four waves, lane-invariant tables in registers (team_kernel.h); every raw container
-		// the general kernel reads directly (uint16, int16, uint8, packed 12 bit) and the prepared float32 rows (other
-		// containers).  `roll` still set here: uint16 rows whose rolling average runs inside the kernel (needsPrepared)
-		a.twiddle = h->d_twTeam;
-		path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
-		HIP_TRY(oct::launch_team(h->log2n, intype, rs, roll, p.signalLogScaling != 0, a, h->stream));
-	} else if ((h->log2n == 10 || oct::real2n_supported(h->log2n)) && intype == oct::IN_U16 && rs != oct::RS_LANCZOS && !roll && !spectrum &&
-	           !p.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT)) {
-		// real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
-		path |= OCTPIPE_PATH_REAL_INPUT;
-		if (h->log2n == 10) HIP_TRY(oct::launch_real2(rs, p.signalLogScaling != 0, a, h->stream));
-		else HIP_TRY(oct::launch_real2n(h->log2n, rs, p.signalLogScaling != 0, a, h->stream));
-	} else {
-		path |= roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0;
-		if (wantDisp && !spectrum && (!wantDisp->bgPostPassFollowsUnlessFused || a.bgTerm)) {
-			a.dispBscan = wantDisp->bscan; a.dispEnFace = wantDisp->enface;
-			a.dispBscanRow0 = wantDisp->bscanRow0; a.dispEnFaceBin = wantDisp->enfaceBin; a.dispEnFaceLast = wantDisp->enfaceLast;
-			if (dispApplied) *dispApplied = true;
-			path |= OCTPIPE_PATH_FUSED_DISPLAY;
-		}
-		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, p.signalLogScaling != 0, a, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0, h->stream, &h->lastGrid));
+		HIP_TRY(oct::launch_bluestein(h->log2n, rs, spectrum, logScale, b, h->stream));
+		break;
 	}
-	if (!spectrum) h->lastPath = path;
+	case oct::ROUTE_KIND_REAL2:   // real FFT input (the reference's default: no dispersion compensation): two A-scans per complex transform
+		HIP_TRY(oct::launch_real2(rs, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_REAL2N:
+		HIP_TRY(oct::launch_real2n(h->log2n, rs, logScale, a, h->stream));
+		break;
+	case oct::ROUTE_KIND_FUSED:
+		HIP_TRY(oct::launch_fused(h->log2n, intype, rs, roll, spectrum, logScale, a, (h->route & OCTPIPE_ROUTE_TINY_GRID) ? 2 : 0, h->stream, &h->lastGrid));
+		break;
+	default:
+		return fail(OCTPIPE_ERR_DEVICE, "no route for this configuration");
+	}
+	if (!spectrum) h->lastPath = plan.path;
 	if (timed) {
 		if (!lt.used) {  // (a launcher that did not take the events: an empty launch, or a route bracketed from outside)
-			if (willRunFusedOrReal2) HIP_TRY(hipEventRecord(t.start, h->stream));
+			if (plan.launcherTimes) HIP_TRY(hipEventRecord(t.start, h->stream));
 			HIP_TRY(hipEventRecord(t.stop, h->stream));
 		}
 		h->timed.push_back(t);
@@ -961,14 +957,17 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	// Display frames (cu:1571-1578).  In the reference's default form -- ONE frame per enabled view, displayFunctionFrames <= 1
 	// (octalgorithmparameters.cpp:92-99) -- every pixel of them is a copy of one value of the volume this buffer writes: the B-scan
 	// frame is B-scan frameNr reversed (cu:858), the en-face frame bin frameNrEnFaceView of every A-scan (cu:909).  The fused
-	// kernel's image store writes them along (MODE_DISP) when nothing behind it changes the volume (no sinusoidal correction, no
+	// kernel's image store can write them along (MODE_DISP) when nothing behind it changes the volume (no sinusoidal correction, no
 	// background post pass); oct_display_frames_kernel remains for averaging / MIP, for the routes without MODE_DISP and for the
-	// full extraction from the other buffers of a volume after a change of the display settings.
+	// full extraction from the other buffers of a volume after a change of the display settings.  OPT-IN (OCTPIPE_ROUTE_FUSED_DISPLAY):
+	// measured on the 1024 x 512 x 256 workload the store side costs the fused kernel 4-5.5 us (the 131 072 single-dword en-face
+	// writes of a launch land in 8 192 different cache lines whatever their timing) against 4.4 us for the extraction kernel and
+	// its launch gap -- same step time within 1 %, lower kernel-only roofline fraction (profiles/r5b/c/d/e/f_*_ab.txt).
 	const bool wantViews = p.bscanViewEnabled || p.enFaceViewEnabled;
 	const int modeB = oct::display_mode(p.functionFramesBscan, p.displayFunctionBscan), modeE = oct::display_mode(p.functionFramesEnFaceView, p.displayFunctionEnFaceView);
 	DispFold fold{};
 	bool foldAsked = false, dispFused = false;
-	if (wantViews && !sinus && !(h->route & (OCTPIPE_ROUTE_NO_FUSED_DISPLAY | OCTPIPE_ROUTE_FULL_DISPLAY)) &&
+	if (wantViews && !sinus && (h->route & OCTPIPE_ROUTE_FUSED_DISPLAY) && !(h->route & OCTPIPE_ROUTE_FULL_DISPLAY) &&
 	    (!p.bscanViewEnabled || modeB == oct::DISP_SINGLE) && (!p.enFaceViewEnabled || modeE == oct::DISP_SINGLE) &&
 	    !(bgRemoval && p.postProcessBackgroundRecordingRequested)) {
 		const unsigned BV = (unsigned)B * h->acq.buffersPerVolume, W = (unsigned)(N / 2), slot = h->bufferNumberInVolume;
@@ -1128,17 +1127,15 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "packed 12-bit buffers need an even number of samples");
 	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0 || acq->buffersPerVolume == 0 || acq->bitDepth == 0 || acq->bitDepth > 32)
 		return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
-	// OCTPIPE_ROUTE_FORCE_LIBFFT: every length through the library route (measurement: the reference's multi-pass structure on this GPU)
-	// Lengths that are neither a power of two nor 1664: Bluestein on the in-register FFT (bluestein.h, up to 2047) or the library
-	// route; measured on MI355X the library route is 1.4-3x faster (N = 600: 160 vs 91 M A-scans/s, N = 2000: 48 vs 16 M), so it
-	// is the default where hipFFT can be loaded and Bluestein the fallback (OCTPIPE_ROUTE_NO_LIBFFT forces it).
-	const bool forceLib = (createRoute & OCTPIPE_ROUTE_FORCE_LIBFFT) != 0, noLib = (createRoute & OCTPIPE_ROUTE_NO_LIBFFT) != 0;
-	const bool noFused = !oct::fused_supported(acq->samplesPerLine) && acq->samplesPerLine != oct::kMixedLength;
-	const bool bluesteinOk = oct::bluestein_log2m(acq->samplesPerLine) >= 0;
-	bool needLibFft = (noFused && (!bluesteinOk || !noLib)) || forceLib;
-	if (needLibFft && bluesteinOk && !forceLib && !fftLibraryAvailable()) needLibFft = false;
-	if (needLibFft && (acq->samplesPerLine < 8 || acq->samplesPerLine > 65536))
-		return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine must lie in 8..65536");
+	// What this length runs on -- which of the kernel families exist for it, the library route, Bluestein -- is decided by
+	// route.h derive_route_facts from the acquisition parameters and the creation-time route flags alone (tests/test_route.py);
+	// whether hiprtc works in this process is found out by the probe compilation further down
+	oct::RouteFacts facts;
+	{
+		std::string why;
+		const int frc = oct::derive_route_facts(*acq, sampleFormat, createRoute, fftLibraryAvailable(), true, 0, &facts, &why);
+		if (frc) return fail(frc, why);
+	}
 	int count = 0;
 	int rc = octpipe_device_count(&count);
 	if (rc) return rc;
@@ -1154,18 +1151,12 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	h->A = (int)acq->ascansPerBscan;
 	h->B = (int)acq->bscansPerBuffer;
 	h->S = (size_t)h->N * h->A * h->B;
-	h->bytesPerSample = (int)((acq->bitDepth + 7) / 8);  // ceil(bitDepth/8), cu:1077
-	if (h->bytesPerSample == 3) h->bytesPerSample = 4;    // 17..24 bit live in uint32 (cu:122-124)
+	h->bytesPerSample = facts.bytesPerSample;  // ceil(bitDepth/8), cu:1077; 17..24 bit live in uint32 (cu:122-124)
 	h->sampleFormat = sampleFormat;  // input decode only; the output quantiser keeps following bitDepth
-	h->log2n = 0;
-	while ((1 << h->log2n) < h->N) h->log2n++;
-	if (needLibFft) {
-		h->libfft = true;
-	} else if (!oct::fused_supported(acq->samplesPerLine)) {
-		h->bluestein = true;
-		h->log2n = oct::bluestein_log2m(acq->samplesPerLine);
-		h->mixed = acq->samplesPerLine == oct::kMixedLength && !(createRoute & OCTPIPE_ROUTE_NO_MIXED);  // (A/B route: Bluestein for 1664 too)
-	}
+	h->log2n = facts.log2n;           // (Bluestein: of the padded length)
+	h->libfft = facts.libfft;
+	h->bluestein = facts.bluestein;
+	h->mixed = facts.mixed;
 	h->resample.assign(h->N, 0.0f);
 	h->dispersion.assign(h->N, 0.0f);
 	h->window.assign(h->N, 0.0f);
@@ -1213,14 +1204,17 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	if ((rc = ensure(h, (void**)&h->d_dispEnFace, sizeof(float) * ((size_t)h->A * h->B * acq->buffersPerVolume)))) return rc;
 	// lengths without a dedicated kernel: the generic mixed-radix kernel where the length factors into 2, 3, 5, 7, 11, 13 and its
 	// tables fit the LDS (mixedn_plan); the library route / Bluestein stay for Lanczos and for every other length
-	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT)) && oct::mixedn_plan(acq->samplesPerLine, &h->mxnPasses, h->mxnRadix, (createRoute & OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES) != 0)) {
+	if (facts.mixedN) {
 		h->mixedN = true;
+		h->mxnPasses = facts.mxnPasses;
+		for (int i = 0; i < 8; ++i) h->mxnRadix[i] = facts.mxnRadix[i];
 		if ((rc = uploadMixedNTable(h))) return rc;
 	}
 	// ... and, up to 4096, the static-plan kernel compiled for this very length at run time (mixedn_static.h, mixedn_rtc.hip), if hiprtc
 	// can be had in this process: a probe launch of zero A-scans compiles the most likely instance now, so that a process without a
 	// working hiprtc keeps its other route for the length and says why (octpipe_debug_rtc_status)
-	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT | OCTPIPE_ROUTE_NO_MIXEDN_STATIC)) && oct::mixedn_rtc_plan(acq->samplesPerLine, &h->mxsPlan, (createRoute & OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT) != 0)) {
+	if (facts.mixedStatic) {  // (a plan exists; the probe says whether an instance of it can be had here)
+		h->mxsPlan = facts.mxsPlan;
 		oct::FusedArgs probe{};
 		std::string why;
 		// (the instance the first buffer will most likely run with the settings the handle is created with: resampling mode, scaling, two
@@ -1238,6 +1232,9 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 			HIP_TRY(hipMalloc((void**)&h->d_twMixedStatic, sizeof(f2) * tw.size()));
 			if ((rc = uploadSync(h, h->d_twMixedStatic, tw.data(), sizeof(f2) * tw.size()))) return rc;
 			h->mixedStatic = true;
+			hipDeviceProp_t prop;
+			if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) h->arch = prop.gcnArchName; else (void)hipGetLastError();
+			prefetchRunTimeVariants(h, h->params);
 		} else {
 			(void)hipGetLastError();
 			h->rtcMessage = e == hipErrorNotSupported ? why : std::string(hipGetErrorString(e));
@@ -1245,15 +1242,16 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	}
 	if (h->libfft) {
 		rc = bindFftLibrary(h);
-		if (rc && !h->mixedN) return rc;  // (with a mixed-radix plan only Lanczos needs the library: it fails when it is asked for)
+		// (with a mixed-radix plan only Lanczos needs the library, with a kernel compiled for the length nothing does: a variant that
+		// needs the library fails when it is asked for)
+		if (rc && !h->mixedN && !h->mixedStatic) return rc;
 	}
 	else if ((rc = uploadTwiddles(h))) return rc;
 	if (h->bluestein && (rc = uploadBluesteinTables(h))) return rc;
 	if (h->mixed && (rc = uploadMixedTables(h))) return rc;
 	// power-of-two lengths with a team kernel (team_kernel.h): 4096, and 8192 next to the library route it keeps for the
 	// variants the team kernel does not cover
-	if (!h->bluestein && h->N == (1 << h->log2n) && oct::team_supported(h->log2n) && !(createRoute & OCTPIPE_ROUTE_FORCE_LIBFFT) &&
-	    (rc = uploadTeamTables(h))) return rc;
+	if (facts.teamTables && (rc = uploadTeamTables(h))) return rc;
 	{  // cu:1093
 		std::vector<float> sc((size_t)h->A);
 		octhost::sinusoidal_curve((unsigned)h->A, sc.data());
@@ -1318,9 +1316,15 @@ int octpipe_set_params(octpipe_t* h, const OctPipeParams* params) {
 	// one-shot requests stay pending until the pipeline has consumed them (cu:1524, cu:1561),
 	// even if the caller's next snapshot no longer carries them
 	const int pendingRedetermine = o.redetermineFixedPatternNoise, pendingRecord = o.postProcessBackgroundRecordingRequested;
+	const bool variantChanged = o.resampling != params->resampling || o.resamplingInterpolation != params->resamplingInterpolation ||
+	                            o.dispersionCompensation != params->dispersionCompensation || o.signalLogScaling != params->signalLogScaling ||
+	                            o.backgroundRemoval != params->backgroundRemoval || o.rollingAverageWindowSize != params->rollingAverageWindowSize ||
+	                            o.postProcessBackgroundRemoval != params->postProcessBackgroundRemoval || o.fixedPatternNoiseRemoval != params->fixedPatternNoiseRemoval ||
+	                            o.sinusoidalScanCorrection != params->sinusoidalScanCorrection || o.bitshift != params->bitshift;
 	h->params = *params;
 	h->params.redetermineFixedPatternNoise |= pendingRedetermine;
 	h->params.postProcessBackgroundRecordingRequested |= pendingRecord;
+	if (variantChanged) prefetchRunTimeVariants(h, h->params);  // (a map lookup per variant once they exist)
 	return OCTPIPE_OK;
 }
 
@@ -1611,6 +1615,36 @@ int octpipe_release_idle_streams(void) {
 	(void)hipGetLastError();
 	return OCTPIPE_OK;
 }
+// The routing decision without a device (route.h): what octpipe_debug_create would build for these acquisition parameters and what
+// the image launch (spectrum = 0) or the spectrum launch of the mean-line estimate (spectrum = 1) of a buffer with these settings
+// would run on.  assumeFftLibrary / assumeRtc: whether libhipfft.so / hiprtc are taken to be usable (what only a live process knows).
+// wantBg / wantDisp as processDeviceRaw would ask: derived here from the parameters the same way.
+int octpipe_debug_route(const OctPipeAcquisitionParams* acq, const OctPipeParams* params, int sampleFormat, unsigned routeFlags, int assumeFftLibrary, int assumeRtc,
+                        int spectrum, unsigned* path, int* kind, int* intype, int* preparedRollW) {
+	if (!acq || !params) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	if (acq->samplesPerLine == 0 || acq->ascansPerBscan == 0 || acq->bscansPerBuffer == 0) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid acquisition parameters");
+	const int n = (int)acq->samplesPerLine;
+	const size_t rowsLds = sizeof(int) * (n <= 4096 ? oct::prepare_rows_wave_lds_ints(n) : oct::prepare_rows_lds_ints(n, 512));
+	oct::RouteFacts f;
+	std::string why;
+	const int rc = oct::derive_route_facts(*acq, sampleFormat, routeFlags, assumeFftLibrary != 0, assumeRtc != 0, rowsLds, &f, &why);
+	if (rc) return fail(rc, why);
+	const OctPipeParams& p = *params;
+	const bool sinus = p.sinusoidalScanCorrection != 0, bgRemoval = p.postProcessBackgroundRemoval != 0;
+	const bool wantBg = bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !(routeFlags & OCTPIPE_ROUTE_NO_FUSED_BG);
+	const int modeB = oct::display_mode(p.functionFramesBscan, p.displayFunctionBscan), modeE = oct::display_mode(p.functionFramesEnFaceView, p.displayFunctionEnFaceView);
+	const bool wantDisp = (p.bscanViewEnabled || p.enFaceViewEnabled) && !sinus && (routeFlags & OCTPIPE_ROUTE_FUSED_DISPLAY) && !(routeFlags & OCTPIPE_ROUTE_FULL_DISPLAY) &&
+	                      (!p.bscanViewEnabled || modeB == oct::DISP_SINGLE) && (!p.enFaceViewEnabled || modeE == oct::DISP_SINGLE) &&
+	                      !(bgRemoval && p.postProcessBackgroundRecordingRequested);
+	const oct::RoutePlan plan = oct::choose_route(f, p, spectrum != 0, spectrum ? false : wantBg, spectrum ? false : wantDisp, bgRemoval);
+	if (path) *path = plan.path;
+	if (kind) *kind = plan.kind;
+	if (intype) *intype = plan.intype;
+	if (preparedRollW) *preparedRollW = plan.prepared ? plan.prepareRollW : -1;
+	if (plan.error) return fail(OCTPIPE_ERR_UNSUPPORTED, plan.error);
+	return OCTPIPE_OK;
+}
+
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path) {
 	if (!h || !path) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	*path = h->lastPath;
@@ -1631,11 +1665,8 @@ int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int
 	return OCTPIPE_OK;
 }
 int octpipe_set_kernel_cache_dir(const char* directory) {
-	if (directory && *directory) {
-		struct stat st;
-		if (stat(directory, &st) != 0 || !S_ISDIR(st.st_mode)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, std::string("not a directory: ") + directory);
-	}
-	oct::mixedn_rtc_set_cache_dir(directory);
+	std::string why;
+	if (!oct::mixedn_rtc_set_cache_dir(directory, &why)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, why);
 	return OCTPIPE_OK;
 }
 int octpipe_debug_rtc_disk_hits(int* hits) {
@@ -1744,6 +1775,8 @@ int octpipe_register_gl_buffer_volume_view(unsigned) { return fail(OCTPIPE_ERR_U
 int octpipe_enable_kernel_timing(octpipe_t* h, int enable) {
 	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
 	h->timing = enable != 0;
+	h->timingStride = enable > 1 ? (unsigned)enable : 1u;  // enable = n > 1: every n-th launch only (the events cost 2-4 us per timed launch)
+	h->timingCounter = 0;
 	return OCTPIPE_OK;
 }
 int octpipe_kernel_timing(octpipe_t* h, double* avgMs, unsigned* launches, int reset) {

@@ -245,8 +245,9 @@ class Pipeline:
         check(self._lib.octpipe_get_postprocess_background_host(self._h, out.ctypes.data, self.N // 2))
         return out
 
-    def enable_kernel_timing(self, on=True):
-        check(self._lib.octpipe_enable_kernel_timing(self._h, 1 if on else 0))
+    def enable_kernel_timing(self, on=True, every=1):
+        """HIP events around the dominant kernel of every launch (`every` = n > 1: of every n-th launch only)"""
+        check(self._lib.octpipe_enable_kernel_timing(self._h, (max(1, int(every)) if on else 0)))
 
     def kernel_timing(self, reset=True):
         ms, n = C.c_double(), C.c_uint()

@@ -30,7 +30,37 @@ DB_FLOOR = 1e-6
 # metric a transform's rounding error is uniform in (SPECTRUM_RTOL, applied to what the image still shows of the spectrum), and
 # it is what holds the weak bins, which the linear-power bound (relative to the line MAXIMUM) leaves almost free and the dB
 # comparison does not resolve: a bin at 1e-6 of the line maximum in power may be off by 1 % in amplitude, not by 1000 %.
-AMP_RTOL = 1e-5
+# Round 5: the bound follows the transform length instead of sitting 4 % above the largest value ever measured (9.6e-6 in a
+# 1500-seed run against a flat 1e-5): a float32 FFT's rounding error grows like eps x log2 N relative to the line's largest
+# amplitude, so AMP_RTOL(N) = 2e-6 x log2 N -- 1.1e-5 at N = 48, 2.0e-5 at 1024, 2.4e-5 at 4096 -- about 17 eps per pass, twice the
+# measured maxima; beyond N = 4096 the round-4 rule 1e-5 x N / 4096 (found at 8192 / 16384 on the library route) still applies
+# where it is the larger one.  The ledger reports the measured maximum and the largest measured / allowed ratio.
+AMP_RTOL = 1e-5  # (the value at N = 32: the floor of amp_rtol below; kept under its old name for the tests that quote it)
+
+
+def amp_rtol(n):
+    n = int(n)
+    return max(2e-6 * np.log2(max(n, 32)), 1e-5 * n / 4096.0)
+
+
+# A float32 IMAGE cannot carry an amplitude more finely than one unit in its last place: with linear scaling, a grey-scale range much
+# wider than the samples and an offset (addend) the image's ulp can exceed AMP_RTOL x the line's amplitude -- uint8 samples under the
+# 0 .. 900 range of the linear draws with addend -0.25: one ulp = 3.5e-6 of the line's largest amplitude -- and the two sides'
+# grey-scale arithmetic (one FMA with folded constants in the kernels, the reference's four roundings cu:739 in the oracle)
+# legitimately differ by a few ulps.  Callers that have the stored images pass `image_ulp_amp` (per bin: the amplitude equivalent of
+# one ulp of the stored value, ulp_amplitude_of_image below); such bins are allowed IMAGE_ULPS ulps on top of the relative bound.
+IMAGE_ULPS = 4.0
+
+
+def ulp_amplitude_of_image(img, p):
+    """amplitude (sqrt of the power image_to_power returns) that one unit in the last place of the float32 image value stands for;
+    linear scaling only (under log scaling an ulp is a RELATIVE amplitude step of ~1e-7 x range, far inside every bound)"""
+    if p.signalLogScaling:
+        return None
+    half = p.samplesPerLine / 2
+    rng = float(p.signalGrayscaleMax) - float(p.signalGrayscaleMin)
+    v = np.abs(np.where(np.isfinite(img), img, 0).astype(np.float32))
+    return np.spacing(v).astype(np.float64) * half * abs(rng) / abs(float(p.signalMultiplicator))
 # Mean-line subtraction cancels: a bin whose residual power is below CANCEL_FLOOR x |mean line|^2 at that bin lost more than
 # 3.5 digits to the subtraction.  A float32 transform carries ~1e-6 relative error on the UNSUBTRACTED value, so below that
 # ratio the residual's dB value is not resolved to DB_ATOL (0.065 dB = 0.75 % in amplitude needs |residual| / |mean| >= 1.3e-4,
@@ -76,14 +106,19 @@ def image_to_power(v, p):
 # (tests/conftest.py: "tolerance ledger").  `strict=True` allows none of them.
 EXEMPT_FRAC = 1e-3          # one-sided -inf: at most this fraction of the buffer's bins per call (strict: none)
 CANCEL_FRAC = 2e-2          # bins excused from the dB comparison by the cancellation rule (randomised tests only, cancel=True; measured
-                            # up to 1.2 % of a buffer on draws with large DC terms; strict: the rule does not exist)
+                            # up to 1.2 % of a buffer on draws with large DC terms; strict: the rule does not exist).  Round 5: stated PER
+                            # LINE -- the rule excuses depth bins, and a depth bin that cancels does so on most lines: at most
+                            # max(CANCEL_MIN_BINS, 2 % of the line's bins) of a line's bins.  (As a fraction of the buffer alone the
+                            # bound presumed hundreds of bins per line: ONE cancelled depth bin is 4 % of a buffer with 24 bins per
+                            # line, which is why N = 48 had left the draws in round 4; it is back.)
+CANCEL_MIN_BINS = 2
 # Bins under the dB floor are counted and reported, not bounded: on the synthetic fringes with the v1.8.0 settings the noise floor
 # sits at ~1e-6 of the line maximum (2 % of the bins under the floor at N = 1024, 41 % at N = 2048), and in the settings that
 # keep the DC term (no fixed-pattern-noise removal, or its exact cancellation without dispersion compensation) 75-97 % of the
 # bins lie more than 60 dB under it (measured, profiles/r4k_tolerance_ledger.txt).  Those bins are not unchecked: the amplitude
 # bound holds every one of them -- it is the same statement as a dB bound that widens with 1 / amplitude.
 LEDGER = {"calls": 0, "strict_calls": 0, "bins": 0, "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "db_checked": 0,
-          "max_rel": 0.0, "max_amp": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0, "worst_fraction": {"one_sided_inf": (0.0, ""), "below_db_floor": (0.0, ""), "cancelled": (0.0, "")}}
+          "max_rel": 0.0, "max_amp": 0.0, "max_amp_over_allowed": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0, "worst_fraction": {"one_sided_inf": (0.0, ""), "below_db_floor": (0.0, ""), "cancelled": (0.0, "")}}
 LAST_STATS = {}
 
 
@@ -92,7 +127,7 @@ def _ledger(stats, what):
     LEDGER["strict_calls"] += 1 if stats["strict"] else 0
     for k in ("bins", "one_sided_inf", "below_db_floor", "cancelled", "db_checked"):
         LEDGER[k] += stats[k]
-    for k in ("max_rel", "max_amp", "max_db", "max_one_sided_residue"):
+    for k in ("max_rel", "max_amp", "max_amp_over_allowed", "max_db", "max_one_sided_residue"):
         LEDGER[k] = max(LEDGER[k], stats[k])
     for k in ("one_sided_inf", "below_db_floor", "cancelled"):
         f = stats[k] / max(1, stats["bins"])
@@ -100,7 +135,7 @@ def _ledger(stats, what):
             LEDGER["worst_fraction"][k] = (f, what)
 
 
-def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_frac=None, cancel=False):
+def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_frac=None, cancel=False, image_ulp_amp=None):
     """Tolerance check of two processed buffers [lines, N/2]; returns the measured maxima (linear power relative to the line
     maximum, normalised dB); the per-call exemption counts are left in common.LAST_STATS and added to common.LEDGER.
 
@@ -132,7 +167,7 @@ def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_f
     assert g.shape == w.shape
     frac = 0.0 if strict else (EXEMPT_FRAC if exempt_frac is None else exempt_frac)
     stats = {"strict": bool(strict), "bins": int(g.size), "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "db_checked": 0,
-             "max_rel": 0.0, "max_amp": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0}
+             "max_rel": 0.0, "max_amp": 0.0, "max_amp_over_allowed": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0}
     LAST_STATS.clear(); LAST_STATS.update(stats)
     bad_g = np.isnan(g) | np.isposinf(g)
     bad_w = np.isnan(w) | np.isposinf(w)
@@ -161,14 +196,18 @@ def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_f
     amp_scale = np.sqrt(line_max)
     if mean_line is not None and p.fixedPatternNoiseRemoval:
         amp_scale = np.maximum(amp_scale, float(np.abs(np.asarray(mean_line).astype(np.complex128)[:half]).max()))
-    amp_tol = AMP_RTOL * max(1.0, int(p.samplesPerLine) / 4096.0) * (10.0 if getattr(p, "sinusoidalScanCorrection", 0) else 1.0)
+    amp_tol = amp_rtol(p.samplesPerLine) * (10.0 if getattr(p, "sinusoidalScanCorrection", 0) else 1.0)
     amp = np.abs(np.sqrt(pg) - np.sqrt(pw)) / amp_scale
     max_amp = float(amp.max())
     stats["max_amp"] = max_amp
-    if max_amp > amp_tol:
-        i = np.unravel_index(int(amp.argmax()), amp.shape)
-        raise AssertionError("%s: amplitude error %.3e > %.1e of the line's largest amplitude at line %d bin %d (powers %.4g vs %.4g, line maximum %.4g)" % (
-            what, max_amp, amp_tol, i[0], i[1], pg[i], pw[i], float(line_max[i[0], 0])))
+    # per bin: the relative bound, or -- where the caller knows the stored image's resolution -- IMAGE_ULPS units in the last place
+    allowed_amp = amp_tol if image_ulp_amp is None else np.maximum(amp_tol, IMAGE_ULPS * np.asarray(image_ulp_amp).reshape(amp.shape) / amp_scale)
+    ratio = amp / allowed_amp
+    stats["max_amp_over_allowed"] = float(ratio.max())
+    if stats["max_amp_over_allowed"] > 1.0:
+        i = np.unravel_index(int(ratio.argmax()), amp.shape)
+        raise AssertionError("%s: amplitude error %.3e > %.2e of the line's largest amplitude at line %d bin %d (powers %.4g vs %.4g, line maximum %.4g)" % (
+            what, float(amp[i]), float(np.broadcast_to(allowed_amp, amp.shape)[i]), i[0], i[1], pg[i], pw[i], float(line_max[i[0], 0])))
     max_db = 0.0
     if p.signalLogScaling:
         # float32 rounding of the transform grows with its length: beyond N = 4096 the floor moves up with N (at N = 8192 a
@@ -181,9 +220,11 @@ def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_f
             m2 = np.abs(np.asarray(mean_line).astype(np.complex128)[:half]) ** 2
             kept = strong & (pw >= CANCEL_FLOOR * m2[None, :])
             stats["cancelled"] = int((strong & ~kept).sum())
+            per_line = (strong & ~kept).sum(axis=1)
+            per_line_allowed = max(CANCEL_MIN_BINS, int(np.ceil(CANCEL_FRAC * half)))
+            assert int(per_line.max()) <= per_line_allowed, "%s: %d of a line's %d bins left out of the dB comparison by the 'cancelled' rule (allowed per line: %d)" % (
+                what, int(per_line.max()), half, per_line_allowed)
             strong = kept
-        assert stats["cancelled"] <= int(CANCEL_FRAC * g.size), "%s: %d of %d bins left out of the dB comparison by the 'cancelled' rule (allowed: %d)" % (
-            what, stats["cancelled"], g.size, int(CANCEL_FRAC * g.size))
         stats["db_checked"] = int(strong.sum())
         if strong.any():
             max_db = float(np.abs(g[strong].astype(np.float64) - w[strong]).max())

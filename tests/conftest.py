@@ -72,11 +72,12 @@ def pytest_terminal_summary(terminalreporter):
     tr.write_sep("-", "tolerance ledger (tests/common.py compare_images)")
     tr.write_line("%d image comparisons (%d strict), %d bins; every bin under the linear-power bound: max %.3e of the line maximum (bound %.0e)" % (
         L["calls"], L["strict_calls"], L["bins"], L["max_rel"], common.POWER_RTOL))
-    tr.write_line("every bin under the amplitude bound: max %.3e of the line's largest amplitude (bound %.0e, x N/4096 beyond 4096)" % (L["max_amp"], common.AMP_RTOL))
+    tr.write_line("every bin under the amplitude bound: max %.3e of the line's largest amplitude (bound 2e-6 x log2 N, or 1e-5 x N/4096 beyond 4096: 2.0e-5 at N = 1024); "
+                  "largest measured / allowed: %.3f" % (L["max_amp"], L["max_amp_over_allowed"]))
     tr.write_line("normalised dB compared on %d bins (%.4f %% of all): max %.3e (bound %.0e)" % (
         L["db_checked"], 100.0 * L["db_checked"] / max(1, L["bins"]), L["max_db"], common.DB_ATOL))
     for rule in ("one_sided_inf", "below_db_floor", "cancelled"):
         f, where = L["worst_fraction"][rule]
         tr.write_line("  exempt by '%s': %d bins = %.2e of all; worst single call %.2e of its bins (%s)" % (
             rule, L[rule], L[rule] / max(1, L["bins"]), f, where or "-"))
-    tr.write_line("  largest power (rel. to the line maximum) opposite a one-sided -inf: %.2e (bound %.0e)" % (L["max_one_sided_residue"], common.AMP_RTOL ** 2))
+    tr.write_line("  largest power (rel. to the line maximum) opposite a one-sided -inf: %.2e (the amplitude bound squared: %.1e at N = 1024)" % (L["max_one_sided_residue"], common.amp_rtol(1024) ** 2))

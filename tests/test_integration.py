@@ -39,7 +39,8 @@ def test_notifier_leg_of_the_adapter_compiles(tmp_path):
 def test_adapter_callbacks_make_no_device_call():
     """a HIP call inside a hipLaunchHostFunc callback deadlocks the stream it blocks"""
     src = open(os.path.join(ROOT, "integration", "octproz_kernels_amd.cpp")).read()
-    body = src[src.index("void onStreaming("):src.index("}  // namespace")]
+    start = src.index("void onStreaming(")
+    body = src[start:src.index("}  // namespace", start)]
     assert "octpipe_copy_postprocess_background_to_host" not in body
     assert "octpipe_get_postprocess_background_host" in body
 
@@ -52,3 +53,28 @@ def test_adapter_exports_all_legacy_entry_points():
                  "cuda_registerGlBufferBscan", "cuda_registerGlBufferEnFaceView", "cuda_registerGlBufferVolumeView",
                  "changeDisplayedBscanFrame", "changeDisplayedEnFaceFrame"]:
         assert ('extern "C" void %s(' % name in src) or ('extern "C" bool %s(' % name in src), name
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF) and os.path.isdir(QT)), reason="needs /root/reference and Qt (build container)")
+def test_adapter_links_with_the_reference_parameter_object_and_runs(tmp_path):
+    """not only a syntax check.  integration/octproz_kernels_amd.cpp + the reference's own octalgorithmparameters.cpp /
+    polynomial.cpp / windowfunction.cpp (compiled where they lie, real Qt) + liboctpipe.so become an executable
+    (integration/adapter_link_check.cpp) that calls the legacy names as Processing does: initializeCuda must return false cleanly on
+    a box without a GPU (the reference would exit() in checkCudaErrors), cleanupCuda must be safe afterwards (twice), and every field
+    of the reference's parameter object that the pipeline reads must arrive in OctPipeParams (sentinel per field, both polarities of
+    every switch; sizeof(OctPipeParams) pinned so that a field added on one side only fails the build)."""
+    exe = str(tmp_path / "adapter_link_check")
+    lib = os.path.join(ROOT, "octproz_amd")
+    cmd = ["g++", "-std=c++11", "-O1", "-fPIC", "-Wall", "-DOCTPIPE_ADAPTER_NO_NOTIFIER", "-I", os.path.join(ROOT, "include"), "-I", REF, "-I", QT, "-I", os.path.join(QT, "QtCore"),
+           os.path.join(ROOT, "integration", "adapter_link_check.cpp"), os.path.join(ROOT, "integration", "octproz_kernels_amd.cpp"),
+           os.path.join(REF, "octalgorithmparameters.cpp"), os.path.join(REF, "polynomial.cpp"), os.path.join(REF, "windowfunction.cpp"),
+           "-L" + lib, "-loctpipe", "/opt/conda/lib/libQt5Core.so.5", "-Wl,-rpath-link,/opt/conda/lib", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # Qt comes from the conda tree, whose libstdc++ is older than the one liboctpipe.so / the HIP runtime were built with: the
+    # system's is loaded first
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/conda/lib", LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libstdc++.so.6")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "adapter link check: ok" in r.stdout
+    assert ("initializeCuda -> false" in r.stdout) or ("two buffers processed" in r.stdout)
