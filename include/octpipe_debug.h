@@ -81,6 +81,9 @@ int octpipe_debug_route(const OctPipeAcquisitionParams* acq, const OctPipeParams
  * the handle's length does (h may be NULL), its plan (five radices, 0 = unused), how many instances the process has compiled, the
  * seconds that took, and why the last attempt failed / why this handle keeps another route (empty: no failure). */
 int octpipe_debug_rtc_status(const octpipe_t* h, int* usesIt, int* radices5, int* compiledInProcess, double* compileSeconds, char* message, size_t messageBytes);
+/* The variants a handle can reach next are compiled on a background thread (octpipe_create / octpipe_set_params): returns OCTPIPE_OK
+ * once none is queued or running, an error after timeoutSeconds. */
+int octpipe_debug_rtc_wait_idle(double timeoutSeconds);
 /* how many instances this process took from the directory of octpipe_set_kernel_cache_dir instead of compiling them */
 int octpipe_debug_rtc_disk_hits(int* hits);
 /* Further compiler options for the instances compiled from now on (process-wide, blank-separated, NULL = none): the A/B switches

@@ -136,7 +136,7 @@ OCTPIPE_SYMBOLS = [
 ]
 OCTPIPE_DEBUG_SYMBOLS = [
     "octpipe_debug_spectrum", "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_create",
-    "octpipe_debug_read_raw_slot", "octpipe_debug_last_grid", "octpipe_debug_last_path", "octpipe_debug_rtc_status", "octpipe_debug_rtc_compile", "octpipe_debug_rtc_set_options", "octpipe_debug_rtc_disk_hits",
+    "octpipe_debug_read_raw_slot", "octpipe_debug_last_grid", "octpipe_debug_last_path", "octpipe_debug_rtc_status", "octpipe_debug_rtc_compile", "octpipe_debug_rtc_set_options", "octpipe_debug_rtc_disk_hits", "octpipe_debug_route", "octpipe_debug_rtc_wait_idle",
 ]
 OCTHOST_SYMBOLS = [
     "octhost_buffer_create", "octhost_buffer_destroy", "octhost_buffer_allocate", "octhost_buffer_release",

@@ -43,7 +43,9 @@ struct FusedArgs {
 	unsigned ascansPerBscan;
 	int bitshift;
 	int rollingW;            // window half-size of the rolling average (ROLL variants)
-	int rollExact;           // (host-side rule, kept for the ABI of the argument block) 2 W x (largest sample value) < 2^24: integer window sums equal the reference's float sums
+	int rollExact;           // host-side rule: 1 = 2 W x (largest sample value) < 2^24, integer window sums equal the reference's float sums;
+	                         // 2 = in addition 2 W is a power of two 2^k, the sums stay below 2^23 and the samples below 2^(23-k): the whole
+	                         // windows of the row take the one-FMA form of the fused kernel (ROLL stage, round 5)
 	int flip;
 	int subtractMean;
 	float sA, sB;            // out = sA * log2(P) + sB   (LOGSCALE)   |   sA * sqrt(P) + sB   (linear)
@@ -864,12 +866,21 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					const uint32_t* loP = pfx + ROLL_PAD + 4 * lane - W;      // P[j - W]
 					const float cntIn = (float)(2 * W), rcIn = __fdiv_rn(1.0f, cntIn);
 					const bool quad = (W & 3) == 0;  // (uniform) the lane's four P[j +- W] are 16-byte aligned: one ds_read_b128 each
+					// Whole windows whose length 2 W is a power of two 2^k (the GUI's default W = 64; rollExact == 2): s / 2^k is exact, so the
+					// reference's x - RN(s / cnt) is ONE rounding of x - s 2^-k, and with s and x placed under the exponents of 2^23 and
+					// 2^(23-k) as bit patterns -- (2^23 + s) and (2^(23-k) + x) exactly -- that is one FMA: -(2^23 + s) 2^-k + (2^(23-k) + x).
+					// Five instructions per sample (subtract, or, extract, shift-or, fma) instead of nine (two conversions, multiply, two FMAs
+					// of the exact quotient, subtract); the first and the last chunk, where windows are clipped, keep the general form.
+					const bool fast = a.rollExact == 2;
+					const uint32_t kLog = 31u - (uint32_t)__builtin_clz((unsigned)(2 * W));
+					const uint32_t xBias = (150u - kLog) << 23;  // bit pattern of 2^(23-k)
 #pragma unroll
 					for (int i = 0; i < NL; i++) {
 						float o[4];
 						const uint4 x = chunk_to_uint(pre[i], 0, shift);  // (recomputed: cheaper than 16 live registers)
 						const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 						uint32_t ws[4];
+						const bool whole = fast && i > 0 && i < NL - 1;
 						if (quad) {
 							const uint4 h4 = *reinterpret_cast<const uint4*>(hiP + 256 * i), l4 = *reinterpret_cast<const uint4*>(loP + 256 * i);
 							ws[0] = h4.x - l4.x; ws[1] = h4.y - l4.y; ws[2] = h4.z - l4.z; ws[3] = h4.w - l4.w;
@@ -877,6 +888,11 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 #pragma unroll
 							for (int c = 0; c < 4; c++) ws[c] = hiP[256 * i + c] - loP[256 * i + c];
 						}
+						if (whole) {
+#pragma unroll
+							for (int c = 0; c < 4; c++)
+								o[c] = __builtin_fmaf(-__builtin_bit_cast(float, 0x4B000000u | ws[c]), rcIn, __builtin_bit_cast(float, xBias | (xs[c] << kLog)));
+						} else
 #pragma unroll
 						for (int c = 0; c < 4; c++) {
 							const float sum = (float)ws[c];

@@ -153,6 +153,7 @@ bool mixedn_rtc_set_cache_dir(const char* dir, std::string* why);
 // start compiling a variant on the background thread (returns at once; nothing happens if it exists or is under way)
 void mixedn_rtc_prefetch(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, bool bg, const char* arch);
 int mixedn_rtc_disk_hits();
+bool mixedn_rtc_wait_idle(double seconds);
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why);
 hipError_t launch_mixedn(unsigned n, int passes, const int* radix, int intype, int rs, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream);
 

@@ -128,6 +128,8 @@ struct Cache {
 	std::condition_variable qcv;
 	std::deque<std::function<void()>> queue;
 	bool workerRunning = false;
+	int pending = 0;           // jobs queued or running
+	std::condition_variable idle;
 };
 Cache& cache() { static Cache* c = new Cache; return *c; }  // (never destroyed: a detached worker may outlive static destruction)
 
@@ -306,6 +308,7 @@ void enqueue_background(std::function<void()> job) {
 	Cache& c = cache();
 	std::lock_guard<std::mutex> lock(c.qmtx);
 	c.queue.push_back(std::move(job));
+	c.pending++;
 	if (!c.workerRunning) {
 		c.workerRunning = true;
 		std::thread([&c]() {
@@ -318,6 +321,10 @@ void enqueue_background(std::function<void()> job) {
 					c.queue.pop_front();
 				}
 				next();
+				{
+					std::lock_guard<std::mutex> l(c.qmtx);
+					if (--c.pending == 0) c.idle.notify_all();
+				}
 			}
 		}).detach();
 	} else {
@@ -388,12 +395,22 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out, bool oldLayout) {
 
 // the build check of the run-time path, without a device: compile the instance of a length for `arch`
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why) {
-	const CodePtr code = get_code(d, intype, rs, mode, arch ? arch : "");
-	if (codeBytes) *codeBytes = code->bytes.size();
-	if (waves) *waves = code->waves;
-	if (seconds) *seconds = code->seconds;
-	if (!code->ok && why) *why = code->why;
-	return code->ok;
+	// (not through the in-memory cache: "compile this now" is the point of the build check; the disk cache, where switched on, applies)
+	Cache& c = cache();
+	std::string extra, diskDir;
+	{ std::lock_guard<std::mutex> lock(c.mtx); extra = c.extraOptions; diskDir = c.diskDir; }
+	std::vector<char> code;
+	bool fromDisk = false;
+	int w = 0;
+	double sec = 0.0;
+	std::string msg;
+	const bool ok = compileCode(d, intype, rs, mode, arch ? arch : "", extra, diskDir, code, &w, &sec, &msg, &fromDisk);
+	{ std::lock_guard<std::mutex> lock(c.mtx); if (ok && fromDisk) c.diskHits++; if (!ok) c.lastMessage = msg; }
+	if (codeBytes) *codeBytes = code.size();
+	if (waves) *waves = w;
+	if (seconds) *seconds = sec;
+	if (!ok && why) *why = msg;
+	return ok;
 }
 
 // the tables of passes 1 .. as [k][t - 1], k < NS_p, row pitch pd_tws: exp(+2 pi i t k / (NS_p R_p))
@@ -519,6 +536,12 @@ bool mixedn_rtc_set_cache_dir(const char* dir, std::string* why) {
 	std::lock_guard<std::mutex> lock(c.mtx);
 	c.diskDir = d;
 	return true;
+}
+// true once no background compilation is queued or running (tests; a host that wants to know when toggling is free of compile stalls)
+bool mixedn_rtc_wait_idle(double seconds) {
+	Cache& c = cache();
+	std::unique_lock<std::mutex> l(c.qmtx);
+	return c.idle.wait_for(l, std::chrono::duration<double>(seconds), [&c] { return c.pending == 0; });
 }
 int mixedn_rtc_disk_hits() {
 	Cache& c = cache();

@@ -655,7 +655,14 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	{  // integer window sums are the reference's float sums while every partial sum stays below 2^24
 		const unsigned bits = h->acq.bitDepth > 16 ? 16 : h->acq.bitDepth;
 		const uint64_t maxSample = ((1ull << bits) - 1ull) >> (p.bitshift ? 4 : 0);
-		a.rollExact = p.rollingAverageWindowSize > 0 && 2ull * (uint64_t)p.rollingAverageWindowSize * maxSample < (1ull << 24) ? 1 : 0;
+		const uint64_t W = p.rollingAverageWindowSize > 0 ? (uint64_t)p.rollingAverageWindowSize : 0;
+		a.rollExact = W > 0 && 2ull * W * maxSample < (1ull << 24) ? 1 : 0;
+		// ... and whole windows as one FMA (kernels.h ROLL stage) when 2 W = 2^k, the sums stay below 2^23 and a sample below 2^(23-k)
+		if (a.rollExact && (W & (W - 1)) == 0 && 2ull * W * maxSample < (1ull << 23)) {
+			unsigned k = 0;
+			while ((1ull << k) < 2ull * W) ++k;
+			if (k <= 22 && maxSample < (1ull << (23 - k))) a.rollExact = 2;
+		}
 	}
 	a.flip = p.bscanFlip;
 	a.subtractMean = p.fixedPatternNoiseRemoval;
@@ -1673,6 +1680,9 @@ int octpipe_debug_rtc_disk_hits(int* hits) {
 	if (!hits) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
 	*hits = oct::mixedn_rtc_disk_hits();
 	return OCTPIPE_OK;
+}
+int octpipe_debug_rtc_wait_idle(double timeoutSeconds) {
+	return oct::mixedn_rtc_wait_idle(timeoutSeconds) ? OCTPIPE_OK : fail(OCTPIPE_ERR_DEVICE, "background compilation still running");
 }
 int octpipe_debug_rtc_set_options(const char* extraOptions) {
 	oct::mixedn_rtc_set_options(extraOptions);

@@ -1,6 +1,7 @@
 """Contracts of the C ABI that only show with more than one handle, stream or buffer in play:
 per-kernel launch geometry, the library-FFT route after octpipe_set_stream, display frames after an explicit frame change,
 and the result stream (octpipe.h "result delivery")."""
+import ctypes as C
 import json
 import os
 import subprocess
@@ -201,8 +202,10 @@ def test_routing_table(N, settings, fmt, route, want):
 
 
 def test_handles_created_concurrently_share_one_run_time_compilation():
-    """four threads create a handle for the same (so far unseen) length at once and process a buffer: the instance cache of
-    csrc/mixedn_rtc.hip is behind one mutex, every (plan, container, resampling, mode) is compiled once per process and device"""
+    """four threads create a handle for the same (so far unseen) length at once and process a buffer: every (architecture, plan,
+    container, resampling, mode) is compiled ONCE per process (csrc/mixedn_rtc.hip: the first thread that needs a variant compiles it
+    outside the cache's lock, the others wait for exactly that variant), modules are loaded per device; the variants one setting away
+    are compiled on the background thread -- afterwards a fifth handle and a changed setting find everything there"""
     import threading
     import torch
     import common
@@ -239,13 +242,31 @@ def test_handles_created_concurrently_share_one_run_time_compilation():
     for i in range(4):
         assert np.array_equal(out[i].view(np.uint32), out[0].view(np.uint32))
     common.compare_images(out[0], want, p, "N=1820, four handles at once", mean_line=mean)
-    assert probe.rtc_status()["compiled_in_process"] - before == 1  # the probe instance IS the one the buffers ran (uint16, cubic, log)
-    probe.close(); o.close()
+    L = _lib.lib()
+    L.octpipe_debug_rtc_wait_idle.argtypes = [C.c_double]
+    assert L.octpipe_debug_rtc_wait_idle(C.c_double(120.0)) == 0
+    n1 = probe.rtc_status()["compiled_in_process"]
+    # the probe instance (uint16, cubic, log) IS the one the buffers ran, compiled once, plus the variants one setting away: at most
+    # 16 distinct ones whatever the number of handles (four handles compiling each for itself would be 4 x that)
+    assert 1 <= n1 - before <= 16, (before, n1)
+    q = Pipeline(p, device=0)
+    q.set_mean_line(mean, pin=True)
+    for change in ({}, {"signalLogScaling": 0}, {"signalLogScaling": 1, "resamplingInterpolation": 0}, {"resamplingInterpolation": 1, "dispersionCompensation": 0}):
+        for k, v in change.items():
+            setattr(p, k, v)
+        p.update_all_curves()
+        q.process_device(d.data_ptr()); q.synchronize()
+        assert q.last_path() & _lib.PATH_STATIC_PLAN
+    assert L.octpipe_debug_rtc_wait_idle(C.c_double(120.0)) == 0
+    # the four variants just run had all been compiled ahead (each is one setting away from the one before): whatever the last set_params
+    # queued on top of that is bounded the same way
+    assert probe.rtc_status()["compiled_in_process"] - n1 <= 12, (n1, probe.rtc_status())
+    q.close(); probe.close(); o.close()
 
 
 def test_run_time_compiled_kernel_loaded_from_the_disk_cache_gives_the_same_image(tmp_path):
     """octpipe_set_kernel_cache_dir on the GPU box: a child process compiles the instances of N = 1400 into the directory, a second
-    child loads them (no compilation) -- both images equal bit for bit"""
+    child loads them (no compilation at all, the background variants included) -- both images equal bit for bit"""
     code = r"""
 import sys, ctypes as C, numpy as np, torch, zlib
 from octproz_amd import Pipeline, _lib, synthetic_raw, v180_benchmark_params
@@ -258,6 +279,8 @@ d = torch.from_numpy(raw.view(np.uint8).reshape(-1)).to("cuda:0"); torch.cuda.sy
 q = Pipeline(p, device=0)
 q.process_device(d.data_ptr()); q.synchronize()
 assert q.last_path() & _lib.PATH_STATIC_PLAN, q.rtc_status()
+L.octpipe_debug_rtc_wait_idle.argtypes = [C.c_double]
+assert L.octpipe_debug_rtc_wait_idle(C.c_double(240.0)) == 0   # the variants one setting away, compiled on the background thread
 hits = C.c_int(0); L.octpipe_debug_rtc_disk_hits(C.byref(hits))
 st = q.rtc_status()
 print("RESULT", zlib.crc32(q.processed_host().tobytes()), hits.value, st["compiled_in_process"], "%.3f" % st["compile_seconds"])
@@ -266,20 +289,22 @@ q.close()
     env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     runs = []
     for k in range(2):
-        r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, timeout=300, env=env)
+        os.chmod(str(tmp_path), 0o700)  # (the cache directory has to be the caller's own: ADVICE r4)
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
         runs.append((int(line[1]), int(line[2]), int(line[3]), float(line[4])))
     (crc0, hits0, n0, sec0), (crc1, hits1, n1, sec1) = runs
-    assert crc0 == crc1 and hits0 == 0 and sec0 > 0.0 and hits1 == n1 >= 2 and sec1 == 0.0, runs
+    assert crc0 == crc1 and hits0 == 0 and n0 >= 2 and sec0 > 0.0 and hits1 == n0 and n1 == 0 and sec1 == 0.0, runs
     assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".co")]) == n0
 
 
 def test_a_failed_run_time_compilation_is_reported_and_survivable():
     """csrc/mixedn_rtc.hip: (1) a handle whose probe instance does not compile keeps its other HIP route for the length and says why
-    (octpipe_debug_rtc_status) -- its images are still the oracle's; (2) once a handle HAS a run-time compiled kernel, an instance that
-    fails later is an error of that call (OCTPIPE_ERR_DEVICE with the compiler's log), never a silent change of route; (3) the failure
-    is cached per option string: with the options gone the same process compiles and runs the instance."""
+    (octpipe_debug_rtc_status) -- its images are still the oracle's; (2) round 5: a handle that HAS a run-time compiled
+    kernel and meets an instance that cannot be had later does not fail the buffer either when the length has another route -- it
+    takes that route from then on and octpipe_debug_rtc_status says why, with the compiler's log; (3) failures are not cached: with
+    the options gone a new handle of the same process compiles and runs the instance."""
     import ctypes as C
     import torch
     import common
@@ -307,13 +332,19 @@ def test_a_failed_run_time_compilation_is_reported_and_survivable():
         good.process_device(d.data_ptr()); good.synchronize()
         assert good.last_path() & _lib.PATH_STATIC_PLAN, good.rtc_status()
         L.octpipe_debug_rtc_set_options(b"-DOCT_MXS_LUT_AHEAD=not_a_number")
-        with pytest.raises(RuntimeError) as err:  # (2) every instance is looked up under the current options: this one cannot be built
-            good.process_device(d.data_ptr())
-        assert "run-time compilation" in str(err.value) and "not_a_number" in str(err.value), str(err.value)
-        L.octpipe_debug_rtc_set_options(None)
-        good.process_device(d.data_ptr()); good.synchronize()  # (3)
-        common.compare_images(good.processed_host(), want, p, "N=1200 after the failed call", mean_line=o.mean_line())
+        good.process_device(d.data_ptr()); good.synchronize()  # (2) every instance is looked up under the current options: this one cannot be built
+        st = good.rtc_status()
+        assert not (good.last_path() & _lib.PATH_STATIC_PLAN) and good.last_path() & _lib.PATH_MIXED_RADIX, hex(good.last_path())
+        assert not st["uses_it"] and "left the run-time compiled kernel" in st["message"] and "not_a_number" in st["message"], st
+        common.compare_images(good.processed_host(), want, p, "N=1200 after the failed instance: the run-time plan's kernel", mean_line=o.mean_line())
         good.close()
+        L.octpipe_debug_rtc_set_options(None)
+        again = Pipeline(p, device=0)  # (3)
+        again.set_mean_line(o.mean_line(), pin=True)
+        again.process_device(d.data_ptr()); again.synchronize()
+        assert again.last_path() & _lib.PATH_STATIC_PLAN, again.rtc_status()
+        common.compare_images(again.processed_host(), want, p, "N=1200 after the failed call", mean_line=o.mean_line())
+        again.close()
     finally:
         L.octpipe_debug_rtc_set_options(None)
     o.close()

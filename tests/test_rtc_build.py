@@ -100,32 +100,63 @@ def test_lengths_without_a_static_plan_are_refused(n):
 def test_opt_in_disk_cache_of_compiled_kernels(tmp_path):
     """octpipe_set_kernel_cache_dir: off by default (nothing is written anywhere); with a directory the code object of an instance
     is written there atomically under a name that hashes everything it depends on (kernel sources, options, architecture, plan,
-    variant) and the next compilation of the same instance -- here: the device-less build check, which has no in-memory cache --
-    loads it; a truncated file is recompiled and overwritten; a different variant gets its own file"""
+    variant, hiprtc version) and the next compilation of the same instance -- here: the device-less build check, which does not use
+    the in-memory cache -- loads it; a truncated or altered file is recompiled and overwritten; a different variant gets its own
+    file.  Round 5: a code object read from disk RUNS on the device, so the directory must be the caller's own (owner,
+    no group / other write bit, no symbolic link), files are created 0600 through mkstemp and carry a header (magic, hiprtc version,
+    length, checksum) in front of the ELF."""
     import os
+    import stat
     L = _lib.lib()
     L.octpipe_last_error.restype = C.c_char_p
     hits = C.c_int(0)
+    HEADER = 32
 
     def nhits():
         assert L.octpipe_debug_rtc_disk_hits(C.byref(hits)) == 0
         return hits.value
 
     assert L.octpipe_set_kernel_cache_dir(b"/nonexistent/dir") == 1 and b"not a directory" in L.octpipe_last_error()
-    d = str(tmp_path)
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    assert L.octpipe_set_kernel_cache_dir(str(shared).encode()) == 1 and b"writable by group or others" in L.octpipe_last_error()
+    os.chmod(shared, 0o775)
+    assert L.octpipe_set_kernel_cache_dir(str(shared).encode()) == 1
+    real = tmp_path / "cache"
+    real.mkdir(mode=0o700)
+    link = tmp_path / "link"
+    os.symlink(real, link)
+    assert L.octpipe_set_kernel_cache_dir(str(link).encode()) == 1 and b"symbolic link" in L.octpipe_last_error()
+    d = str(real)
     try:
         assert L.octpipe_set_kernel_cache_dir(d.encode()) == 0
         h0 = nhits()
         rc, radices, waves, code, sec, err = _compile(1260)
         assert rc == 0 and sec > 0.0, err
         files = os.listdir(d)
-        assert len(files) == 1 and files[0].startswith("oct_mxs_") and files[0].endswith(".co") and os.path.getsize(os.path.join(d, files[0])) == code
+        assert len(files) == 1 and files[0].startswith("oct_mxs_") and files[0].endswith(".co")
+        path = os.path.join(d, files[0])
+        assert os.path.getsize(path) == code + HEADER and stat.S_IMODE(os.stat(path).st_mode) == 0o600
+        blob = open(path, "rb").read()
+        assert blob[:7] == b"OCTMXS2" and blob[HEADER:HEADER + 4] == b"\x7fELF"
         rc, radices, waves, code2, sec2, err = _compile(1260)
         assert rc == 0 and code2 == code and sec2 == 0.0 and nhits() == h0 + 1  # loaded, not compiled
-        with open(os.path.join(d, files[0]), "r+b") as f:
+        with open(path, "r+b") as f:
             f.truncate(100)
         rc, radices, waves, code3, sec3, err = _compile(1260)
-        assert rc == 0 and code3 == code and sec3 > 0.0 and nhits() == h0 + 1 and os.path.getsize(os.path.join(d, files[0])) == code
+        assert rc == 0 and code3 == code and sec3 > 0.0 and nhits() == h0 + 1 and os.path.getsize(path) == code + HEADER
+        # one flipped byte of the payload: the checksum no longer fits, the file is not trusted
+        blob = bytearray(open(path, "rb").read())
+        blob[HEADER + 200] ^= 0x40
+        open(path, "wb").write(bytes(blob))
+        os.chmod(path, 0o600)
+        rc, radices, waves, code5, sec5, err = _compile(1260)
+        assert rc == 0 and sec5 > 0.0 and nhits() == h0 + 1 and open(path, "rb").read() != bytes(blob)
+        # a file somebody else could have written (group-writable) is not read either
+        os.chmod(path, 0o660)
+        rc, radices, waves, code6, sec6, err = _compile(1260)
+        assert rc == 0 and sec6 > 0.0 and nhits() == h0 + 1 and stat.S_IMODE(os.stat(path).st_mode) == 0o600
         rc, radices, waves, code4, sec4, err = _compile(1260, IN_U16, RS_LINEAR, MODE_LOG)
         assert rc == 0 and sec4 > 0.0 and len(os.listdir(d)) == 2
     finally:
