@@ -108,11 +108,17 @@ struct FusedArgs {
 #ifndef OCT_CW11
 #define OCT_CW11 8
 #endif
+// OCT_REGTAB11 = 1 (experiment, VERDICT r4 item 2 "tables in AccVGPRs"): N = 2048 with the register tables of N = 1024 -- 128 registers of tap
+// weights + 64 of window x phasor next to 64 of data need more than 256 registers, i.e. the accumulation half of the unified
+// 512-entry file, which a wave only has at ONE wave per SIMD (4 waves per CU).  Measured: DESIGN.md 5.1, profiles/r5j_*.
+#ifndef OCT_REGTAB11
+#define OCT_REGTAB11 0
+#endif
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<10> { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 12; static constexpr int WAVES = 16, MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = OCT_REGTAB ? 8 : 15; };
-template <> struct Cfg<11> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = OCT_CW11 ? 5 : 6; static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = OCT_CW11; };
+template <> struct Cfg<11> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = OCT_CW11 ? 5 : 6; static constexpr int WAVES = 12, MINW = 3; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = OCT_REGTAB11 ? 4 : OCT_CW11; };
 template <> struct Cfg<12> { static constexpr bool PLANAR = true; static constexpr int WAVES_ROLL = 3; static constexpr int WAVES = 6,  MINW = 2; static constexpr bool LDS_LUT = false; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = false; static constexpr int WAVES_CW = 0; };
 // per kernel variant: the cubic gather with precomputed weights trades waves for a larger table
 template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
@@ -125,7 +131,7 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 #ifndef OCT_REGTAB8
 #define OCT_REGTAB8 1  // N = 256 likewise (4 samples per lane): +6.5 %
 #endif
-	static constexpr bool REGTAB = CW && (LOG2N == 10 || (LOG2N == 9 && OCT_REGTAB9 != 0) || (LOG2N == 8 && OCT_REGTAB8 != 0)) && OCT_REGTAB != 0;
+	static constexpr bool REGTAB = CW && (LOG2N == 10 || (LOG2N == 9 && OCT_REGTAB9 != 0) || (LOG2N == 8 && OCT_REGTAB8 != 0) || (LOG2N == 11 && OCT_REGTAB11 != 0 && !ROLL)) && OCT_REGTAB != 0;
 #ifndef OCT_REGLIN_SHORT
 #define OCT_REGLIN_SHORT 1  // the register tables of the linear / no-resampling variants at N = 512 and 256 too: +6 .. +12 %
 #endif
@@ -135,7 +141,7 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 	static constexpr int WAVES_PLAIN = REGLIN ? (LOG2N <= 9 ? Cfg<LOG2N>::WAVES : RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : (LZ_LDS && LOG2N == 10) ? 8 : Cfg<LOG2N>::WAVES;
 	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
 	static constexpr int WAVES = (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0 && Cfg<LOG2N>::WAVES_ROLL < WAVES_PLAIN) ? Cfg<LOG2N>::WAVES_ROLL : WAVES_PLAIN;
-	static constexpr int MINW = ((REGTAB || REGLIN) && LOG2N <= 9) ? 4 : (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN || (LZ_LDS && LOG2N == 10)) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
+	static constexpr int MINW = (REGTAB && LOG2N == 11) ? 1 : ((REGTAB || REGLIN) && LOG2N <= 9) ? 4 : (REGLIN && RS == RS_NONE && OCT_NONE12) ? 3 : (REGTAB || REGLIN || (LZ_LDS && LOG2N == 10)) ? 2 : (ROLL && Cfg<LOG2N>::WAVES_ROLL > 0) ? (WAVES + 3) / 4 : (CW && LOG2N == 11) ? (WAVES + 3) / 4 : Cfg<LOG2N>::MINW;  // waves per SIMD -> register budget
 };
 
 #ifndef OCT_CVT_PERM
@@ -871,7 +877,13 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					// 2^(23-k) as bit patterns -- (2^23 + s) and (2^(23-k) + x) exactly -- that is one FMA: -(2^23 + s) 2^-k + (2^(23-k) + x).
 					// Five instructions per sample (subtract, or, extract, shift-or, fma) instead of nine (two conversions, multiply, two FMAs
 					// of the exact quotient, subtract); the first and the last chunk, where windows are clipped, keep the general form.
-					const bool fast = a.rollExact == 2;
+#ifndef OCT_ROLL_FAST
+#define OCT_ROLL_FAST 0  // measured 1 % SLOWER than the general form (0.2198 vs 0.2174 ms per 1024 x 512 x 256 buffer, same box interleaved,
+                         // profiles/r5k_roll_fast_ab.txt): 32 VALU instructions fewer per A-scan buy nothing here -- with two waves per SIMD the
+                         // variant waits on its two dependent LDS round trips (prefix array written -> window sums read -> row written -> taps
+                         // read), not on instruction issue.  Kept as a switch and a record.
+#endif
+					const bool fast = OCT_ROLL_FAST != 0 && a.rollExact == 2;
 					const uint32_t kLog = 31u - (uint32_t)__builtin_clz((unsigned)(2 * W));
 					const uint32_t xBias = (150u - kLog) << 23;  // bit pattern of 2^(23-k)
 #pragma unroll

@@ -127,7 +127,8 @@ struct Cache {
 	std::mutex qmtx;
 	std::condition_variable qcv;
 	std::deque<std::function<void()>> queue;
-	bool workerRunning = false;
+	bool workerRunning = false, stopping = false;
+	std::thread worker;        // joined at process exit (shutdown_background): a compilation still running while the runtime tears down corrupts the heap
 	int pending = 0;           // jobs queued or running
 	std::condition_variable idle;
 };
@@ -303,20 +304,38 @@ CodePtr get_code(const mxs::PlanDesc& d, int intype, int rs, int mode, const std
 	return fut.get();
 }
 
-// one background thread works the prefetch queue off (started with the first request, asleep when the queue is empty)
+// one background thread works the prefetch queue off (started with the first request, asleep when the queue is empty, stopped and
+// joined at process exit: what is still queued then is dropped, the compilation under way is waited for)
+void shutdown_background() {
+	Cache& c = cache();
+	std::thread t;
+	{
+		std::lock_guard<std::mutex> lock(c.qmtx);
+		c.stopping = true;
+		c.pending -= (int)c.queue.size();
+		c.queue.clear();
+		c.qcv.notify_all();
+		t = std::move(c.worker);
+	}
+	if (t.joinable()) t.join();
+}
 void enqueue_background(std::function<void()> job) {
 	Cache& c = cache();
 	std::lock_guard<std::mutex> lock(c.qmtx);
+	if (c.stopping) return;
 	c.queue.push_back(std::move(job));
 	c.pending++;
 	if (!c.workerRunning) {
 		c.workerRunning = true;
-		std::thread([&c]() {
+		static bool registered = false;
+		if (!registered) { registered = true; std::atexit(shutdown_background); }
+		c.worker = std::thread([&c]() {
 			for (;;) {
 				std::function<void()> next;
 				{
 					std::unique_lock<std::mutex> l(c.qmtx);
-					if (!c.qcv.wait_for(l, std::chrono::seconds(2), [&c] { return !c.queue.empty(); })) { c.workerRunning = false; return; }
+					c.qcv.wait(l, [&c] { return c.stopping || !c.queue.empty(); });
+					if (c.stopping) { c.idle.notify_all(); return; }
 					next = std::move(c.queue.front());
 					c.queue.pop_front();
 				}
@@ -326,7 +345,7 @@ void enqueue_background(std::function<void()> job) {
 					if (--c.pending == 0) c.idle.notify_all();
 				}
 			}
-		}).detach();
+		});
 	} else {
 		c.qcv.notify_one();
 	}
@@ -541,7 +560,7 @@ bool mixedn_rtc_set_cache_dir(const char* dir, std::string* why) {
 bool mixedn_rtc_wait_idle(double seconds) {
 	Cache& c = cache();
 	std::unique_lock<std::mutex> l(c.qmtx);
-	return c.idle.wait_for(l, std::chrono::duration<double>(seconds), [&c] { return c.pending == 0; });
+	return c.idle.wait_for(l, std::chrono::duration<double>(seconds), [&c] { return c.pending <= 0 || c.stopping; });
 }
 int mixedn_rtc_disk_hits() {
 	Cache& c = cache();

@@ -80,7 +80,7 @@ def test_a_failing_rank_fails_the_launcher():
 @pytest.mark.gpu
 def test_force_dist_single_rank_rccl():
     """one rank over RCCL on the GPU box: init, calibration broadcast, barrier, all-reduce, and the real timed path"""
-    d = _run(["--force-dist", "--steps", "10", "--warmup", "2", "--warmup-seconds", "0.2", "--bscans", "32",
+    d = _run(["--force-dist", "--steps", "10", "--warmup", "2", "--warmup-seconds", "0.2", "--bscans", "32", "--time-every", "1",
               "--no-cpu-baseline", "--no-extras"], timeout=900)
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1
     assert d["value"] > 1e6 and 0.0 < d["roofline"]["frac"] < 1.0

@@ -219,6 +219,9 @@ def test_handles_created_concurrently_share_one_run_time_compilation():
     want = o.process(raw)
     mean = o.mean_line()
     probe = Pipeline(v180_benchmark_params(1024, 8, 1), device=0)
+    L = _lib.lib()
+    L.octpipe_debug_rtc_wait_idle.argtypes = [C.c_double]
+    assert L.octpipe_debug_rtc_wait_idle(C.c_double(300.0)) == 0   # (what earlier tests of the session left in the background queue)
     before = probe.rtc_status()["compiled_in_process"]
     out, errs = [None] * 4, []
 
@@ -242,13 +245,11 @@ def test_handles_created_concurrently_share_one_run_time_compilation():
     for i in range(4):
         assert np.array_equal(out[i].view(np.uint32), out[0].view(np.uint32))
     common.compare_images(out[0], want, p, "N=1820, four handles at once", mean_line=mean)
-    L = _lib.lib()
-    L.octpipe_debug_rtc_wait_idle.argtypes = [C.c_double]
     assert L.octpipe_debug_rtc_wait_idle(C.c_double(120.0)) == 0
     n1 = probe.rtc_status()["compiled_in_process"]
     # the probe instance (uint16, cubic, log) IS the one the buffers ran, compiled once, plus the variants one setting away: at most
-    # 16 distinct ones whatever the number of handles (four handles compiling each for itself would be 4 x that)
-    assert 1 <= n1 - before <= 16, (before, n1)
+    # 20 distinct ones whatever the number of handles (four handles compiling each for itself would be 4 x that)
+    assert 1 <= n1 - before <= 20, (before, n1)
     q = Pipeline(p, device=0)
     q.set_mean_line(mean, pin=True)
     for change in ({}, {"signalLogScaling": 0}, {"signalLogScaling": 1, "resamplingInterpolation": 0}, {"resamplingInterpolation": 1, "dispersionCompensation": 0}):
