@@ -5,156 +5,16 @@
 // the handle instead of module globals (cu:39-105), and every failure is a status code instead
 // of exit(EXIT_FAILURE) (helper_cuda.h:583-590).  There is no CPU fallback: without a HIP device
 // octpipe_create fails with OCTPIPE_ERR_NO_DEVICE.
-#include <dlfcn.h>
-#include <sys/stat.h>
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/octpipe.h"
-#include "../../include/octpipe_debug.h"
-#include "host_luts.h"
-#include "launch.h"
-#include "route.h"
+#include "pipe_internal.h"
 #include "side_kernels.h"
 
-namespace {
-
+namespace octimpl {
 thread_local std::string g_lastError;
-thread_local bool t_inCallback = false;  // this thread is inside a data / event callback of the pipeline (hipLaunchHostFunc)
+thread_local bool t_inCallback = false;
+}  // namespace octimpl
+using namespace octimpl;
 
-int fail(int code, const std::string& msg) {
-	g_lastError = msg;
-	return code;
-}
-
-#define HIP_TRY(expr)                                                                                         \
-	do {                                                                                                      \
-		hipError_t _e = (expr);                                                                               \
-		if (_e != hipSuccess) {                                                                               \
-			return fail(_e == hipErrorOutOfMemory ? OCTPIPE_ERR_OUT_OF_MEMORY : OCTPIPE_ERR_DEVICE,           \
-			            std::string(#expr) + ": " + hipGetErrorString(_e));                                   \
-		}                                                                                                     \
-	} while (0)
-
-struct CalibrationHeader {  // layout of the calibration blob (octpipe_export_calibration)
-	uint32_t magic, version, samplesPerLine, fixedPatternNoiseDetermined;
-};
-constexpr uint32_t kCalibMagic = 0x4F435443u;  // "OCTC"
-
-struct TimedLaunch { hipEvent_t start, stop; };
-
-}  // namespace
-
-struct octpipe {
-	int device = 0;
-	OctPipeAcquisitionParams acq{};
-	OctPipeParams params{};
-	int N = 0, A = 0, B = 0, log2n = 0, bytesPerSample = 0, sampleFormat = OCTPIPE_FORMAT_AUTO;
-	size_t S = 0;  // samplesPerBuffer
-
-	hipStream_t stream = nullptr;      // compute stream (all kernels of the chain)
-	hipStream_t copyStream = nullptr;  // H2D of the raw buffer
-	hipStream_t outStream = nullptr;   // result delivery: quantiser, both D2H copies, data callbacks (cu:1357-1386)
-	hipEvent_t chainDone = nullptr;    // compute stream: the processed slot of the current buffer is complete
-	std::vector<hipEvent_t> destRead;  // result stream: everything that reads processed destination d has finished
-	std::vector<char> destReadPending;
-	float* d_processedAlt = nullptr;   // second processed buffer (buffersPerVolume == 1 with float streaming, see octpipe.h)
-	float* d_processedCur = nullptr;   // the one of the two the last buffer went to
-	int altCur = 0;
-	unsigned route = 0;                // OCTPIPE_ROUTE_* (octpipe_debug_set_route)
-	int lastGrid = 0;
-	unsigned lastPath = 0;  // OCTPIPE_PATH_* of the last image launch
-	bool ownStream = true;
-	hipEvent_t h2dDone[2] = {nullptr, nullptr};   // raw slot filled
-	hipEvent_t slotFree[2] = {nullptr, nullptr};  // fused kernel finished reading the raw slot
-	bool slotUsed[2] = {false, false};
-	int slot = 0;
-	int lastInputSlot = -1;  // raw slot of the last octpipe_process[_async] call
-
-	void* d_raw[2] = {nullptr, nullptr};
-	float* d_prepared = nullptr;   // S floats (uint8/uint32 input, Lanczos): lazily allocated
-	float* d_processed = nullptr;  // S/2 * buffersPerVolume
-	float* d_sinusTmp = nullptr;   // S/2, lazily
-	void* d_output = nullptr;      // quantised output, lazily
-	float4* d_lut = nullptr;
-	float4* d_cubicW = nullptr;    // [N] Catmull-Rom tap weights of the resampling curve (oct_tap_weights_kernel, FusedArgs::cubicW)
-	f2* d_twiddle = nullptr;
-	f2* d_meanLine = nullptr;
-	float* d_postBg = nullptr;
-	float* d_bgTerm = nullptr;       // weight * d_postBg + offset for the removal inside the fused kernels' store
-	unsigned bgVersion = 1, bgTermVersion = 0;  // d_postBg content / what d_bgTerm was computed from
-	float bgTermWeight = 0.0f, bgTermOffset = 0.0f;
-	float* d_sinusCurve = nullptr;
-	f2* d_spectrum = nullptr;  // FPN / debug scratch, lazily
-	size_t spectrumLines = 0;
-	float4* d_segs = nullptr;
-	float* d_dispBscan = nullptr;
-	float* d_dispEnFace = nullptr;
-	uint64_t displaySig = 0;          // display settings of the last full extraction from the volume (0 = none yet)
-	uint8_t* d_volumeView = nullptr;  // [N/2][B*buffersPerVolume][A] uint8, lazily (cu:914-941 into a plain buffer)
-	bool libfft = false;       // no fused kernel for this length: gather -> hipFFT -> epilogue through a complex buffer (side_kernels.h)
-	f2* d_cplx = nullptr;      // libfft: [A*B][N] complex
-	void* fftLib = nullptr;
-	int (*fftPlan1d)(void**, int, int, int) = nullptr;       // hipfftHandle is an opaque pointer
-	int (*fftSetStream)(void*, hipStream_t) = nullptr;
-	int (*fftExecC2C)(void*, void*, void*, int) = nullptr;
-	int (*fftDestroy)(void*) = nullptr;
-	void* fftPlan[2] = {nullptr, nullptr};
-	size_t fftPlanBatch[2] = {0, 0};
-	bool mixed = false;        // samplesPerLine == 1664: mixed-radix kernel (mixed1664.h); Bluestein stays for Lanczos
-	float* d_lanczosW = nullptr;   // [N][16] Lanczos tap weights (uploaded with the LUT while that interpolation is selected)
-	float4* d_lutPlain = nullptr;  // mixed: the LUT without the Bluestein chirp folded in
-	f2* d_twMixed = nullptr;       // mixed: W_1664^{n2 k1}, [32][52]
-	bool mixedN = false;           // a generic mixed-radix plan exists for this length (mixedn_kernel.h): every variant but Lanczos runs on it
-	int mxnPasses = 0, mxnRadix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	bool mixedStatic = false;      // ... and a static-plan instance of it (mixedn_static.h, one wave per A-scan) for this length
-	oct::mxs::PlanDesc mxsPlan{};
-	std::string rtcMessage;        // why this length has no static-plan kernel although a plan exists (hiprtc not loadable ...)
-	std::string arch;              // gcnArchName of the device (key of the run-time compiled code objects)
-	f2* d_twMixedStatic = nullptr;
-	f2* d_twMixedN = nullptr;      // W_N^j, j < N
-	f2* d_twTeam = nullptr;        // N = 4096: twiddles of the 16 x 16 x 16 plan of the one-A-scan-per-team kernel (team_kernel.h)
-	bool bluestein = false;    // samplesPerLine is not a power of two: log2n = log2 of the padded length M
-	f2* d_filter = nullptr;    // [M] Bluestein filter spectrum
-	f2* d_outChirp = nullptr;  // [N] c[k] / M
-
-	std::vector<float> resample, dispersion, window, phase;  // host copies (N each, phase 2N); zero like cu:1082-1085
-	std::vector<float> h_postBg;                             // host shadow of the recorded background
-	bool lutDirty = true;
-
-	unsigned bufferNumberInVolume = 0;
-	bool fpnDetermined = false;
-	bool pinMean = false;
-	bool forcePrepared = false;
-	unsigned streamedBuffers = 0, streamingBufferNumber = 0, floatStreamingBufferNumber = 0;
-
-	void* h_buffer[2] = {nullptr, nullptr};
-	bool h_bufferRegistered[2] = {false, false};
-	void* h_stream[2] = {nullptr, nullptr};
-	void* h_floatStream[2] = {nullptr, nullptr};
-	bool floatStreamingRegistered = false;
-	size_t streamBytes = 0, floatStreamBytes = 0;
-
-	octpipe_data_callback onStreaming = nullptr, onFloatStreaming = nullptr;
-	octpipe_event_callback onBackground = nullptr;
-	void* user = nullptr;
-
-	bool timing = false;
-	unsigned timingStride = 1, timingCounter = 0;  // every timingStride-th launch of the dominant kernel is timed
-	std::vector<TimedLaunch> timed;
-	double timedMs = 0.0;
-	unsigned timedLaunches = 0;
-};
-
-namespace {
+namespace octimpl {
 
 struct CallbackCtx {  // heap object handed to hipLaunchHostFunc; freed by the callback
 	octpipe* h;
@@ -203,87 +63,7 @@ int gridFor(size_t n, int block = 256) {
 	return (int)(g > cap ? cap : (g == 0 ? 1 : g));
 }
 
-// {rho, window, phasor} per sample; a disabled stage contributes its neutral element, which is
-// exactly what the reference's 8-way kernel selection does (cu:1448-1511): x*1.0f == x.
-int uploadLut(octpipe* h) {
-	const int N = h->N;
-	std::vector<float4> lut(N), plain(h->mixed ? N : 0);
-	const OctPipeParams& p = h->params;
-	for (int j = 0; j < N; ++j) {
-		float rho = p.resampling ? h->resample[j] : (float)j;
-		// memory safety only: a curve outside [0, N-3] is undefined behaviour in the reference
-		// (octalgorithmparameters.cpp:167 clamps on the host for exactly this reason)
-		if (!(rho >= 0.0f)) rho = 0.0f;
-		if (rho > (float)(N - 3)) rho = (float)(N - 3);
-		float4 e;
-		e.x = rho;
-		e.y = p.windowing ? h->window[j] : 1.0f;
-		e.z = p.dispersionCompensation ? h->phase[2 * j] : 1.0f;
-		e.w = p.dispersionCompensation ? h->phase[2 * j + 1] : 0.0f;
-		if (h->mixed) plain[j] = e;
-		if (h->bluestein) {  // fold the input chirp c[j] = e^{+i pi j^2 / N} into the phasor (float64 product)
-			const double ang = 3.14159265358979323846 * (double)(((long long)j * j) % (2LL * N)) / (double)N;
-			const double cr = cos(ang), ci = sin(ang), pr = e.z, pi = e.w;
-			e.z = (float)(pr * cr - pi * ci);
-			e.w = (float)(pr * ci + pi * cr);
-		}
-		lut[j] = e;
-	}
-	HIP_TRY(hipMemcpyAsync(h->d_lut, lut.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
-	// the cubic variants of the fused kernel read their four tap weights per sample from a table (once per curve, not per workgroup)
-	if (!h->d_cubicW) HIP_TRY(hipMalloc((void**)&h->d_cubicW, sizeof(float4) * N));
-	hipLaunchKernelGGL(oct::oct_tap_weights_kernel, dim3((N + 255) / 256), dim3(256), 0, h->stream, h->d_lut, h->d_cubicW, N);
-	HIP_TRY(hipGetLastError());
-	if (h->mixed) HIP_TRY(hipMemcpyAsync(h->d_lutPlain, plain.data(), sizeof(float4) * N, hipMemcpyHostToDevice, h->stream));
-	if (p.resampling && p.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS) {
-		// cu:297-326: L(t) = sinc(pi t) sinc(pi t / 8) at t = rho_j - (n0_j + i), i = -7..8, float32 like the reference's device code;
-		// the weights depend on the sample index only, so they are evaluated once per curve instead of per A-scan
-		std::vector<float> w((size_t)N * 16);
-		const float PI_F = 3.141592654f, PI_OVER_8 = 0.3926990817f;
-		for (int j = 0; j < N; ++j) {
-			const float rho = lut[j].x;
-			const int n0 = (int)rho;
-			for (int i = -7; i <= 8; ++i) {
-				const float x = rho - (float)(n0 + i), ax = fabsf(x);
-				const float s1 = sinf(PI_F * ax) / (PI_F * ax), s8 = sinf(PI_OVER_8 * ax) / (PI_OVER_8 * ax);
-				w[(size_t)j * 16 + (size_t)(i + 7)] = (ax < 0.00001f) ? 1.0f : (s1 * s8);
-			}
-		}
-		if (h->mixed) {  // the mixed-radix kernel reads the weights of sample 52 q + n2 as units [q][c][n2] (coalesced across lanes)
-			std::vector<float> r(w.size());
-			for (int j = 0; j < N; ++j)
-				for (int c = 0; c < 4; ++c) std::memcpy(&r[(size_t)oct::mixed1664_lanczos_unit(j, c) * 4], &w[(size_t)j * 16 + (size_t)c * 4], 16);
-			w.swap(r);
-		}
-		if (!h->d_lanczosW) HIP_TRY(hipMalloc((void**)&h->d_lanczosW, sizeof(float) * w.size()));
-		HIP_TRY(hipMemcpyAsync(h->d_lanczosW, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice, h->stream));
-		HIP_TRY(hipStreamSynchronize(h->stream));
-	}
-	HIP_TRY(hipStreamSynchronize(h->stream));  // lut is a stack vector
-	h->lutDirty = false;
-	return OCTPIPE_OK;
-}
 
-int uploadTwiddles(octpipe* h) {
-	int radices[4];
-	const int count = oct::fused_twiddle_plan(h->log2n, radices);
-	if (count < 0) return fail(OCTPIPE_ERR_UNSUPPORTED, "no FFT plan for this samplesPerLine");
-	std::vector<f2> tw((size_t)count);
-	size_t pos = 0;
-	int ns = radices[0];
-	for (int pass = 1; pass < 4; ++pass) {
-		const int R = radices[pass];
-		if (R <= 1) break;
-		for (int t = 1; t < R; ++t)
-			for (int k = 0; k < ns; ++k) {
-				const double ang = 2.0 * 3.14159265358979323846 * (double)t * (double)k / ((double)ns * R);
-				tw[pos++] = f2{(float)cos(ang), (float)sin(ang)};
-			}
-		ns *= R;
-	}
-	HIP_TRY(hipMalloc(&h->d_twiddle, sizeof(f2) * (size_t)count));
-	return uploadSync(h, h->d_twiddle, tw.data(), sizeof(f2) * (size_t)count);
-}
 
 // lazily allocated, zero-filled device buffer.  The fill runs on the handle's compute stream and is waited for (a memset is
 // asynchronous to the host): whichever of the handle's streams touches the buffer next does so after this call has returned
@@ -295,50 +75,7 @@ int ensure(octpipe* h, void** p, size_t bytes) {
 	return OCTPIPE_OK;
 }
 
-// Bluestein tables for a non-power-of-two length N on the padded length M (float64 on the host):
-//   filter  Bt = IFFT_M(b),  b[m] = b[M-m] = conj(c[m]) for m < N, 0 elsewhere,  c[m] = e^{+i pi m^2/N}
-//   outChirp[k] = c[k] / M
-int uploadBluesteinTables(octpipe* h) {
-	const int N = h->N, M = 1 << h->log2n;
-	const double pi = 3.14159265358979323846;
-	std::vector<double> cr(N), ci(N), wr(M), wi(M);
-	for (int m = 0; m < N; ++m) {
-		const double ang = pi * (double)(((long long)m * m) % (2LL * N)) / (double)N;
-		cr[m] = cos(ang); ci[m] = sin(ang);
-	}
-	for (int j = 0; j < M; ++j) { wr[j] = cos(2.0 * pi * j / M); wi[j] = sin(2.0 * pi * j / M); }
-	std::vector<f2> filter(M), chirp(N);
-	for (int k = 0; k < M; ++k) {
-		double sr = cr[0], si = -ci[0];  // m = 0
-		for (int m = 1; m < N; ++m) {
-			// b[m] e^{+2 pi i mk/M} + b[M-m] e^{+2 pi i (M-m)k/M} = conj(c[m]) * 2 cos(2 pi mk/M)
-			const double t = 2.0 * wr[(int)(((long long)m * k) % M)];
-			sr += cr[m] * t;
-			si -= ci[m] * t;
-		}
-		filter[k] = f2{(float)sr, (float)si};
-	}
-	for (int k = 0; k < N; ++k) chirp[k] = f2{(float)(cr[k] / M), (float)(ci[k] / M)};
-	HIP_TRY(hipMalloc((void**)&h->d_filter, sizeof(f2) * M));
-	HIP_TRY(hipMalloc((void**)&h->d_outChirp, sizeof(f2) * N));
-	int rc = uploadSync(h, h->d_filter, filter.data(), sizeof(f2) * M);
-	return rc ? rc : uploadSync(h, h->d_outChirp, chirp.data(), sizeof(f2) * N);
-}
 
-// hipFFT for the lengths without a fused kernel, bound at run time (no link dependency; a process that already holds the
-// library -- PyTorch brings a copy -- reuses it)
-int bindFftLibrary(octpipe* h) {
-	const char* names[] = {"libhipfft.so.0", "libhipfft.so"};
-	for (const char* n : names) if (!h->fftLib) h->fftLib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-	for (const char* n : names) if (!h->fftLib) h->fftLib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-	if (!h->fftLib) return fail(OCTPIPE_ERR_UNSUPPORTED, "samplesPerLine outside 256..4096 / 8..2047 needs libhipfft.so, which could not be loaded");
-	h->fftPlan1d = reinterpret_cast<decltype(h->fftPlan1d)>(dlsym(h->fftLib, "hipfftPlan1d"));
-	h->fftSetStream = reinterpret_cast<decltype(h->fftSetStream)>(dlsym(h->fftLib, "hipfftSetStream"));
-	h->fftExecC2C = reinterpret_cast<decltype(h->fftExecC2C)>(dlsym(h->fftLib, "hipfftExecC2C"));
-	h->fftDestroy = reinterpret_cast<decltype(h->fftDestroy)>(dlsym(h->fftLib, "hipfftDestroy"));
-	if (!h->fftPlan1d || !h->fftSetStream || !h->fftExecC2C || !h->fftDestroy) return fail(OCTPIPE_ERR_UNSUPPORTED, "libhipfft.so lacks the C2C entry points");
-	return OCTPIPE_OK;
-}
 
 // gather -> batched inverse C2C -> epilogue for `lines` A-scans of the prepared float32 buffer (cufftExecC2C cu:1514-1515)
 int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, bool logScale) {
@@ -407,60 +144,8 @@ void keepIdleStreams(int device, hipStream_t compute, hipStream_t copy, hipStrea
 	destroyStreams(s);
 }
 
-int uploadTeamTables(octpipe* h) {
-	std::vector<f2> tw((size_t)oct::team_twiddle_count(h->log2n));
-	size_t pos = 0;
-	const int radix[3] = {16, oct::team_last_radix(h->log2n), 2}, ns[3] = {16, 256, 4096};
-	const int passes = h->log2n == 13 ? 3 : 2;  // N = 8192: 16 x 16 x 16 x 2
-	for (int pass = 0; pass < passes; ++pass)
-		for (int t = 1; t < radix[pass]; ++t)
-			for (int k = 0; k < ns[pass]; ++k) {
-				const double ang = 2.0 * 3.14159265358979323846 * (double)t * (double)k / ((double)ns[pass] * radix[pass]);
-				tw[pos++] = f2{(float)cos(ang), (float)sin(ang)};
-			}
-	if (pos != tw.size()) return fail(OCTPIPE_ERR_DEVICE, "team twiddle table size mismatch");
-	HIP_TRY(hipMalloc((void**)&h->d_twTeam, sizeof(f2) * tw.size()));
-	return uploadSync(h, h->d_twTeam, tw.data(), sizeof(f2) * tw.size());
-}
 
-// the one twiddle table of the generic mixed-radix kernel: W_N^j = e^{+2 pi i j / N}, j < N
-int uploadMixedNTable(octpipe* h) {
-	const int N = h->N;
-	std::vector<f2> tw((size_t)N);
-	for (int j = 0; j < N; ++j) {
-		const double ang = 2.0 * 3.14159265358979323846 * (double)j / (double)N;
-		tw[(size_t)j] = f2{(float)cos(ang), (float)sin(ang)};
-	}
-	HIP_TRY(hipMalloc((void**)&h->d_twMixedN, sizeof(f2) * tw.size()));
-	return uploadSync(h, h->d_twMixedN, tw.data(), sizeof(f2) * tw.size());
-}
 
-// twiddles between the 32-point and the 52-point stage of the N = 1664 plan: W^{n2 k1}, W = e^{+2 pi i / 1664}, as [k1][n2]
-int uploadMixedTables(octpipe* h) {
-	const int N = 1664, N1 = 32, N2 = 52;
-	std::vector<f2> tw((size_t)N1 * N2);
-	for (int k1 = 0; k1 < N1; ++k1)
-		for (int n2 = 0; n2 < N2; ++n2) {
-			const double ang = 2.0 * 3.14159265358979323846 * (double)((k1 * n2) % N) / (double)N;
-			tw[(size_t)k1 * N2 + n2] = f2{(float)cos(ang), (float)sin(ang)};
-		}
-	HIP_TRY(hipMalloc((void**)&h->d_twMixed, sizeof(f2) * tw.size()));
-	if (int rcUp = uploadSync(h, h->d_twMixed, tw.data(), sizeof(f2) * tw.size())) return rcUp;
-	HIP_TRY(hipMalloc((void**)&h->d_lutPlain, sizeof(float4) * N));
-	// the two-wave team kernel of the length (team1664_kernel.h, 13 x 16 x 8): [t-1][r] of pass 2, then [t-1][b] of pass 3
-	std::vector<f2> tt((size_t)oct::team1664_twiddle_count());
-	size_t pos = 0;
-	const int radix[2] = {16, 8}, ns[2] = {13, 208};
-	for (int pass = 0; pass < 2; ++pass)
-		for (int t = 1; t < radix[pass]; ++t)
-			for (int k = 0; k < ns[pass]; ++k) {
-				const double ang = 2.0 * 3.14159265358979323846 * (double)t * (double)k / ((double)ns[pass] * radix[pass]);
-				tt[pos++] = f2{(float)cos(ang), (float)sin(ang)};
-			}
-	if (pos != tt.size()) return fail(OCTPIPE_ERR_DEVICE, "team twiddle table size mismatch");
-	HIP_TRY(hipMalloc((void**)&h->d_twTeam, sizeof(f2) * tt.size()));
-	return uploadSync(h, h->d_twTeam, tt.data(), sizeof(f2) * tt.size());
-}
 
 // bytes of one raw buffer: S * bytesPerSample, 1.5 B/sample for the packed formats
 size_t rawBytes(const octpipe* h) {
@@ -578,18 +263,6 @@ int launchPrepare(octpipe* h, const void* d_raw, float* d_out, size_t count, int
 	return OCTPIPE_OK;
 }
 
-// one launch of the fused kernel over `lines` A-scans of the raw buffer d_raw
-// Signature of the display settings: while it is unchanged only the buffer just written can have changed the frames, and
-// the extraction (cu:1571-1578) is restricted to it: the en-face pixels of its A-scans (every pixel depends on its own
-// A-scan alone) and the B-scan frame only when the displayed B-scan(s) lie in it.  With several buffers per volume this
-// keeps the extraction from re-reading the whole volume for every buffer.
-uint64_t displaySignature(const OctPipeParams& p) {
-	uint64_t s = 1469598103934665603ull;
-	const uint32_t f[] = {(uint32_t)p.bscanViewEnabled, (uint32_t)p.enFaceViewEnabled, p.frameNr, p.functionFramesBscan, (uint32_t)p.displayFunctionBscan,
-	                      p.frameNrEnFaceView, p.functionFramesEnFaceView, (uint32_t)p.displayFunctionEnFaceView};
-	for (uint32_t v : f) { s ^= v; s *= 1099511628211ull; }
-	return s | 1ull;
-}
 
 // wantBg: fold the post-process background removal into the image store if this buffer's route has such a kernel (raw uint16 rows
 // without the in-kernel rolling average through the fused / real-input / mixed-radix kernels); *bgApplied tells the caller
@@ -828,60 +501,6 @@ int minVarianceMean(octpipe* h, const f2* d_in, int width, int height, f2* d_mea
 	return OCTPIPE_OK;
 }
 
-// display-frame extraction (cu:1223-1308): one launch for the B-scan frame (blocks first) and / or the en-face frame
-template <int MB, int VB, int ME>
-void launchDisplayT(const oct::DisplayArgs& d, unsigned enfaceBlocks, hipStream_t st) {
-	hipLaunchKernelGGL((oct::oct_display_frames_kernel<MB, VB, ME>), dim3(d.bscanBlocks + enfaceBlocks), dim3(256), 0, st, d);
-}
-template <int MB, int VB>
-void launchDisplayE(int me, const oct::DisplayArgs& d, unsigned eb, hipStream_t st) {
-	if (me == oct::DISP_AVG) launchDisplayT<MB, VB, oct::DISP_AVG>(d, eb, st);
-	else if (me == oct::DISP_MIP) launchDisplayT<MB, VB, oct::DISP_MIP>(d, eb, st);
-	else launchDisplayT<MB, VB, oct::DISP_SINGLE>(d, eb, st);
-}
-template <int VB>
-void launchDisplayB(int mb, int me, const oct::DisplayArgs& d, unsigned eb, hipStream_t st) {
-	if (mb == oct::DISP_AVG) launchDisplayE<oct::DISP_AVG, VB>(me, d, eb, st);
-	else if (mb == oct::DISP_MIP) launchDisplayE<oct::DISP_MIP, VB>(me, d, eb, st);
-	else launchDisplayE<oct::DISP_SINGLE, VB>(me, d, eb, st);
-}
-// bscan / enface: which frames to extract; a display function other than averaging / MIP with frames > 1 leaves the frame
-// untouched like the reference's switch (cu:826-846)
-int updateDisplay(octpipe* h, bool bscan, unsigned frameNrB, unsigned framesB, int fnB, bool enface, unsigned frameNrE, unsigned framesE, int fnE,
-                  bool currentBufferOnly = false) {
-	oct::DisplayArgs d{};
-	d.dispBscan = h->d_dispBscan; d.dispEnFace = h->d_dispEnFace; d.vol = h->d_processedCur;
-	d.bscansPerVolume = (unsigned)h->B * h->acq.buffersPerVolume;
-	d.nBscan = (unsigned)(h->N * h->A / 2);
-	d.frameNrBscan = frameNrB < d.bscansPerVolume ? frameNrB : 0;   // cu:1269
-	d.framesBscan = framesB;
-	d.frameWidth = (unsigned)(h->N / 2);
-	d.nEnFace = d.bscansPerVolume * (unsigned)h->A;
-	d.frameNrEnFace = frameNrE < d.frameWidth ? frameNrE : 0;       // cu:1288
-	d.framesEnFace = framesE;
-	const int mb = oct::display_mode(framesB, fnB), me = oct::display_mode(framesE, fnE);
-	if (mb < 0) bscan = false;
-	if (me < 0) enface = false;
-	if (!bscan && !enface) return OCTPIPE_OK;
-	d.enFaceFirst = 0;
-	d.enFaceCount = d.nEnFace;
-	if (currentBufferOnly) {
-		const unsigned slot = h->bufferNumberInVolume, B = (unsigned)h->B;
-		d.enFaceFirst = slot * B * (unsigned)h->A;
-		d.enFaceCount = B * (unsigned)h->A;
-		// the B-scan frame reads B-scans frameNr .. frameNr + frames - 1 (those that exist): untouched unless one lies in this buffer
-		const unsigned lastB = d.frameNrBscan + (framesB > 1 ? framesB - 1 : 0);
-		if (d.frameNrBscan >= (slot + 1) * B || lastB < slot * B) bscan = false;
-		if (!bscan && !enface) return OCTPIPE_OK;
-	}
-	const int vec = (d.nBscan % 4 == 0) ? 4 : 1;
-	d.bscanBlocks = bscan ? (unsigned)((d.nBscan / vec + 255) / 256) : 0u;
-	const unsigned eb = enface ? (d.enFaceCount + 255) / 256 : 0u;
-	if (vec == 4) launchDisplayB<4>(mb, me, d, eb, h->stream);
-	else launchDisplayB<1>(mb, me, d, eb, h->stream);
-	HIP_TRY(hipGetLastError());
-	return OCTPIPE_OK;
-}
 
 // sinusoidal correction and / or background removal in one pass (in == out unless sinus)
 template <int VEC>
@@ -1093,7 +712,7 @@ int setDevice(const octpipe* h) {
 	return OCTPIPE_OK;
 }
 
-}  // namespace
+}  // namespace octimpl
 
 extern "C" {
 
@@ -1341,96 +960,8 @@ int octpipe_get_acquisition_params(const octpipe_t* h, OctPipeAcquisitionParams*
 	return OCTPIPE_OK;
 }
 
-int octpipe_update_resample_curve(octpipe_t* h, const float* curve, int size) {
-	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
-	if (curve && size > 0 && size <= h->N) {  // the reference's own guard, cu:970
-		std::memcpy(h->resample.data(), curve, sizeof(float) * (size_t)size);
-		h->lutDirty = true;
-	}
-	return OCTPIPE_OK;
-}
-int octpipe_update_dispersion_curve(octpipe_t* h, const float* curve, int size) {
-	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
-	if (curve && size > 0 && size <= h->N) {
-		std::memcpy(h->dispersion.data(), curve, sizeof(float) * (size_t)size);
-		octhost::dispersive_phase(h->dispersion.data(), (unsigned)h->N, h->phase.data());  // fillDispersivePhase, cu:1439
-		h->lutDirty = true;
-	}
-	return OCTPIPE_OK;
-}
-int octpipe_update_window_curve(octpipe_t* h, const float* curve, int size) {
-	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
-	if (curve && size > 0 && size <= h->N) {
-		std::memcpy(h->window.data(), curve, sizeof(float) * (size_t)size);
-		h->lutDirty = true;
-	}
-	return OCTPIPE_OK;
-}
-int octpipe_update_postprocess_background(octpipe_t* h, const float* background, int size) {
-	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
-	if (background && size > 0 && size <= h->N / 2) {
-		int rc = setDevice(h); if (rc) return rc;
-		std::memcpy(h->h_postBg.data(), background, sizeof(float) * (size_t)size);
-		HIP_TRY(hipMemcpyAsync(h->d_postBg, h->h_postBg.data(), sizeof(float) * (size_t)size, hipMemcpyHostToDevice, h->stream));
-		h->bgVersion++;
-		HIP_TRY(hipStreamSynchronize(h->stream));
-	}
-	return OCTPIPE_OK;
-}
-int octpipe_copy_postprocess_background_to_host(octpipe_t* h, float* background, int size) {
-	if (!h || !background || size <= 0 || size > h->N / 2) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
-	int rc = setDevice(h); if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(background, h->d_postBg, sizeof(float) * (size_t)size, hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(hipStreamSynchronize(h->stream));
-	return OCTPIPE_OK;
-}
 
-int octpipe_get_postprocess_background_host(const octpipe_t* h, float* background, int size) {
-	if (!h || !background || size <= 0 || size > h->N / 2) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
-	std::memcpy(background, h->h_postBg.data(), sizeof(float) * (size_t)size);  // no HIP call: safe inside a callback
-	return OCTPIPE_OK;
-}
 
-size_t octpipe_calibration_size(const octpipe_t* h) {
-	if (!h) return 0;
-	const size_t N = (size_t)h->N;
-	return sizeof(CalibrationHeader) + sizeof(float) * (N /*resample*/ + N /*dispersion*/ + N /*window*/ + 2 * N /*mean line*/ + N / 2 /*post bg*/);
-}
-int octpipe_export_calibration(octpipe_t* h, void* blob, size_t size) {
-	if (!h || !blob || size < octpipe_calibration_size(h)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "calibration blob too small");
-	int rc = setDevice(h); if (rc) return rc;
-	const size_t N = (size_t)h->N;
-	char* p = static_cast<char*>(blob);
-	CalibrationHeader hd{kCalibMagic, 1u, (uint32_t)h->N, h->fpnDetermined ? 1u : 0u};
-	std::memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
-	std::memcpy(p, h->resample.data(), sizeof(float) * N); p += sizeof(float) * N;
-	std::memcpy(p, h->dispersion.data(), sizeof(float) * N); p += sizeof(float) * N;
-	std::memcpy(p, h->window.data(), sizeof(float) * N); p += sizeof(float) * N;
-	// behind everything the compute stream still has to do to them (the mean-line estimate of the buffer just enqueued)
-	HIP_TRY(hipMemcpyAsync(p, h->d_meanLine, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, h->stream)); p += sizeof(float) * 2 * N;
-	return downloadSync(h, p, h->d_postBg, sizeof(float) * (N / 2));
-}
-int octpipe_import_calibration(octpipe_t* h, const void* blob, size_t size) {
-	if (!h || !blob || size < octpipe_calibration_size(h)) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "calibration blob too small");
-	int rc = setDevice(h); if (rc) return rc;
-	const size_t N = (size_t)h->N;
-	const char* p = static_cast<const char*>(blob);
-	CalibrationHeader hd;
-	std::memcpy(&hd, p, sizeof(hd)); p += sizeof(hd);
-	if (hd.magic != kCalibMagic || hd.samplesPerLine != (uint32_t)h->N) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "calibration blob does not match this pipeline");
-	std::memcpy(h->resample.data(), p, sizeof(float) * N); p += sizeof(float) * N;
-	std::memcpy(h->dispersion.data(), p, sizeof(float) * N); p += sizeof(float) * N;
-	std::memcpy(h->window.data(), p, sizeof(float) * N); p += sizeof(float) * N;
-	octhost::dispersive_phase(h->dispersion.data(), (unsigned)h->N, h->phase.data());
-	// on the compute stream, i.e. behind the kernels already enqueued there and in front of those of the next buffer
-	HIP_TRY(hipMemcpyAsync(h->d_meanLine, p, sizeof(float) * 2 * N, hipMemcpyHostToDevice, h->stream)); p += sizeof(float) * 2 * N;
-	if ((rc = uploadSync(h, h->d_postBg, p, sizeof(float) * (N / 2)))) return rc;
-	h->bgVersion++;
-	std::memcpy(h->h_postBg.data(), p, sizeof(float) * (N / 2));
-	h->fpnDetermined = hd.fixedPatternNoiseDetermined != 0;
-	h->lutDirty = true;
-	return OCTPIPE_OK;
-}
 
 int octpipe_process_async(octpipe_t* h, const void* h_inputSignal) {
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
@@ -1516,22 +1047,6 @@ int octpipe_set_stream(octpipe_t* h, void* stream) {
 	return OCTPIPE_OK;
 }
 
-int octpipe_get_mean_line(octpipe_t* h, float* m) {
-	if (!h || !m) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
-	int rc = setDevice(h); if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(m, h->d_meanLine, sizeof(f2) * h->N, hipMemcpyDeviceToHost, h->stream));
-	HIP_TRY(hipStreamSynchronize(h->stream));
-	return OCTPIPE_OK;
-}
-int octpipe_set_mean_line(octpipe_t* h, const float* m, int pin) {
-	if (!h || !m) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
-	int rc = setDevice(h); if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(h->d_meanLine, m, sizeof(f2) * h->N, hipMemcpyHostToDevice, h->stream));
-	HIP_TRY(hipStreamSynchronize(h->stream));
-	h->fpnDetermined = true;
-	h->pinMean = pin != 0;
-	return OCTPIPE_OK;
-}
 
 int octpipe_min_variance_mean(octpipe_t* h, const float* data, int isDevice, int width, int height, float* meanOut) {
 	if (!h || !data || !meanOut || width <= 0 || height <= 0) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "invalid argument");
@@ -1749,26 +1264,6 @@ int octpipe_set_callbacks(octpipe_t* h, octpipe_data_callback onStreamingData, o
 	return OCTPIPE_OK;
 }
 
-int octpipe_change_displayed_bscan_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1223-1240
-	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
-	int rc = setDevice(h); if (rc) return rc;
-	h->displaySig = 0;  // the frame no longer shows what params describe: the next buffer extracts both frames in full (cu:1571-1578)
-	return updateDisplay(h, true, frameNr, frames, fn, false, 0, 1, 0);
-}
-int octpipe_change_displayed_enface_frame(octpipe_t* h, unsigned frameNr, unsigned frames, int fn) {  // cu:1243-1265
-	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
-	int rc = setDevice(h); if (rc) return rc;
-	h->displaySig = 0;
-	return updateDisplay(h, false, 0, 1, 0, true, frameNr, frames, fn);
-}
-int octpipe_get_display_buffers(octpipe_t* h, void** d_bscanFrame, size_t* bscanCount, void** d_enFaceFrame, size_t* enFaceCount) {
-	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
-	if (d_bscanFrame) *d_bscanFrame = h->d_dispBscan;
-	if (bscanCount) *bscanCount = (size_t)h->N * h->A / 2;
-	if (d_enFaceFrame) *d_enFaceFrame = h->d_dispEnFace;
-	if (enFaceCount) *enFaceCount = (size_t)h->A * h->B * h->acq.buffersPerVolume;
-	return OCTPIPE_OK;
-}
 int octpipe_get_volume_view_buffer(octpipe_t* h, void** d_voxels, size_t* bytes) {
 	if (!h) return fail(OCTPIPE_ERR_NOT_INITIALIZED, "pipeline is not initialized");
 	int rc = setDevice(h); if (rc) return rc;
