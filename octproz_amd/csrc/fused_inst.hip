@@ -2,7 +2,7 @@
 // (compiled once per OCT_LOG2N so the lengths build in parallel).
 #include "kernels.h"
 #include "launch.h"
-#if OCT_LOG2N == 8 || OCT_LOG2N == 9 || OCT_LOG2N == 11
+#if (OCT_LOG2N == 8 || OCT_LOG2N == 9 || OCT_LOG2N == 11) && OCT_FUSED_RS == 0
 #define OCT_HAVE_REAL2N 1
 #include "real2n_kernel.h"
 #else
@@ -60,76 +60,66 @@ hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, 
 #define OCT_CAT2(a, b) a##b
 #define OCT_CAT(a, b) OCT_CAT2(a, b)
 
-// intype: IN_U16 or IN_F32; rs: RS_*; roll: in-kernel rolling average (IN_U16 only)
-hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,
-                                             int requestedBlocks, hipStream_t stream, int* blocksUsed) {
+// ONE resampling mode per object (-DOCT_FUSED_RS=0..3; round 5): the four modes of a length compile in parallel, and -- the reason --
+// they want different instruction scheduling.  Same box, interleaved, N = 1024 (profiles/r5n_*, r5o_*): the cubic variants run 5-7 % FASTER
+// under the machine scheduler's "max-ilp" strategy than under "max-memory-clause" (the round-2 choice for the whole file; same
+// instruction counts, same registers, a different order), linear 2.5 % SLOWER, no resampling 0.5 % slower, Lanczos 32 % slower.  The
+// Makefile gives every (length, mode) object its own strategy.
+#ifndef OCT_FUSED_RS
+#error "compile with -DOCT_FUSED_RS=<0..3> (RS_NONE, RS_LINEAR, RS_CUBIC, RS_LANCZOS)"
+#endif
+
+namespace {
+// intype: the sample container the kernel reads (IN_*); roll: in-kernel rolling average (IN_U16 only)
+template <int RS>
+hipError_t launch_rs(int intype, bool roll, bool spectrum, bool logScale, const FusedArgs& a, int requestedBlocks, hipStream_t stream, int* blocksUsed) {
 	if (intype == IN_U16) {
-		if (rs == RS_LANCZOS) {  // raw rows + 8 samples of the neighbour rows on both sides; not with the in-kernel rolling average
+		if constexpr (RS == RS_LANCZOS) {  // raw rows + 8 samples of the neighbour rows on both sides; not with the in-kernel rolling average
 			if (roll) return hipErrorInvalidValue;
 			return launch_out<IN_U16, RS_LANCZOS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		}
-		if (roll) {
-			if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
-			switch (rs) {
-			case RS_NONE: return launch_out<IN_U16, RS_NONE, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-			case RS_LINEAR: return launch_out<IN_U16, RS_LINEAR, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-			default: return launch_out<IN_U16, RS_CUBIC, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		} else {
+			if (roll) {
+				if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
+				return launch_out<IN_U16, RS, MODE_ROLL>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 			}
-		}
-		switch (rs) {
-		case RS_NONE: return launch_out<IN_U16, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		case RS_LINEAR: return launch_out<IN_U16, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		default: return launch_out<IN_U16, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+			return launch_out<IN_U16, RS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 		}
 	}
 	if (roll) return hipErrorInvalidValue;
+	if (intype == IN_F32) return launch_out<IN_F32, RS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	if constexpr (RS != RS_LANCZOS) {
 #if OCT_LOG2N >= 9
-	// packed 12-bit rows read straight from the raw buffer (1.5 B per sample); N = 256 holds half a chunk per lane: prepared route
-	if (intype == IN_P12U || intype == IN_P12S) {
-		if (rs == RS_LANCZOS) return hipErrorInvalidValue;
-		const bool sgn = intype == IN_P12S;
-		switch (rs) {
-		case RS_NONE: return sgn ? launch_out<IN_P12S, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed)
-		                         : launch_out<IN_P12U, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		case RS_LINEAR: return sgn ? launch_out<IN_P12S, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed)
-		                           : launch_out<IN_P12U, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		default: return sgn ? launch_out<IN_P12S, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed)
-		                    : launch_out<IN_P12U, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		}
+		// packed 12-bit rows read straight from the raw buffer (1.5 B per sample); N = 256 holds half a chunk per lane: prepared route
+		if (intype == IN_P12U) return launch_out<IN_P12U, RS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		if (intype == IN_P12S) return launch_out<IN_P12S, RS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+		// 8-bit containers (bitDepth <= 8, cu:109-118) straight from the raw buffer
+		if (intype == IN_U8) return launch_out<IN_U8, RS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+#endif
+		// two's complement 16 bit
+		if (intype == IN_I16) return launch_out<IN_I16, RS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
 	}
-#endif
-	// 8-bit containers (bitDepth <= 8, cu:109-118) and two's complement 16 bit straight from the raw buffer
-	if (intype == IN_U8 || intype == IN_I16) {
-		if (rs == RS_LANCZOS) return hipErrorInvalidValue;
-#if OCT_LOG2N >= 9
-		const bool u8 = intype == IN_U8;
-#else
-		if (intype == IN_U8) return hipErrorInvalidValue;  // N = 256: half a chunk per lane -> prepared route
-#endif
-		switch (rs) {
-		case RS_NONE:
-#if OCT_LOG2N >= 9
-			if (u8) return launch_out<IN_U8, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-#endif
-			return launch_out<IN_I16, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		case RS_LINEAR:
-#if OCT_LOG2N >= 9
-			if (u8) return launch_out<IN_U8, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-#endif
-			return launch_out<IN_I16, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		default:
-#if OCT_LOG2N >= 9
-			if (u8) return launch_out<IN_U8, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-#endif
-			return launch_out<IN_I16, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-		}
-	}
-	if (intype != IN_F32) return hipErrorInvalidValue;
+	return hipErrorInvalidValue;
+}
+}  // namespace
+
+#define OCT_FUSED_RS_NAME(L, R) OCT_CAT(OCT_CAT(launch_fused_, L), OCT_CAT(_rs, R))
+#define OCT_DECL_RS(R) hipError_t OCT_FUSED_RS_NAME(OCT_LOG2N, R)(int intype, bool roll, bool spectrum, bool logScale, const FusedArgs& a, int requestedBlocks, hipStream_t stream, int* blocksUsed);
+OCT_DECL_RS(0) OCT_DECL_RS(1) OCT_DECL_RS(2) OCT_DECL_RS(3)
+
+hipError_t OCT_FUSED_RS_NAME(OCT_LOG2N, OCT_FUSED_RS)(int intype, bool roll, bool spectrum, bool logScale, const FusedArgs& a, int requestedBlocks, hipStream_t stream, int* blocksUsed) {
+	return launch_rs<OCT_FUSED_RS>(intype, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+}
+
+#if OCT_FUSED_RS == 0
+// the dispatcher over the four objects of the length, the real-input kernels of the length and its twiddle plan live in the RS_NONE object
+hipError_t OCT_CAT(launch_fused_, OCT_LOG2N)(int intype, int rs, bool roll, bool spectrum, bool logScale, const FusedArgs& a,
+                                             int requestedBlocks, hipStream_t stream, int* blocksUsed) {
 	switch (rs) {
-	case RS_NONE: return launch_out<IN_F32, RS_NONE, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-	case RS_LINEAR: return launch_out<IN_F32, RS_LINEAR, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-	case RS_CUBIC: return launch_out<IN_F32, RS_CUBIC, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
-	default: return launch_out<IN_F32, RS_LANCZOS, 0>(spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	case RS_NONE: return OCT_FUSED_RS_NAME(OCT_LOG2N, 0)(intype, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	case RS_LINEAR: return OCT_FUSED_RS_NAME(OCT_LOG2N, 1)(intype, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	case RS_CUBIC: return OCT_FUSED_RS_NAME(OCT_LOG2N, 2)(intype, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	case RS_LANCZOS: return OCT_FUSED_RS_NAME(OCT_LOG2N, 3)(intype, roll, spectrum, logScale, a, requestedBlocks, stream, blocksUsed);
+	default: return hipErrorInvalidValue;
 	}
 }
 
@@ -180,5 +170,7 @@ int OCT_CAT(fused_twiddle_plan_, OCT_LOG2N)(int* radices) {
 	radices[0] = Plan<kLog2N>::R0; radices[1] = Plan<kLog2N>::R1; radices[2] = Plan<kLog2N>::R2; radices[3] = Plan<kLog2N>::R3;
 	return twiddle_count<kLog2N>();
 }
+
+#endif  // OCT_FUSED_RS == 0
 
 }  // namespace oct

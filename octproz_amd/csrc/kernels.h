@@ -731,21 +731,25 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 
 	const unsigned wavesTotal = gridDim.x * (unsigned)WAVES;
 	// A-scans of a wave.  Default: wave w takes w, w + wavesTotal, ... (at any moment the waves of the chip work on one contiguous
-	// window of the buffer).  MODE_DISP: a contiguous BLOCK of A-scans per wave, so that the en-face values a wave collects belong to
-	// consecutive A-scans and leave as one coalesced 256-byte store -- strided, the same values are 64 separate 4-byte writes into
-	// 64 different cache lines per wave, 131 072 partial-line writes at the tail of a 1024 x 512 x 256 launch: +4 us
-	// (profiles/r5d_fold_parts_ab.txt)
-#ifndef OCT_DISP_BLOCKED
-#define OCT_DISP_BLOCKED 0  // measured: the blocked mapping itself costs what the coalesced store saves (2 048 separate streams instead of one window: 0.1792 vs 0.1780 ms, profiles/r5e_fold_blocked_ab.txt)
+	// window of the buffer).  MODE_DISP: BLK consecutive A-scans per wave, the BLOCKS strided over the waves of the chip, so that the
+	// en-face values of a block leave as ONE store of BLK consecutive dwords (BLK = 16: a whole, aligned 64-byte sector).  Strided,
+	// the same values are single-dword writes into different cache lines -- 131 072 partial-line writes per 1024 x 512 x 256
+	// launch, +4 us whenever they are issued (profiles/r5d_fold_parts_ab.txt, r5f_*); ONE block per wave (BLK = A-scans per wave)
+	// turns the chip's single window over the buffer into 2 048 separate streams and costs as much (r5e_fold_blocked_ab.txt).
+#ifndef OCT_DISP_BLOCK
+#define OCT_DISP_BLOCK 16
 #endif
-#ifndef OCT_DISP_FLUSH
-#define OCT_DISP_FLUSH 16   // en-face values collected per store: with 64 all partial-line writes of a launch fall into its last microseconds
-#endif
-	constexpr bool BLOCKED = (MODE & MODE_DISP) != 0 && OCT_DISP_BLOCKED != 0;
-	const unsigned perWave = BLOCKED ? (a.numLines + wavesTotal - 1u) / wavesTotal : 0u;
-	const unsigned lineStep = BLOCKED ? 1u : wavesTotal;
-	unsigned line = (blockIdx.x * (unsigned)WAVES + (unsigned)wave) * (BLOCKED ? perWave : 1u);
-	const unsigned lineEnd = BLOCKED ? (line + perWave < a.numLines ? line + perWave : a.numLines) : a.numLines;
+	constexpr unsigned BLK = (MODE & MODE_DISP) != 0 ? (unsigned)OCT_DISP_BLOCK : 1u;
+	static_assert(BLK >= 1 && BLK <= 64, "a block's en-face values live in the lanes of one register");
+	const unsigned blockStride = wavesTotal * BLK;
+	unsigned line = (blockIdx.x * (unsigned)WAVES + (unsigned)wave) * BLK;
+	unsigned inBlock = 0;  // position of `line` inside its block
+	// the A-scan this wave processes after `ln` (>= numLines: none)
+	auto next_line = [&](unsigned ln, unsigned pos) -> unsigned {
+		if (BLK > 1u && pos + 1u < BLK) return ln + 1u;   // (beyond the buffer only in the buffer's last block: nothing follows it)
+		return ln - pos + blockStride;
+	};
+	const unsigned lineEnd = a.numLines;
 	const __amdgpu_buffer_rsrc_t lutR = make_rsrc(a.lut, N * 16u);
 	const __amdgpu_buffer_rsrc_t lanczosR = make_rsrc(a.lanczosW, N * 64u);
 	const unsigned rowBytes = (unsigned)(N / SPL) * CB;
@@ -833,7 +837,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	const unsigned efIdx = DISP ? __builtin_amdgcn_readfirstlane(a.dispEnFaceBin >> 6) : 0u, efLane = DISP ? __builtin_amdgcn_readfirstlane(a.dispEnFaceBin & 63u) : 0u;
 	float efAcc = 0.0f;
 	unsigned efCount = 0, efFirst = line;  // A-scans collected in efAcc, and the first of them
-	for (; line < lineEnd; line += lineStep) {
+	for (; line < lineEnd; line = next_line(line, inBlock), inBlock = (inBlock + 1u == BLK) ? 0u : inBlock + 1u) {
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
 			bool staged = false;
@@ -927,7 +931,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 						*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);
 				}
 			}
-			const unsigned next = line + lineStep;  // prefetch the next row of this wave
+			const unsigned next = next_line(line, inBlock);  // prefetch the next row of this wave
 			if (next < lineEnd) {
 				const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
 #pragma unroll
@@ -1136,10 +1140,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				// (readfirstlane: where the loop's exit is not provably wave-uniform the counter lives in a VGPR and an "s" operand would get it as such)
 				asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(efAcc) : "s"(picked), "s"(__builtin_amdgcn_readfirstlane(efCount)) : "m0");
 				efCount++;
-				if (efCount == (unsigned)OCT_DISP_FLUSH) {
-					if (a.dispEnFace) ef_flush<true>(a, efAcc, efFirst, lineStep, lane, (unsigned)OCT_DISP_FLUSH);
+				if (efCount == BLK) {  // (BLK consecutive A-scans: one coalesced store)
+					if (a.dispEnFace) ef_flush<true>(a, efAcc, efFirst, 1u, lane, BLK);
 					efCount = 0;
-					efFirst = line + lineStep;
+					efFirst = next_line(line, inBlock);
 				}
 			}
 		}
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		wave_sync_lds();
 	}
 	if constexpr (DISP) {
-		if (a.dispEnFace && efCount) ef_flush<true>(a, efAcc, efFirst, lineStep, lane, efCount);
+		if (a.dispEnFace && efCount) ef_flush<true>(a, efAcc, efFirst, 1u, lane, efCount);  // (the ragged last block of the buffer)
 	}
 }
 

@@ -7,7 +7,7 @@ import collections, os, re, subprocess, sys, tempfile
 
 def census(d, log2n="10", kern="oct_fused_kernelILi10ELi1ELi2ELi4EE", src="fused_inst.hip"):
     out = tempfile.mktemp(suffix=".s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DOCT_LOG2N=" + log2n, "-S",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DOCT_LOG2N=" + log2n, "-DOCT_FUSED_RS=" + os.environ.get("OCT_FUSED_RS", "2"), "-Wno-inline-asm", "-S",
                            "--cuda-device-only", "-Wno-pass-failed", "-Wno-unused-value", "-o", out, src], cwd=d, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     os.unlink(out)
