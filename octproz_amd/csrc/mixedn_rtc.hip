@@ -293,7 +293,16 @@ CodePtr get_code(const mxs::PlanDesc& d, int intype, int rs, int mode, const std
 	if (compileHere) {
 		std::shared_ptr<Code> code = std::make_shared<Code>();
 		bool fromDisk = false;
-		code->ok = compileCode(d, intype, rs, mode, arch.c_str(), extra, diskDir, code->bytes, &code->waves, &code->seconds, &code->why, &fromDisk);
+		// (an exception out of here would leave the promise unset and every waiter with std::future_error: it becomes a failed compilation)
+		try {
+			code->ok = compileCode(d, intype, rs, mode, arch.c_str(), extra, diskDir, code->bytes, &code->waves, &code->seconds, &code->why, &fromDisk);
+		} catch (const std::exception& ex) {
+			code->ok = false;
+			code->why = std::string("compiling the kernel threw: ") + ex.what();
+		} catch (...) {
+			code->ok = false;
+			code->why = "compiling the kernel threw";
+		}
 		{
 			std::lock_guard<std::mutex> lock(c.mtx);
 			if (code->ok) { if (fromDisk) c.diskHits++; else { c.compiled++; c.compileSeconds += code->seconds; } }
