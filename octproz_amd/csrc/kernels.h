@@ -742,7 +742,14 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	constexpr unsigned BLK = (MODE & MODE_DISP) != 0 ? (unsigned)OCT_DISP_BLOCK : 1u;
 	static_assert(BLK >= 1 && BLK <= 64, "a block's en-face values live in the lanes of one register");
 	const unsigned blockStride = wavesTotal * BLK;
-	unsigned line = (blockIdx.x * (unsigned)WAVES + (unsigned)wave) * BLK;
+	// OCT_XCD_REMAP = 1 (experiment): workgroups are dealt round-robin to the 8 XCDs, so with the plain mapping 8 consecutive A-scans
+	// belong to one XCD and the next 8 to the next one; remapped, every XCD works on ONE contiguous eighth of the chip's window
+#ifndef OCT_XCD_REMAP
+#define OCT_XCD_REMAP 0
+#endif
+	unsigned blk = blockIdx.x;
+	if (OCT_XCD_REMAP != 0 && (gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+	unsigned line = (blk * (unsigned)WAVES + (unsigned)wave) * BLK;
 	unsigned inBlock = 0;  // position of `line` inside its block
 	// the A-scan this wave processes after `ln` (>= numLines: none)
 	auto next_line = [&](unsigned ln, unsigned pos) -> unsigned {

@@ -111,6 +111,10 @@ CANCEL_FRAC = 2e-2          # bins excused from the dB comparison by the cancell
                             # max(CANCEL_MIN_BINS, CANCEL_FRAC_PER_LINE of the line's bins) of a line's bins.  (As a fraction of the buffer alone the
                             # bound presumed hundreds of bins per line: ONE cancelled depth bin is 4 % of a buffer with 24 bins per
                             # line, which is why N = 48 had left the draws in round 4; it is back.)
+                            # Second 1500-seed run of round 5 (profiles/r5s_fuzz_1500.txt): two draws with the flat-top window and a kept DC
+                            # term had bins 0-3 cancelled on a line -- the DC term's main lobe, 4 bins at N = 48 and at N = 130 alike.  Those
+                            # bins are recognised from the mean line itself (compare_images: "lobe") and not counted; the bound is for the bins
+                            # behind them.
 CANCEL_MIN_BINS = 2
 CANCEL_FRAC_PER_LINE = 4e-2  # (a single line may hold twice the buffer-wide share: 7 of 256 bins = 2.7 % measured, seed 4 of test_settings_changed_between_buffers)
 # Bins under the dB floor are counted and reported, not bounded: on the synthetic fringes with the v1.8.0 settings the noise floor
@@ -118,7 +122,7 @@ CANCEL_FRAC_PER_LINE = 4e-2  # (a single line may hold twice the buffer-wide sha
 # keep the DC term (no fixed-pattern-noise removal, or its exact cancellation without dispersion compensation) 75-97 % of the
 # bins lie more than 60 dB under it (measured, profiles/r4k_tolerance_ledger.txt).  Those bins are not unchecked: the amplitude
 # bound holds every one of them -- it is the same statement as a dB bound that widens with 1 / amplitude.
-LEDGER = {"calls": 0, "strict_calls": 0, "bins": 0, "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "db_checked": 0,
+LEDGER = {"calls": 0, "strict_calls": 0, "bins": 0, "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "cancelled_in_dc_lobe": 0, "db_checked": 0,
           "max_rel": 0.0, "max_amp": 0.0, "max_amp_over_allowed": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0, "worst_fraction": {"one_sided_inf": (0.0, ""), "below_db_floor": (0.0, ""), "cancelled": (0.0, "")}}
 LAST_STATS = {}
 
@@ -126,7 +130,7 @@ LAST_STATS = {}
 def _ledger(stats, what):
     LEDGER["calls"] += 1
     LEDGER["strict_calls"] += 1 if stats["strict"] else 0
-    for k in ("bins", "one_sided_inf", "below_db_floor", "cancelled", "db_checked"):
+    for k in ("bins", "one_sided_inf", "below_db_floor", "cancelled", "cancelled_in_dc_lobe", "db_checked"):
         LEDGER[k] += stats[k]
     for k in ("max_rel", "max_amp", "max_amp_over_allowed", "max_db", "max_one_sided_residue"):
         LEDGER[k] = max(LEDGER[k], stats[k])
@@ -167,7 +171,7 @@ def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_f
     w = want.reshape(-1, half)
     assert g.shape == w.shape
     frac = 0.0 if strict else (EXEMPT_FRAC if exempt_frac is None else exempt_frac)
-    stats = {"strict": bool(strict), "bins": int(g.size), "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "db_checked": 0,
+    stats = {"strict": bool(strict), "bins": int(g.size), "one_sided_inf": 0, "below_db_floor": 0, "cancelled": 0, "cancelled_in_dc_lobe": 0, "db_checked": 0,
              "max_rel": 0.0, "max_amp": 0.0, "max_amp_over_allowed": 0.0, "max_db": 0.0, "max_one_sided_residue": 0.0}
     LAST_STATS.clear(); LAST_STATS.update(stats)
     bad_g = np.isnan(g) | np.isposinf(g)
@@ -221,9 +225,17 @@ def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_f
             m2 = np.abs(np.asarray(mean_line).astype(np.complex128)[:half]) ** 2
             kept = strong & (pw >= CANCEL_FLOOR * m2[None, :])
             stats["cancelled"] = int((strong & ~kept).sum())
-            per_line = (strong & ~kept).sum(axis=1)
+            # The DC term's lobe under the window: the leading run of bins (from bin 0) where the mean line stands so far above the
+            # line's own maximum that ANY bin over the dB floor there is a cancelled one (pw > DB_FLOOR x line max and
+            # pw < CANCEL_FLOOR x |mean|^2 need |mean|^2 > DB_FLOOR / CANCEL_FLOOR x line max).  Its width is a property of the draw's
+            # window and fill factor (flat top at fill 0.9: bins 0-3 whatever the line length), not of the implementation under test --
+            # the whole set is computed from the oracle's image and the pinned mean line -- so it is not counted; what IS counted per
+            # line are the cancelled bins behind it (depth bins of structure common to all lines).
+            lobe = np.cumprod(m2[None, :] > (floor / CANCEL_FLOOR) * line_max, axis=1).astype(bool)
+            stats["cancelled_in_dc_lobe"] = int((strong & ~kept & lobe).sum())
+            per_line = (strong & ~kept & ~lobe).sum(axis=1)
             per_line_allowed = max(CANCEL_MIN_BINS, int(np.ceil(CANCEL_FRAC_PER_LINE * half)))
-            assert int(per_line.max()) <= per_line_allowed, "%s: %d of a line's %d bins left out of the dB comparison by the 'cancelled' rule (allowed per line: %d)" % (
+            assert int(per_line.max()) <= per_line_allowed, "%s: %d of a line's %d bins behind the DC lobe left out of the dB comparison by the 'cancelled' rule (allowed per line: %d)" % (
                 what, int(per_line.max()), half, per_line_allowed)
             strong = kept
         stats["db_checked"] = int(strong.sum())

@@ -80,4 +80,5 @@ def pytest_terminal_summary(terminalreporter):
         f, where = L["worst_fraction"][rule]
         tr.write_line("  exempt by '%s': %d bins = %.2e of all; worst single call %.2e of its bins (%s)" % (
             rule, L[rule], L[rule] / max(1, L["bins"]), f, where or "-"))
+    tr.write_line("  of the 'cancelled' bins, in the DC term's lobe (recognised from the mean line, not counted against the per-line bound): %d" % L.get("cancelled_in_dc_lobe", 0))
     tr.write_line("  largest power (rel. to the line maximum) opposite a one-sided -inf: %.2e (the amplitude bound squared: %.1e at N = 1024)" % (L["max_one_sided_residue"], common.amp_rtol(1024) ** 2))

@@ -113,6 +113,8 @@ def test_random_setting_combination_matches_oracle(seed):
 # no dedicated kernel: compiled at run time (mixedn_static.h), or the run-time plan.  N = 48 -- 24 bins per line -- is drawn again
 # (round 5): the 'cancelled' rule is stated per line now (common.CANCEL_MIN_BINS), so one depth bin that the mean-line subtraction
 # cancels on most lines no longer breaks a bound that presumed hundreds of bins per line (seed 426 of profiles/r4ap_fuzz_1500.txt).
+# (profiles/r5s_fuzz_1500.txt: with N = 48 and N = 130 two draws had the four bins of the DC term's flat-top lobe cancelled on a line;
+# the rule recognises that lobe from the mean line and bounds the bins behind it -- common.compare_images.)
 RTC_LENGTHS = [1000, 1200, 1536, 2000, 130, 182, 48, 2500]
 
 

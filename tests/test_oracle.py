@@ -228,3 +228,31 @@ def test_min_variance_checker_accepts_the_oracle_and_catches_a_wrong_bin():
     with pytest.raises(AssertionError):
         common.check_min_variance_mean(bad, spec, N, "perturbed")
     o.close()
+
+
+def test_cancelled_rule_counts_the_bins_behind_the_dc_lobe_only():
+    """compare_images(cancel=True): the bins the mean-line subtraction cancels are taken out of the dB comparison and their number per
+    line is bounded -- except inside the DC term's lobe, which is recognised from the mean line (leading run of bins where
+    |mean|^2 > DB_FLOOR / CANCEL_FLOOR x the line's maximum) and whose width belongs to the draw's window, not to the
+    implementation.  Synthetic image: 24 bins per line (N = 48), a mean line with a four-bin DC lobe and one strong depth bin."""
+    p = v180_benchmark_params(48, 8, 1)
+    p.signalLogScaling, p.fixedPatternNoiseRemoval = 1, 1
+    half, lines = 24, 8
+    power = np.full((lines, half), 1.0e-5)      # ten times the dB floor of a line whose maximum is 1
+    power[:, 12] = 1.0                          # the line maximum
+    mean = np.zeros(half, np.complex128)
+    mean[:4] = [400.0, 380.0, 300.0, 60.0]      # |mean|^2 = 3.6e3 ... 1.6e5 x the line maximum: everything over the dB floor there is "cancelled"
+    q = p
+    rng = float(q.signalGrayscaleMax) - float(q.signalGrayscaleMin)   # the grey-scale map of cu:718, inverted by common.image_to_power
+    want = (((10.0 * np.log10(power / half) - float(q.signalGrayscaleMin)) / rng + float(q.signalAddend)) * float(q.signalMultiplicator)).astype(np.float32)
+    assert np.allclose(common.image_to_power(want, q), power, rtol=1e-3)
+    common.compare_images(want.copy(), want, q, "dc lobe only", mean_line=mean, cancel=True)
+    assert common.LAST_STATS["cancelled"] == 4 * lines and common.LAST_STATS["cancelled_in_dc_lobe"] == 4 * lines
+    # three more cancelled depth bins behind the lobe: over the per-line bound of max(2, 4 % of 24) = 2
+    mean2 = mean.copy()
+    mean2[[8, 16, 20]] = 500.0
+    with pytest.raises(AssertionError, match="behind the DC lobe"):
+        common.compare_images(want.copy(), want, q, "three behind the lobe", mean_line=mean2, cancel=True)
+    mean2[20] = 0.0                             # two: allowed
+    common.compare_images(want.copy(), want, q, "two behind the lobe", mean_line=mean2, cancel=True)
+    assert common.LAST_STATS["cancelled"] == 6 * lines and common.LAST_STATS["cancelled_in_dc_lobe"] == 4 * lines
