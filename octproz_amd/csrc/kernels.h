@@ -114,6 +114,13 @@ struct FusedArgs {
 #ifndef OCT_REGTAB11
 #define OCT_REGTAB11 0
 #endif
+#ifndef OCT_MIRROR_AT_STAGING
+#define OCT_MIRROR_AT_STAGING 1
+#endif
+// OCT_GATHER_GROUP / OCT_GATHER_AHEAD (experiments: override the per-length choice below): see the gather of oct_fused_kernel (cubic with tap weights)
+// per length: samples whose tap reads are issued together, and whether the next group's reads go out before the current group's sums
+template <int LOG2N> struct GatherCfg { static constexpr int GROUP = 1; static constexpr bool AHEAD = false; };
+template <> struct GatherCfg<10> { static constexpr int GROUP = 4; static constexpr bool AHEAD = true; };  // +5 % (profiles/r5y_*, r5z_*)
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
@@ -844,6 +851,15 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	const unsigned efIdx = DISP ? __builtin_amdgcn_readfirstlane(a.dispEnFaceBin >> 6) : 0u, efLane = DISP ? __builtin_amdgcn_readfirstlane(a.dispEnFaceBin & 63u) : 0u;
 	float efAcc = 0.0f;
 	unsigned efCount = 0, efFirst = line;  // A-scans collected in efAcc, and the first of them
+	// Everything the prologue loaded from global memory into registers (tap weights, window x phasor, tap addresses, mean-line bins) has
+	// arrived before the loop is entered.  Without this wait hipcc guards the FIRST use of every such register inside the loop -- the
+	// gather -- with s_waitcnt vmcnt(15) ... vmcnt(0), one per sample, and those waits run in every iteration: vmcnt(3) ... vmcnt(0)
+	// then wait for the next row's prefetch, issued a few instructions earlier, i.e. for a full HBM round trip in the middle of every
+	// A-scan (tools/isa_sequence.py; round 5).  One wait per persistent wave here instead.
+#ifndef OCT_PROLOGUE_WAIT
+#define OCT_PROLOGUE_WAIT 1
+#endif
+	if constexpr (OCT_PROLOGUE_WAIT != 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (expcnt / lgkmcnt untouched)
 	for (; line < lineEnd; line = next_line(line, inBlock), inBlock = (inBlock + 1u == BLK) ? 0u : inBlock + 1u) {
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
@@ -927,6 +943,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 							o[c] = (float)xs[c] - q;
 						}
 						*reinterpret_cast<float4*>(&row[ROW_OFF + 4 * lane + 256 * i]) = float4{o[0], o[1], o[2], o[3]};
+						if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING != 0) { if (i == 0 && lane == 0) row[ROW_OFF - 1] = o[1]; }  // mirror tap, see below
 					}
 				}
 			}
@@ -934,8 +951,13 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 #pragma unroll
 				for (int i = 0; i < NL; i++) {
 #pragma unroll
-					for (int h = 0; h < SPL / 4; h++)
-						*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);
+					for (int h = 0; h < SPL / 4; h++) {
+						const float4 f = chunk_to_float<INTYPE>(pre[i], h, shift);
+						*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = f;
+						// n0 = |n1 - 1| mirror tap (cu:284): sample 1 of the row is in lane 0's first unit -- written from the register it is
+						// converted into instead of read back from LDS behind the staging (one dependent LDS round trip per A-scan less)
+						if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING != 0) { if (i == 0 && h == 0 && lane == 0) row[ROW_OFF - 1] = f.y; }
+					}
 				}
 			}
 			const unsigned next = next_line(line, inBlock);  // prefetch the next row of this wave
@@ -985,7 +1007,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 		wave_sync_lds();
 
-		if constexpr (RS == RS_CUBIC) {
+		if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING == 0) {
 			if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)
 			wave_sync_lds();
 		}
@@ -1010,6 +1032,55 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 #pragma unroll
 				for (int c = 0; c < 4; c++) lzw[q][c] = buf_load128(lanczosR, lane * 64, q * 4096 + c * 16);
 		}
+		// Grouped gather (cubic with tap weights): the tap reads of OCT_GATHER_GROUP samples are issued together, and with OCT_GATHER_AHEAD
+		// the reads of the next group before the sums of the current one.  Sample by sample (group 1, what hipcc makes of the plain loop at a
+		// register budget this tight: two reads, wait, two FMAs, wait, two FMAs) a wave pays one LDS round trip per sample, 16 in a row.
+#ifdef OCT_GATHER_GROUP
+		constexpr int GGW = OCT_GATHER_GROUP;
+		constexpr bool AHEAD = (OCT_GATHER_AHEAD) != 0;
+#else
+		constexpr int GGW = GatherCfg<LOG2N>::GROUP;
+		constexpr bool AHEAD = GatherCfg<LOG2N>::AHEAD;
+#endif
+		constexpr int GG = (CW && GGW > 1 && P % GGW == 0 && (REGTAB || GGW % 2 == 0)) ? GGW : 1;
+		if constexpr (GG > 1) {
+			constexpr int NG = P / GG;
+			float tp[AHEAD ? 2 : 1][GG][4];
+			f32x4 cwG[AHEAD ? 2 : 1][REGTAB ? 1 : GG];
+			f32x4 wpG[AHEAD ? 2 : 1][REGTAB ? 1 : (GG + 1) / 2];
+			auto loadg = [&](int g, int b) {
+#pragma unroll
+				for (int i = 0; i < GG; i++) {
+					const int q = g * GG + i;
+					lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
+#pragma unroll
+					for (int k = 0; k < 4; k++) tp[b][i][k] = t[k];
+					if constexpr (!REGTAB) {
+						cwG[b][i] = cwL[lane + 64 * q];
+						if ((q & 1) == 0) wpG[b][i >> 1] = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];
+					}
+				}
+			};
+			loadg(0, 0);
+#pragma unroll
+			for (int g = 0; g < NG; g++) {
+				const int b = AHEAD ? (g & 1) : 0;
+				if constexpr (AHEAD) { if (g + 1 < NG) loadg(g + 1, (g + 1) & 1); }
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int i = 0; i < GG; i++) {
+					const int q = g * GG + i;
+					f32x4 cw;
+					f2 wph;
+					if constexpr (REGTAB) { cw = cwR[q]; wph = wphR[q]; }
+					else { cw = cwG[b][i]; const f32x4 w2 = wpG[b][i >> 1]; wph = (q & 1) ? f2{w2.z, w2.w} : f2{w2.x, w2.y}; }
+					const float y = __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));
+					v[q] = wph * y;
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				if constexpr (!AHEAD) { if (g + 1 < NG) loadg(g + 1, 0); }
+			}
+		} else
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			// {rho, window, phasor.x, phasor.y} of sample j = lane + 64q
