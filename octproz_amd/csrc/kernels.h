@@ -121,6 +121,9 @@ struct FusedArgs {
 // per length: samples whose tap reads are issued together, and whether the next group's reads go out before the current group's sums
 template <int LOG2N> struct GatherCfg { static constexpr int GROUP = 1; static constexpr bool AHEAD = false; };
 template <> struct GatherCfg<10> { static constexpr int GROUP = 4; static constexpr bool AHEAD = true; };  // +5 % (profiles/r5y_*, r5z_*)
+template <> struct GatherCfg<11> { static constexpr int GROUP = 4; static constexpr bool AHEAD = false; };  // +2 % (profiles/r5aa_*): tables from LDS too, 10 registers per sample in flight
+template <> struct GatherCfg<9> { static constexpr int GROUP = 4; static constexpr bool AHEAD = true; };
+template <> struct GatherCfg<8> { static constexpr int GROUP = 4; static constexpr bool AHEAD = false; };
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
@@ -379,6 +382,17 @@ constexpr int pad16c(int j) { return j + OCT_PADK * (j >> 4); }
 //   PACK == 2 (R = 16, NS = 16, one butterfly per lane): unit [c][k] = {w(2c, k), w(2c+1, k)}, c < 8, k = lane & 15
 //   PACK == 3 (R = 4, NS = 256, four butterflies per lane): unit [c][lane] = entries 2c, 2c+1 of the lane's
 //             12 twiddles, entry m*3 + t-1 = w(t, lane + 64 m)
+#ifndef OCT_TW_LDS_GROUP
+#define OCT_TW_LDS_GROUP 1
+#endif
+// twiddle reads of the generic passes in groups (fft_pass): per transform length
+#ifndef OCT_TW_GROUP
+#define OCT_TW_GROUP 0
+#endif
+#ifndef OCT_TW_AHEAD
+#define OCT_TW_AHEAD 0
+#endif
+template <int N> struct TwGroupCfg { static constexpr int GROUP = (N == 2048) ? (OCT_TW_GROUP) : 0; static constexpr bool AHEAD = (OCT_TW_AHEAD) != 0; };
 template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0, bool REGTW = false, bool REGTW3 = false>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const f32x4* twr = nullptr) {
 	constexpr int P = N / 64, NB = P / R;
@@ -392,21 +406,76 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 	if constexpr (PACK == 2) {
 		static_assert(PACK != 2 || (R == 16 && NS == 16 && NB == 1), "packed layout 2");
 		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + (lane & 15);
+		// (twiddles from LDS -- the variants without room for them in registers: four reads go out together; one by one, as hipcc
+		// orders them at this register budget, every read is a dependent LDS round trip in the middle of the transform)
+		f32x4 wl[REGTW ? 1 : 8];
+		if constexpr (!REGTW && OCT_TW_LDS_GROUP != 0) {
+#pragma unroll
+			for (int c = 0; c < 4; c++) wl[c] = tp[c * 16];
+			__builtin_amdgcn_sched_barrier(0);
+		}
 #pragma unroll
 		for (int c = 0; c < 8; c++) {
-			const f32x4 w = REGTW ? twr[c] : tp[c * 16];
+			if constexpr (!REGTW && OCT_TW_LDS_GROUP != 0) {
+				if (c == 2) {
+#pragma unroll
+					for (int d = 4; d < 8; d++) wl[d] = tp[d * 16];
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			const f32x4 w = REGTW ? twr[c] : (OCT_TW_LDS_GROUP != 0 ? wl[c] : tp[c * 16]);
 			if (c > 0) v[2 * c] = octfft::cmul(v[2 * c], f2{w.x, w.y});
 			v[2 * c + 1] = octfft::cmul(v[2 * c + 1], f2{w.z, w.w});
 		}
 	} else if constexpr (PACK == 3) {
 		static_assert(PACK != 3 || (R == 4 && NS == 256 && NB == 4), "packed layout 3");
 		const f32x4* tp = reinterpret_cast<const f32x4*>(twp) + lane;
+		f32x4 wl3[REGTW3 ? 1 : 6];
+		if constexpr (!REGTW3 && OCT_TW_LDS_GROUP != 0) {
+#pragma unroll
+			for (int c = 0; c < 6; c++) wl3[c] = tp[c * 64];
+			__builtin_amdgcn_sched_barrier(0);
+		}
 #pragma unroll
 		for (int c = 0; c < 6; c++) {
-			const f32x4 w = REGTW3 ? twr[8 + c] : tp[c * 64];
+			const f32x4 w = REGTW3 ? twr[8 + c] : (OCT_TW_LDS_GROUP != 0 ? wl3[c] : tp[c * 64]);
 			const int i0 = 2 * c, i1 = 2 * c + 1;
 			v[i0 / 3 + (i0 % 3 + 1) * NB] = octfft::cmul(v[i0 / 3 + (i0 % 3 + 1) * NB], f2{w.x, w.y});
 			v[i1 / 3 + (i1 % 3 + 1) * NB] = octfft::cmul(v[i1 / 3 + (i1 % 3 + 1) * NB], f2{w.z, w.w});
+		}
+	} else if constexpr (NS > 1 && TwGroupCfg<N>::GROUP > 1) {
+		// the NB (R - 1) twiddles of the lane in groups: the reads of a group go out together (with AHEAD the next group's before the
+		// products of the current one) instead of one read, one wait, one product -- a dependent LDS round trip per twiddle, 30 + 24
+		// per A-scan at N = 2048 (tools/isa_sequence.py)
+		constexpr int TG = TwGroupCfg<N>::GROUP, TOT = NB * (R - 1), NG = (TOT + TG - 1) / TG;
+		constexpr bool AHEAD = TwGroupCfg<N>::AHEAD;
+		f2 w[AHEAD ? 2 : 1][TG];
+		auto loadg = [&](int g, int bsel) {
+#pragma unroll
+			for (int i = 0; i < TG; i++) {
+				const int idx = g * TG + i;
+				if (idx < TOT) {
+					const int m = idx / (R - 1), t = idx % (R - 1) + 1;
+					w[bsel][i] = twp[((lane + 64 * m) & (NS - 1)) + (t - 1) * NS];  // table layout [t-1][k]
+				}
+			}
+		};
+		loadg(0, 0);
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			const int bsel = AHEAD ? (g & 1) : 0;
+			if constexpr (AHEAD) { if (g + 1 < NG) loadg(g + 1, (g + 1) & 1); }
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int i = 0; i < TG; i++) {
+				const int idx = g * TG + i;
+				if (idx < TOT) {
+					const int m = idx / (R - 1), t = idx % (R - 1) + 1;
+					v[m + t * NB] = octfft::cmul(v[m + t * NB], w[bsel][i]);
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			if constexpr (!AHEAD) { if (g + 1 < NG) loadg(g + 1, 0); }
 		}
 	} else if constexpr (NS > 1) {
 #pragma unroll
@@ -913,20 +982,28 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					const bool fast = OCT_ROLL_FAST != 0 && a.rollExact == 2;
 					const uint32_t kLog = 31u - (uint32_t)__builtin_clz((unsigned)(2 * W));
 					const uint32_t xBias = (150u - kLog) << 23;  // bit pattern of 2^(23-k)
+					// the window sums of all chunks are read before the first quotient (one LDS round trip instead of one per chunk)
+					uint32_t wsAll[NL][4];
+					if (quad) {
+						uint4 h4[NL], l4[NL];
+#pragma unroll
+						for (int i = 0; i < NL; i++) { h4[i] = *reinterpret_cast<const uint4*>(hiP + 256 * i); l4[i] = *reinterpret_cast<const uint4*>(loP + 256 * i); }
+#pragma unroll
+						for (int i = 0; i < NL; i++) { wsAll[i][0] = h4[i].x - l4[i].x; wsAll[i][1] = h4[i].y - l4[i].y; wsAll[i][2] = h4[i].z - l4[i].z; wsAll[i][3] = h4[i].w - l4[i].w; }
+					} else {
+#pragma unroll
+						for (int i = 0; i < NL; i++)
+#pragma unroll
+							for (int c = 0; c < 4; c++) wsAll[i][c] = hiP[256 * i + c] - loP[256 * i + c];
+					}
+					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 					for (int i = 0; i < NL; i++) {
 						float o[4];
 						const uint4 x = chunk_to_uint(pre[i], 0, shift);  // (recomputed: cheaper than 16 live registers)
 						const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-						uint32_t ws[4];
+						uint32_t ws[4] = {wsAll[i][0], wsAll[i][1], wsAll[i][2], wsAll[i][3]};
 						const bool whole = fast && i > 0 && i < NL - 1;
-						if (quad) {
-							const uint4 h4 = *reinterpret_cast<const uint4*>(hiP + 256 * i), l4 = *reinterpret_cast<const uint4*>(loP + 256 * i);
-							ws[0] = h4.x - l4.x; ws[1] = h4.y - l4.y; ws[2] = h4.z - l4.z; ws[3] = h4.w - l4.w;
-						} else {
-#pragma unroll
-							for (int c = 0; c < 4; c++) ws[c] = hiP[256 * i + c] - loP[256 * i + c];
-						}
 						if (whole) {
 #pragma unroll
 							for (int c = 0; c < 4; c++)
@@ -1043,6 +1120,30 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		constexpr bool AHEAD = GatherCfg<LOG2N>::AHEAD;
 #endif
 		constexpr int GG = (CW && GGW > 1 && P % GGW == 0 && (REGTAB || GGW % 2 == 0)) ? GGW : 1;
+#ifndef OCT_GATHER_DIST
+#define OCT_GATHER_DIST 0
+#endif
+		// (experiment) OCT_GATHER_DIST = D > 0: sample by sample with the reads of sample q + D issued before the sum of sample q
+		constexpr int GD = (CW && REGTAB && (OCT_GATHER_DIST) > 0 && (OCT_GATHER_DIST) < P) ? (OCT_GATHER_DIST) : 0;
+		if constexpr (GD > 0) {
+			float tp[GD + 1][4];
+			auto load1 = [&](int q) {
+				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
+#pragma unroll
+				for (int k = 0; k < 4; k++) tp[q % (GD + 1)][k] = t[k];
+			};
+#pragma unroll
+			for (int q = 0; q < GD; q++) load1(q);
+#pragma unroll
+			for (int q = 0; q < P; q++) {
+				if (q + GD < P) load1(q + GD);
+				__builtin_amdgcn_sched_barrier(0);
+				const f32x4 cw = cwR[q];
+				const float* t = tp[q % (GD + 1)];
+				v[q] = wphR[q] * __builtin_fmaf(cw.w, t[3], __builtin_fmaf(cw.z, t[2], __builtin_fmaf(cw.y, t[1], cw.x * t[0])));
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		} else
 		if constexpr (GG > 1) {
 			constexpr int NG = P / GG;
 			float tp[AHEAD ? 2 : 1][GG][4];

@@ -155,6 +155,8 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 				float* dst = reinterpret_cast<float*>(rowp + ROW_OFF + 4 * lane + 256 * c);
 				*reinterpret_cast<float4*>(dst) = lo4;
 				*reinterpret_cast<float4*>(dst + 4) = hi4;
+				// mirror tap of both rows (cu:284, n0 = |n1 - 1|): sample 1 is in lane 0's first unit -- written from the registers
+				if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING != 0) { if (c == 0 && lane == 0) rowp[ROW_OFF - 1] = f2{lo4.z, lo4.w}; }
 			}
 		} else {
 #pragma unroll
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 		}
 		if (pi + pairsStride < numPairs) prefetch(pi + pairsStride);
 		wave_sync_lds();
-		if constexpr (RS == RS_CUBIC) {
+		if constexpr (RS == RS_CUBIC && !(ILV && OCT_MIRROR_AT_STAGING != 0)) {
 			if constexpr (ILV) {
 				if (lane == 0) rowp[ROW_OFF - 1] = rowp[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284) of both rows
 			} else if (lane < 2) {
@@ -179,6 +181,42 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 		__builtin_amdgcn_s_setprio(3);
 		f2 v[P];
 		f32x4 win4;
+		// grouped gather (see oct_fused_kernel, kernels.h): the tap reads of GG samples go out together, the next group's ahead of the sums
+#ifndef OCT_R2_GATHER_GROUP
+#define OCT_R2_GATHER_GROUP 2
+#endif
+#ifndef OCT_R2_GATHER_AHEAD
+#define OCT_R2_GATHER_AHEAD 1
+#endif
+		constexpr int GG = (ILV && RS == RS_CUBIC && (OCT_R2_GATHER_GROUP) > 1 && P % (OCT_R2_GATHER_GROUP) == 0) ? (OCT_R2_GATHER_GROUP) : 1;
+		if constexpr (GG > 1) {
+			constexpr int NG = P / GG;
+			constexpr bool AHEAD = (OCT_R2_GATHER_AHEAD) != 0;
+			f2 tp[AHEAD ? 2 : 1][GG][4];
+			auto loadg = [&](int g, int b) {
+#pragma unroll
+				for (int i = 0; i < GG; i++) {
+					lds_cf2* t = (lds_cf2*)(uintptr_t)(tapA[g * GG + i]);
+#pragma unroll
+					for (int k = 0; k < 4; k++) tp[b][i][k] = t[k];
+				}
+			};
+			loadg(0, 0);
+#pragma unroll
+			for (int g = 0; g < NG; g++) {
+				const int b = AHEAD ? (g & 1) : 0;
+				if constexpr (AHEAD) { if (g + 1 < NG) loadg(g + 1, (g + 1) & 1); }
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int i = 0; i < GG; i++) {
+					const int q = g * GG + i;
+					const f2 w01 = f2{cwR[q].x, cwR[q].y}, w23 = f2{cwR[q].z, cwR[q].w};
+					v[q] = pk_scale_fma(1, tp[b][i][3], w23, pk_scale_fma(0, tp[b][i][2], w23, pk_scale_fma(1, tp[b][i][1], w01, pk_scale(0, tp[b][i][0], w01))));  // window already inside the weights
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				if constexpr (!AHEAD) { if (g + 1 < NG) loadg(g + 1, 0); }
+			}
+		} else
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			float w;
