@@ -33,6 +33,12 @@ template <int N_, int PADP_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 
 	static_assert(N_ % 2 == 0, "N / 2 bins");
 };
 
+#ifndef OCT_MXS_TAP_AHEAD
+#define OCT_MXS_TAP_AHEAD 3       // samples whose tap reads are in flight ahead of the interpolation (0: read and interpolate sample by sample)
+#endif
+#ifndef OCT_MXS_TAP_AHEAD_PAIR
+#define OCT_MXS_TAP_AHEAD_PAIR 2  // likewise on the pair route (8 registers per sample in flight instead of 4)
+#endif
 #ifndef OCT_MXS_LUT_AHEAD
 #define OCT_MXS_LUT_AHEAD 8  // table entries in flight per lane in the first pass (16 B each)
 #endif
@@ -106,10 +112,48 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 		};
 #pragma unroll
 		for (int sIdx = 0; sIdx < AHEAD; sIdx++) request(sIdx);
+		// second stage of the pipeline (round 5): the TAP reads of sample s + TA go out (as soon as its table entry is there) before sample
+		// s is interpolated -- read, wait, interpolate per sample is one dependent LDS round trip per sample, 20 per A-scan at N = 1000
+		constexpr int TAW = (LZ || RS == RS_NONE) ? 0 : (PAIR ? OCT_MXS_TAP_AHEAD_PAIR : OCT_MXS_TAP_AHEAD);
+		constexpr int TA = TAW <= 0 ? 0 : (TAW < AHEAD ? (TAW < S ? TAW : S - 1) : (AHEAD - 1 < S ? AHEAD - 1 : S - 1));
+		constexpr int NT = RS == RS_CUBIC ? 4 : 2;
+		float T1[PAIR ? 1 : TA + 1][NT];
+		f2 T2[PAIR ? TA + 1 : 1][NT];
+		auto taps = [&](int sIdx) {
+			const f32x4 e = L[sIdx % AHEAD];
+			const int n = (int)e.x - (RS == RS_CUBIC ? 1 : 0);  // tap 0 = sample n1 - 1 (the mirror tap of n1 = 0 sits at row[ROW_OFF - 1])
+#pragma unroll
+			for (int k = 0; k < NT; k++) {
+				if constexpr (PAIR) T2[sIdx % (TA + 1)][k] = reinterpret_cast<const f2*>(row)[ROW_OFF + n + k];
+				else T1[sIdx % (TA + 1)][k] = row[ROW_OFF + n + k];
+			}
+		};
+		if constexpr (TA > 0) {
+#pragma unroll
+			for (int sIdx = 0; sIdx < TA; sIdx++) taps(sIdx);
+		}
 #pragma unroll
 		for (int sIdx = 0; sIdx < S; sIdx++) {
 			const int it = sIdx / R, t = sIdx % R;
+			if constexpr (TA > 0) { if (sIdx + TA < S) taps(sIdx + TA); }
 			const f32x4 e = L[sIdx % AHEAD];
+			if constexpr (TA > 0) {
+				const float fr = __builtin_amdgcn_fractf(e.x);
+				if constexpr (PAIR) {
+					const f2* tp = T2[sIdx % (TA + 1)];
+					f2 y;
+					if constexpr (RS == RS_CUBIC) y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], fr);
+					else y = tp[0] + (tp[1] - tp[0]) * fr;
+					x[it][t] = y * e.y;
+				} else {
+					const float* tp = T1[sIdx % (TA + 1)];
+					float y;
+					if constexpr (RS == RS_CUBIC) y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], fr);
+					else y = tp[0] + (tp[1] - tp[0]) * fr;
+					const float yw = y * e.y;
+					x[it][t] = f2{yw * e.z, yw * e.w};
+				}
+			} else
 			if constexpr (PAIR) {
 				// both rows at once: every tap is the pair (row0[n], row1[n]); the windowed pair IS the complex sample (no phasor on this route)
 				const f2* rp = reinterpret_cast<const f2*>(row);
