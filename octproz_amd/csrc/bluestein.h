@@ -59,6 +59,7 @@ __global__ __launch_bounds__(bluestein_waves<LOG2M>() * 64) void oct_bluestein_k
 
 	const int N = (int)a.N, half = N / 2;
 	const unsigned wavesTotal = gridDim.x * (unsigned)WAVES;
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (unsigned line = blockIdx.x * (unsigned)WAVES + (unsigned)wave; line < a.numLines; line += wavesTotal) {
 		// ---- stage the row (plus the Lanczos halo) in LDS
 		if constexpr (RS == RS_LANCZOS) {

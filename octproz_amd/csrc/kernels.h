@@ -124,6 +124,13 @@ template <> struct GatherCfg<10> { static constexpr int GROUP = 4; static conste
 template <> struct GatherCfg<11> { static constexpr int GROUP = 4; static constexpr bool AHEAD = false; };  // +2 % (profiles/r5aa_*): tables from LDS too, 10 registers per sample in flight
 template <> struct GatherCfg<9> { static constexpr int GROUP = 4; static constexpr bool AHEAD = true; };
 template <> struct GatherCfg<8> { static constexpr int GROUP = 4; static constexpr bool AHEAD = false; };
+// see the persistent loop of oct_fused_kernel: one s_waitcnt vmcnt(0) in front of a persistent loop (expcnt / lgkmcnt untouched)
+#ifndef OCT_PROLOGUE_WAIT
+#define OCT_PROLOGUE_WAIT 1
+#endif
+OCT_DEV void prologue_wait() {
+	if constexpr (OCT_PROLOGUE_WAIT != 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+}
 template <int LOG2N> struct Cfg;
 template <> struct Cfg<8>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
 template <> struct Cfg<9>  { static constexpr bool PLANAR = false; static constexpr int WAVES_ROLL = 0; static constexpr int WAVES = 8,  MINW = 4; static constexpr bool LDS_LUT = true; static constexpr bool PRIO = true; static constexpr bool MEAN_REGS = true; static constexpr int WAVES_CW = 8; };
@@ -925,10 +932,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// gather -- with s_waitcnt vmcnt(15) ... vmcnt(0), one per sample, and those waits run in every iteration: vmcnt(3) ... vmcnt(0)
 	// then wait for the next row's prefetch, issued a few instructions earlier, i.e. for a full HBM round trip in the middle of every
 	// A-scan (tools/isa_sequence.py; round 5).  One wait per persistent wave here instead.
-#ifndef OCT_PROLOGUE_WAIT
-#define OCT_PROLOGUE_WAIT 1
-#endif
-	if constexpr (OCT_PROLOGUE_WAIT != 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (expcnt / lgkmcnt untouched)
+	// The same wait also drops what the prologue left pending from the waits at the loop's TOP: without it the first use of the
+	// prefetched row is guarded for "four loads pending" (the state at loop entry) although eight stores of the previous A-scan
+	// have followed those loads in every later iteration -- vmcnt(3) instead of vmcnt(11), i.e. a wait for stores issued a moment ago.
+	prologue_wait();
 	for (; line < lineEnd; line = next_line(line, inBlock), inBlock = (inBlock + 1u == BLK) ? 0u : inBlock + 1u) {
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 	if constexpr (RS != RS_LANCZOS) { if (line < a.numLines) prefetch(line); }
 	const __amdgpu_buffer_rsrc_t lanczosR = make_rsrc(a.lanczosW, N * 64u);
 
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (; line < a.numLines; line += wavesTotal) {
 		if constexpr (RS == RS_LANCZOS) {
 			// stage [off - 8, off + N + 8) of the buffer, off = clamp(line N, 8, S - 9) (cu:313-314), 0 outside the buffer: 16-byte

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(T, OCT_MXN_MINW) void oct_mixedn_kernel(const Mixed
 	for (int i = tid; i < N; i += T) twL[i] = a.twiddle[i];
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (unsigned line = blockIdx.x; line < a.numLines; line += gridDim.x) {
 		__syncthreads();  // tables filled / every thread is past the previous A-scan's gather
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141)

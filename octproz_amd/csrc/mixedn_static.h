@@ -355,6 +355,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	}
 	// one unit of work per wave and iteration: an A-scan, or (PAIR) the A-scans 2 i and 2 i + 1 (an odd last one: a row of zeros as partner)
 	const unsigned units = PAIR ? (a.numLines + 1u) / 2u : a.numLines;
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (unsigned unit = blockIdx.x * W + wave; unit < units; unit += gridDim.x * W) {
 		const unsigned line = PAIR ? 2u * unit : unit;
 		if constexpr (RS == RS_LANCZOS) {

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 	};
 	if (pi < numPairs) prefetch(pi);
 
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (; pi < numPairs; pi += pairsStride) {
 		// ---- stage both raw rows in LDS as float32
 		if constexpr (ILV) {

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(Real2Cfg<LOG2N>::WAVES * 64, Real2Cfg<LOG2N>::MINW)
 	};
 	if (pi < numPairs) prefetch(pi);
 
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (; pi < numPairs; pi += pairsStride) {
 		// ---- stage both raw rows in LDS as float32
 		if constexpr (ILV) {

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 		team_barrier();
 	}
 
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (; line < a.numLines; line += gridDim.x) {
 		if constexpr (ROLL) {
 			// ---- the raw row minus the rolling average (cu:165-211; team_kernel.h): three barriers of its own

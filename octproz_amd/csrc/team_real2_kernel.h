@@ -132,6 +132,7 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_real2_kernel(c
 	const f2* rb2 = rowp + L;
 	f2* wb3 = xbuf + (4096 * (L >> 8) + (L & 255));  // N = 8192: pass 3 output 4096 (L >> 8) + (L & 255) + 256 u at wb3[256 u]
 
+	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
 	for (; pi < numPairs; pi += gridDim.x) {
 		// ---- stage both rows interleaved as float32
 #pragma unroll
