@@ -221,6 +221,43 @@ OCT_DEV u32x2 buf_load64(__amdgpu_buffer_rsrc_t r, int vbase, int c) {
 OCT_DEV void buf_store32(float v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, vbase + (c & 4095), c & ~4095, OCT_STORE_AUX);
 }
+// Cubic gather with the tap weights, window x phasor and tap addresses of the lane's P samples in registers: the tap reads of G samples
+// go out together (ragged last group), with AHEAD the next group's before the sums of the current one (see the gather of oct_fused_kernel).
+typedef __attribute__((address_space(3))) const float lds_cfloat_g;
+template <int P, int G, bool AHEAD>
+OCT_DEV void gather_cubic_groups(const uint32_t (&tapA)[P], const f32x4 (&cwR)[P], const f2 (&wphR)[P], f2 (&v)[P]) {
+	constexpr int NG = (P + G - 1) / G;
+	float tp[AHEAD ? 2 : 1][G][4];
+	auto loadg = [&](int g, int b) {
+#pragma unroll
+		for (int i = 0; i < G; i++) {
+			const int q = g * G + i;
+			if (q < P) {
+				lds_cfloat_g* t = (lds_cfloat_g*)(uintptr_t)(tapA[q]);
+#pragma unroll
+				for (int k = 0; k < 4; k++) tp[b][i][k] = t[k];
+			}
+		}
+	};
+	loadg(0, 0);
+#pragma unroll
+	for (int g = 0; g < NG; g++) {
+		const int b = AHEAD ? (g & 1) : 0;
+		if constexpr (AHEAD) { if (g + 1 < NG) loadg(g + 1, (g + 1) & 1); }
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int i = 0; i < G; i++) {
+			const int q = g * G + i;
+			if (q < P) {
+				const f32x4 cw = cwR[q];
+				v[q] = wphR[q] * __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		if constexpr (!AHEAD) { if (g + 1 < NG) loadg(g + 1, 0); }
+	}
+}
+
 // Image store with the post-process background removal folded in (cu:757-767: saturate(v - (weight bg[bin] + offset)), the only
 // clamp of the float path).  Valid whenever no sinusoidal correction sits between the grey-scale mapping and the removal: the
 // B-scan flip only moves whole A-scans.  term[bin] = weight bg[bin] + offset is prepared by oct_bg_term_kernel with the

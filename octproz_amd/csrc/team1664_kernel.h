@@ -159,6 +159,12 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 		// ---- k-linearisation x window x dispersion phasor: samples L + 128 q
 		__builtin_amdgcn_s_setprio(3);
 		f2 x[13];
+#ifndef OCT_TEAM1664_GATHER_GROUP
+#define OCT_TEAM1664_GATHER_GROUP 2
+#endif
+		if constexpr (RS == RS_CUBIC && (OCT_TEAM1664_GATHER_GROUP) > 1) {
+			gather_cubic_groups<P, OCT_TEAM1664_GATHER_GROUP, true>(tapA, cwR, wphR, x);
+		} else
 #pragma unroll
 		for (int q = 0; q < P; q++) {
 			float y;
