@@ -1202,7 +1202,11 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					for (int k = 0; k < 4; k++) tp[b][i][k] = t[k];
 					if constexpr (!REGTAB) {
 						cwG[b][i] = cwL[lane + 64 * q];
+#ifdef OCT_SKEL_NO_WPH  // (timing skeleton, wrong results: what the window x phasor table reads cost)
+						if ((q & 1) == 0) wpG[b][i >> 1] = cwG[b][i];
+#else
 						if ((q & 1) == 0) wpG[b][i >> 1] = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];
+#endif
 					}
 				}
 			};
