@@ -1018,10 +1018,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					// Five instructions per sample (subtract, or, extract, shift-or, fma) instead of nine (two conversions, multiply, two FMAs
 					// of the exact quotient, subtract); the first and the last chunk, where windows are clipped, keep the general form.
 #ifndef OCT_ROLL_FAST
-#define OCT_ROLL_FAST 0  // measured 1 % SLOWER than the general form (0.2198 vs 0.2174 ms per 1024 x 512 x 256 buffer, same box interleaved,
-                         // profiles/r5k_roll_fast_ab.txt): 32 VALU instructions fewer per A-scan buy nothing here -- with two waves per SIMD the
-                         // variant waits on its two dependent LDS round trips (prefix array written -> window sums read -> row written -> taps
-                         // read), not on instruction issue.  Kept as a switch and a record.
+#define OCT_ROLL_FAST 1  // Round 5, first measurement: 1 % SLOWER than the general form (profiles/r5k_roll_fast_ab.txt) -- the variant was waiting on
+                         // its dependent LDS round trips, not on instruction issue.  With the window sums, the tap reads and the LDS twiddles read in
+                         // groups the same switch is +2.6 % (0.1993 -> 0.1941 ms, profiles/r5an_*) and is on.
 #endif
 					const bool fast = OCT_ROLL_FAST != 0 && a.rollExact == 2;
 					const uint32_t kLog = 31u - (uint32_t)__builtin_clz((unsigned)(2 * W));
@@ -1223,7 +1222,17 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					f2 wph;
 					if constexpr (REGTAB) { cw = cwR[q]; wph = wphR[q]; }
 					else { cw = cwG[b][i]; const f32x4 w2 = wpG[b][i >> 1]; wph = (q & 1) ? f2{w2.z, w2.w} : f2{w2.x, w2.y}; }
-					const float y = __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));
+#ifndef OCT_CUBIC_PK
+#define OCT_CUBIC_PK 0
+#endif
+					float y;
+					if constexpr (OCT_CUBIC_PK != 0) {  // (experiment) packed: (w0 t0, w1 t1) -> fma (w2 t2, w3 t3) -> one add: three instructions instead of four, another rounding order
+						f2 acc = f2{cw.x, cw.y} * f2{tp[b][i][0], tp[b][i][1]};
+						acc = __builtin_elementwise_fma(f2{cw.z, cw.w}, f2{tp[b][i][2], tp[b][i][3]}, acc);
+						y = acc.x + acc.y;
+					} else {
+						y = __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));
+					}
 					v[q] = wph * y;
 				}
 				__builtin_amdgcn_sched_barrier(0);
