@@ -114,6 +114,19 @@ struct FusedArgs {
 #ifndef OCT_REGTAB11
 #define OCT_REGTAB11 0
 #endif
+// static wave priority per phase (s_setprio; experiments override)
+#ifndef OCT_PRIO_GATHER
+#define OCT_PRIO_GATHER 3
+#endif
+#ifndef OCT_PRIO_FFT
+#define OCT_PRIO_FFT 2
+#endif
+#ifndef OCT_PRIO_EPILOGUE
+#define OCT_PRIO_EPILOGUE 1
+#endif
+#ifndef OCT_PRIO_STAGING
+#define OCT_PRIO_STAGING 0
+#endif
 #ifndef OCT_MIRROR_AT_STAGING
 #define OCT_MIRROR_AT_STAGING 1
 #endif
@@ -154,6 +167,16 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 #endif
 	static constexpr bool REGLIN = !CW && (LOG2N == 10 || (LOG2N <= 9 && OCT_REGLIN_SHORT != 0)) && OCT_REGLIN != 0 && (RS == RS_LINEAR || RS == RS_NONE) && !ROLL;
 	// Lanczos: the [N][16] tap-weight table (64 B per sample) in LDS where it fits (N <= 1024; at N = 1024 with 8 waves)
+	// EARLY (N = 1024 register-table kernels without the rolling average): the row of the NEXT A-scan is staged into a row buffer of its
+	// own in the middle of the current A-scan's transform (behind the writes of the first exchange) instead of at the top of the next
+	// iteration: staging leaves the wave's critical path and fills the exchange's round trip.  +4 KiB of LDS per wave (8 waves: fits).
+	// Measured (profiles/r5ap_early_staging_ab.txt): 2.7 % SLOWER (0.1574-0.1589 vs 0.1536-0.1541 ms) with either form of the waits -- the
+	// staging at the top of the iteration runs at the lowest wave priority and yields to the other wave; in the middle of the
+	// transform it sits in front of the exchange's reads.  Off; kept as a switch and a record.
+#ifndef OCT_EARLY_STAGE
+#define OCT_EARLY_STAGE 0
+#endif
+	static constexpr bool EARLY = REGTAB && LOG2N == 10 && !ROLL && OCT_EARLY_STAGE != 0;
 	static constexpr bool LZ_LDS = RS == RS_LANCZOS && LOG2N <= 10 && Cfg<LOG2N>::LDS_LUT && OCT_LANCZOS_LDS != 0;
 	static constexpr int WAVES_PLAIN = REGLIN ? (LOG2N <= 9 ? Cfg<LOG2N>::WAVES : RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : (LZ_LDS && LOG2N == 10) ? 8 : Cfg<LOG2N>::WAVES;
 	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
@@ -678,8 +701,11 @@ template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
 	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value;
 	return lane + 64 * m + u * (N / RL);
 }
-template <int LOG2N, bool PRUNE, bool REGTW = false, bool REGTW3 = false>
-OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane, const f32x4* twr = nullptr) {
+// HOOK: called between the writes and the reads of the first exchange of the PERM plan (N = 1024) -- the place where a wave waits
+// for its own LDS round trip; oct_fused_kernel stages the NEXT A-scan's row there (KCfg::EARLY)
+struct NoHook { OCT_DEV void operator()() const {} };
+template <int LOG2N, bool PRUNE, bool REGTW = false, bool REGTW3 = false, class HOOK = NoHook>
+OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane, const f32x4* twr = nullptr, HOOK hook = HOOK()) {
 	constexpr int N = 1 << LOG2N;
 	typedef Plan<LOG2N> PL;
 	constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
@@ -720,6 +746,7 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 		return;
 	}
 	fft_pass<N, R0, 1, false, true, false>(v, xbuf, tw, lane);
+	hook();
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
 		constexpr bool PX = OCT_PERM_EXCHANGE != 0;
@@ -765,8 +792,12 @@ OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
 }
 template <int LOG2N, int RS> constexpr int mean_lds_bytes() { return KCfg<LOG2N, RS>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
 template <int LOG2N, int RS, bool ROLL = false> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB || KCfg<LOG2N, RS, ROLL>::REGLIN) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12) + (KCfg<LOG2N, RS>::LZ_LDS ? (1 << LOG2N) * 64 : 0); }
+constexpr int early_row_bytes(int n) { return ((n + 2 * ROW_OFF) * 4 + 15) & ~15; }
+template <int LOG2N, int RS, bool ROLL> constexpr int slice_lds_bytes() {
+	return wave_lds_bytes<(1 << LOG2N), ROLL>() + (KCfg<LOG2N, RS, ROLL>::EARLY ? early_row_bytes(1 << LOG2N) : 0);
+}
 template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
-	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
+	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * slice_lds_bytes<LOG2N, RS, ROLL>();
 }
 
 // B-scan flip folded into the output row (cu:787-807): even buffer-local B-scans are mirrored; the reference's launch covers S/4
@@ -816,8 +847,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	f32x4* lzL = reinterpret_cast<f32x4*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + N * 12);
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
-	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * wave_lds_bytes<N, ROLL>();
-	float* row = reinterpret_cast<float*>(wbase);
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * slice_lds_bytes<LOG2N, RS, ROLL>();
+	constexpr bool EARLYROW = KCfg<LOG2N, RS, ROLL>::EARLY;  // the slice holds a row buffer behind the exchange buffer
+	float* row = reinterpret_cast<float*>(EARLYROW ? wbase + wave_lds_bytes<N, ROLL>() : wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
 	// tables -> LDS, once per (persistent) workgroup
@@ -973,8 +1005,43 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// prefetched row is guarded for "four loads pending" (the state at loop entry) although eight stores of the previous A-scan
 	// have followed those loads in every later iteration -- vmcnt(3) instead of vmcnt(11), i.e. a wait for stores issued a moment ago.
 	prologue_wait();
+	// EARLY: standard staging of the row held in pre[] (any container; no rolling average) into the row buffer, and the prefetch of a later row
+	constexpr bool EARLY = EARLYROW && !DISP && RS != RS_LANCZOS;
+	auto stage_std = [&]() {
+#pragma unroll
+		for (int i = 0; i < NL; i++) {
+#pragma unroll
+			for (int h = 0; h < SPL / 4; h++) {
+				const float4 f = chunk_to_float<INTYPE>(pre[i], h, shift);
+				*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = f;
+				if constexpr (RS == RS_CUBIC) { if (i == 0 && h == 0 && lane == 0) row[ROW_OFF - 1] = f.y; }  // mirror tap (cu:284)
+			}
+		}
+	};
+	auto prefetch_line = [&](unsigned ln) {
+		if (ln < lineEnd) {
+			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * rowBytes, rowBytes);
+#pragma unroll
+			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
+		}
+	};
+	if constexpr (EARLY) {
+		if (line < lineEnd) {
+			stage_std();                        // the first row (its loads have arrived: prologue_wait)
+			prefetch_line(line + blockStride);  // BLK == 1 here
+		}
+#ifndef OCT_EARLY_WAIT_AFTER
+#define OCT_EARLY_WAIT_AFTER 0
+#endif
+		// (experiment) also wait for that second prefetch: nothing pending at loop entry, so the waits in the hook count the eight stores
+		// that follow the loads in every later iteration (vmcnt(11) ... (8) instead of (3) ... (0)) -- at the price of one exposed HBM
+		// round trip per persistent wave
+		if constexpr (OCT_EARLY_WAIT_AFTER != 0) prologue_wait();
+	}
 	for (; line < lineEnd; line = next_line(line, inBlock), inBlock = (inBlock + 1u == BLK) ? 0u : inBlock + 1u) {
-		// ---- stage the raw row in LDS as float32
+		// ---- stage the raw row in LDS as float32 (EARLY: done in the middle of the previous iteration, see the transform's hook)
+		if constexpr (EARLY) {
+		} else
 		if constexpr (RS != RS_LANCZOS) {
 			bool staged = false;
 			if constexpr (ROLL) {
@@ -1137,7 +1204,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		// which beat waves in the epilogue, which beat waves staging/prefetching.  With 16 waves per CU
 		// all in different phases this keeps the LDS-latency-bound gather from queueing behind the
 		// VALU-dense FFT of its SIMD neighbours: +7 % A-scans/s measured.
-		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(3);
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_GATHER);
 		f2 v[P];
 		f32x4 wph2;
 		// Lanczos with the weights table behind L2: the four loads of sample q + LZ_AHEAD are issued before the taps of sample q are
@@ -1310,9 +1377,21 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		wave_sync_lds();  // the row is dead from here on; its LDS is reused by the FFT
 
 		// ---- inverse FFT
-		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(2);
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_FFT);
+		if constexpr (EARLY) {
+			// behind the writes of the first exchange: the next row of this wave goes from pre[] into the row buffer (every tap read of the
+			// current A-scan has returned: its sums are what the transform is working on) and the row after it is requested
+			const unsigned nx = line + blockStride;
+			auto hook = [&]() {
+				if (nx < lineEnd) {
+					stage_std();
+					prefetch_line(nx + blockStride);
+				}
+			};
+			fft_wave<LOG2N, !SPECTRUM, TW2, TW3>(v, xbuf, tw, lane, tw2R, hook);
+		} else
 		fft_wave<LOG2N, !SPECTRUM, TW2, TW3>(v, xbuf, tw, lane, tw2R);
-		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(1);
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_EPILOGUE);
 
 		if constexpr (SPECTRUM) {
 			f2* dst = a.spectrum + (size_t)line * N + lane;
@@ -1383,7 +1462,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				}
 			}
 		}
-		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(0);
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_STAGING);
 		wave_sync_lds();
 	}
 	if constexpr (DISP) {
