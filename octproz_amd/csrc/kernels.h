@@ -167,16 +167,6 @@ template <int LOG2N, int RS, bool ROLL = false> struct KCfg {
 #endif
 	static constexpr bool REGLIN = !CW && (LOG2N == 10 || (LOG2N <= 9 && OCT_REGLIN_SHORT != 0)) && OCT_REGLIN != 0 && (RS == RS_LINEAR || RS == RS_NONE) && !ROLL;
 	// Lanczos: the [N][16] tap-weight table (64 B per sample) in LDS where it fits (N <= 1024; at N = 1024 with 8 waves)
-	// EARLY (N = 1024 register-table kernels without the rolling average): the row of the NEXT A-scan is staged into a row buffer of its
-	// own in the middle of the current A-scan's transform (behind the writes of the first exchange) instead of at the top of the next
-	// iteration: staging leaves the wave's critical path and fills the exchange's round trip.  +4 KiB of LDS per wave (8 waves: fits).
-	// Measured (profiles/r5ap_early_staging_ab.txt): 2.7 % SLOWER (0.1574-0.1589 vs 0.1536-0.1541 ms) with either form of the waits -- the
-	// staging at the top of the iteration runs at the lowest wave priority and yields to the other wave; in the middle of the
-	// transform it sits in front of the exchange's reads.  Off; kept as a switch and a record.
-#ifndef OCT_EARLY_STAGE
-#define OCT_EARLY_STAGE 0
-#endif
-	static constexpr bool EARLY = REGTAB && LOG2N == 10 && !ROLL && OCT_EARLY_STAGE != 0;
 	static constexpr bool LZ_LDS = RS == RS_LANCZOS && LOG2N <= 10 && Cfg<LOG2N>::LDS_LUT && OCT_LANCZOS_LDS != 0;
 	static constexpr int WAVES_PLAIN = REGLIN ? (LOG2N <= 9 ? Cfg<LOG2N>::WAVES : RS == RS_NONE && OCT_NONE12 ? 12 : 8) : CW ? Cfg<LOG2N>::WAVES_CW : (LZ_LDS && LOG2N == 10) ? 8 : Cfg<LOG2N>::WAVES;
 	// the rolling-average variants carry a padded prefix-sum array per wave: fewer waves where the LDS budget says so
@@ -452,14 +442,6 @@ constexpr int pad16c(int j) { return j + OCT_PADK * (j >> 4); }
 #ifndef OCT_TW_LDS_GROUP
 #define OCT_TW_LDS_GROUP 1
 #endif
-// twiddle reads of the generic passes in groups (fft_pass): per transform length
-#ifndef OCT_TW_GROUP
-#define OCT_TW_GROUP 0
-#endif
-#ifndef OCT_TW_AHEAD
-#define OCT_TW_AHEAD 0
-#endif
-template <int N> struct TwGroupCfg { static constexpr int GROUP = (N == 2048) ? (OCT_TW_GROUP) : 0; static constexpr bool AHEAD = (OCT_TW_AHEAD) != 0; };
 template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0, bool REGTW = false, bool REGTW3 = false>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const f32x4* twr = nullptr) {
 	constexpr int P = N / 64, NB = P / R;
@@ -509,40 +491,6 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 			const int i0 = 2 * c, i1 = 2 * c + 1;
 			v[i0 / 3 + (i0 % 3 + 1) * NB] = octfft::cmul(v[i0 / 3 + (i0 % 3 + 1) * NB], f2{w.x, w.y});
 			v[i1 / 3 + (i1 % 3 + 1) * NB] = octfft::cmul(v[i1 / 3 + (i1 % 3 + 1) * NB], f2{w.z, w.w});
-		}
-	} else if constexpr (NS > 1 && TwGroupCfg<N>::GROUP > 1) {
-		// the NB (R - 1) twiddles of the lane in groups: the reads of a group go out together (with AHEAD the next group's before the
-		// products of the current one) instead of one read, one wait, one product -- a dependent LDS round trip per twiddle, 30 + 24
-		// per A-scan at N = 2048 (tools/isa_sequence.py)
-		constexpr int TG = TwGroupCfg<N>::GROUP, TOT = NB * (R - 1), NG = (TOT + TG - 1) / TG;
-		constexpr bool AHEAD = TwGroupCfg<N>::AHEAD;
-		f2 w[AHEAD ? 2 : 1][TG];
-		auto loadg = [&](int g, int bsel) {
-#pragma unroll
-			for (int i = 0; i < TG; i++) {
-				const int idx = g * TG + i;
-				if (idx < TOT) {
-					const int m = idx / (R - 1), t = idx % (R - 1) + 1;
-					w[bsel][i] = twp[((lane + 64 * m) & (NS - 1)) + (t - 1) * NS];  // table layout [t-1][k]
-				}
-			}
-		};
-		loadg(0, 0);
-#pragma unroll
-		for (int g = 0; g < NG; g++) {
-			const int bsel = AHEAD ? (g & 1) : 0;
-			if constexpr (AHEAD) { if (g + 1 < NG) loadg(g + 1, (g + 1) & 1); }
-			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for (int i = 0; i < TG; i++) {
-				const int idx = g * TG + i;
-				if (idx < TOT) {
-					const int m = idx / (R - 1), t = idx % (R - 1) + 1;
-					v[m + t * NB] = octfft::cmul(v[m + t * NB], w[bsel][i]);
-				}
-			}
-			__builtin_amdgcn_sched_barrier(0);
-			if constexpr (!AHEAD) { if (g + 1 < NG) loadg(g + 1, 0); }
 		}
 	} else if constexpr (NS > 1) {
 #pragma unroll
@@ -701,11 +649,8 @@ template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
 	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value;
 	return lane + 64 * m + u * (N / RL);
 }
-// HOOK: called between the writes and the reads of the first exchange of the PERM plan (N = 1024) -- the place where a wave waits
-// for its own LDS round trip; oct_fused_kernel stages the NEXT A-scan's row there (KCfg::EARLY)
-struct NoHook { OCT_DEV void operator()() const {} };
-template <int LOG2N, bool PRUNE, bool REGTW = false, bool REGTW3 = false, class HOOK = NoHook>
-OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane, const f32x4* twr = nullptr, HOOK hook = HOOK()) {
+template <int LOG2N, bool PRUNE, bool REGTW = false, bool REGTW3 = false>
+OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane, const f32x4* twr = nullptr) {
 	constexpr int N = 1 << LOG2N;
 	typedef Plan<LOG2N> PL;
 	constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
@@ -746,7 +691,6 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 		return;
 	}
 	fft_pass<N, R0, 1, false, true, false>(v, xbuf, tw, lane);
-	hook();
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
 		constexpr bool PX = OCT_PERM_EXCHANGE != 0;
@@ -792,12 +736,8 @@ OCT_DEV void fill_twiddles(f2* tw, const f2* g, int tid, int threads) {
 }
 template <int LOG2N, int RS> constexpr int mean_lds_bytes() { return KCfg<LOG2N, RS>::MEAN_REGS ? 0 : (1 << LOG2N) * 4; }
 template <int LOG2N, int RS, bool ROLL = false> constexpr int lut_lds_bytes() { return (!Cfg<LOG2N>::LDS_LUT || KCfg<LOG2N, RS>::REGTAB || KCfg<LOG2N, RS, ROLL>::REGLIN) ? 0 : (1 << LOG2N) * (KCfg<LOG2N, RS>::CW ? 24 : 12) + (KCfg<LOG2N, RS>::LZ_LDS ? (1 << LOG2N) * 64 : 0); }
-constexpr int early_row_bytes(int n) { return ((n + 2 * ROW_OFF) * 4 + 15) & ~15; }
-template <int LOG2N, int RS, bool ROLL> constexpr int slice_lds_bytes() {
-	return wave_lds_bytes<(1 << LOG2N), ROLL>() + (KCfg<LOG2N, RS, ROLL>::EARLY ? early_row_bytes(1 << LOG2N) : 0);
-}
 template <int LOG2N, int RS, bool ROLL> constexpr int block_lds_bytes() {
-	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * slice_lds_bytes<LOG2N, RS, ROLL>();
+	return tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + KCfg<LOG2N, RS, ROLL>::WAVES * wave_lds_bytes<(1 << LOG2N), ROLL>();
 }
 
 // B-scan flip folded into the output row (cu:787-807): even buffer-local B-scans are mirrored; the reference's launch covers S/4
@@ -847,9 +787,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	f32x4* lzL = reinterpret_cast<f32x4*>(smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + N * 12);
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
-	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * slice_lds_bytes<LOG2N, RS, ROLL>();
-	constexpr bool EARLYROW = KCfg<LOG2N, RS, ROLL>::EARLY;  // the slice holds a row buffer behind the exchange buffer
-	float* row = reinterpret_cast<float*>(EARLYROW ? wbase + wave_lds_bytes<N, ROLL>() : wbase);
+	char* wbase = smem + tw_lds_bytes<LOG2N>() + mean_lds_bytes<LOG2N, RS>() + lut_lds_bytes<LOG2N, RS, ROLL>() + wave * wave_lds_bytes<N, ROLL>();
+	float* row = reinterpret_cast<float*>(wbase);
 	f2* xbuf = reinterpret_cast<f2*>(wbase);
 
 	// tables -> LDS, once per (persistent) workgroup
@@ -1005,43 +944,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// prefetched row is guarded for "four loads pending" (the state at loop entry) although eight stores of the previous A-scan
 	// have followed those loads in every later iteration -- vmcnt(3) instead of vmcnt(11), i.e. a wait for stores issued a moment ago.
 	prologue_wait();
-	// EARLY: standard staging of the row held in pre[] (any container; no rolling average) into the row buffer, and the prefetch of a later row
-	constexpr bool EARLY = EARLYROW && !DISP && RS != RS_LANCZOS;
-	auto stage_std = [&]() {
-#pragma unroll
-		for (int i = 0; i < NL; i++) {
-#pragma unroll
-			for (int h = 0; h < SPL / 4; h++) {
-				const float4 f = chunk_to_float<INTYPE>(pre[i], h, shift);
-				*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = f;
-				if constexpr (RS == RS_CUBIC) { if (i == 0 && h == 0 && lane == 0) row[ROW_OFF - 1] = f.y; }  // mirror tap (cu:284)
-			}
-		}
-	};
-	auto prefetch_line = [&](unsigned ln) {
-		if (ln < lineEnd) {
-			const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * rowBytes, rowBytes);
-#pragma unroll
-			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
-		}
-	};
-	if constexpr (EARLY) {
-		if (line < lineEnd) {
-			stage_std();                        // the first row (its loads have arrived: prologue_wait)
-			prefetch_line(line + blockStride);  // BLK == 1 here
-		}
-#ifndef OCT_EARLY_WAIT_AFTER
-#define OCT_EARLY_WAIT_AFTER 0
-#endif
-		// (experiment) also wait for that second prefetch: nothing pending at loop entry, so the waits in the hook count the eight stores
-		// that follow the loads in every later iteration (vmcnt(11) ... (8) instead of (3) ... (0)) -- at the price of one exposed HBM
-		// round trip per persistent wave
-		if constexpr (OCT_EARLY_WAIT_AFTER != 0) prologue_wait();
-	}
 	for (; line < lineEnd; line = next_line(line, inBlock), inBlock = (inBlock + 1u == BLK) ? 0u : inBlock + 1u) {
-		// ---- stage the raw row in LDS as float32 (EARLY: done in the middle of the previous iteration, see the transform's hook)
-		if constexpr (EARLY) {
-		} else
+		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
 			bool staged = false;
 			if constexpr (ROLL) {
@@ -1230,30 +1134,6 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		constexpr bool AHEAD = GatherCfg<LOG2N>::AHEAD;
 #endif
 		constexpr int GG = (CW && GGW > 1 && P % GGW == 0 && (REGTAB || GGW % 2 == 0)) ? GGW : 1;
-#ifndef OCT_GATHER_DIST
-#define OCT_GATHER_DIST 0
-#endif
-		// (experiment) OCT_GATHER_DIST = D > 0: sample by sample with the reads of sample q + D issued before the sum of sample q
-		constexpr int GD = (CW && REGTAB && (OCT_GATHER_DIST) > 0 && (OCT_GATHER_DIST) < P) ? (OCT_GATHER_DIST) : 0;
-		if constexpr (GD > 0) {
-			float tp[GD + 1][4];
-			auto load1 = [&](int q) {
-				lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[q]);
-#pragma unroll
-				for (int k = 0; k < 4; k++) tp[q % (GD + 1)][k] = t[k];
-			};
-#pragma unroll
-			for (int q = 0; q < GD; q++) load1(q);
-#pragma unroll
-			for (int q = 0; q < P; q++) {
-				if (q + GD < P) load1(q + GD);
-				__builtin_amdgcn_sched_barrier(0);
-				const f32x4 cw = cwR[q];
-				const float* t = tp[q % (GD + 1)];
-				v[q] = wphR[q] * __builtin_fmaf(cw.w, t[3], __builtin_fmaf(cw.z, t[2], __builtin_fmaf(cw.y, t[1], cw.x * t[0])));
-				__builtin_amdgcn_sched_barrier(0);
-			}
-		} else
 		if constexpr (GG > 1) {
 			constexpr int NG = P / GG;
 			float tp[AHEAD ? 2 : 1][GG][4];
@@ -1268,11 +1148,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					for (int k = 0; k < 4; k++) tp[b][i][k] = t[k];
 					if constexpr (!REGTAB) {
 						cwG[b][i] = cwL[lane + 64 * q];
-#ifdef OCT_SKEL_NO_WPH  // (timing skeleton, wrong results: what the window x phasor table reads cost)
-						if ((q & 1) == 0) wpG[b][i >> 1] = cwG[b][i];
-#else
 						if ((q & 1) == 0) wpG[b][i >> 1] = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];
-#endif
 					}
 				}
 			};
@@ -1289,17 +1165,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					f2 wph;
 					if constexpr (REGTAB) { cw = cwR[q]; wph = wphR[q]; }
 					else { cw = cwG[b][i]; const f32x4 w2 = wpG[b][i >> 1]; wph = (q & 1) ? f2{w2.z, w2.w} : f2{w2.x, w2.y}; }
-#ifndef OCT_CUBIC_PK
-#define OCT_CUBIC_PK 0
-#endif
-					float y;
-					if constexpr (OCT_CUBIC_PK != 0) {  // (experiment) packed: (w0 t0, w1 t1) -> fma (w2 t2, w3 t3) -> one add: three instructions instead of four, another rounding order
-						f2 acc = f2{cw.x, cw.y} * f2{tp[b][i][0], tp[b][i][1]};
-						acc = __builtin_elementwise_fma(f2{cw.z, cw.w}, f2{tp[b][i][2], tp[b][i][3]}, acc);
-						y = acc.x + acc.y;
-					} else {
-						y = __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));
-					}
+					const float y = __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));
 					v[q] = wph * y;
 				}
 				__builtin_amdgcn_sched_barrier(0);
@@ -1378,18 +1244,6 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 
 		// ---- inverse FFT
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_FFT);
-		if constexpr (EARLY) {
-			// behind the writes of the first exchange: the next row of this wave goes from pre[] into the row buffer (every tap read of the
-			// current A-scan has returned: its sums are what the transform is working on) and the row after it is requested
-			const unsigned nx = line + blockStride;
-			auto hook = [&]() {
-				if (nx < lineEnd) {
-					stage_std();
-					prefetch_line(nx + blockStride);
-				}
-			};
-			fft_wave<LOG2N, !SPECTRUM, TW2, TW3>(v, xbuf, tw, lane, tw2R, hook);
-		} else
 		fft_wave<LOG2N, !SPECTRUM, TW2, TW3>(v, xbuf, tw, lane, tw2R);
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_EPILOGUE);
 
