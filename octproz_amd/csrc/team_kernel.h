@@ -340,41 +340,16 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 #pragma unroll
 				for (int c = 0; c < 4; c++) lzw[q][c] = buf_load128(lanczosR, L * 64, q * T * 64 + c * 16);
 		}
-		// cubic: the tap reads of four samples go out together, the next four ahead of the sums (kernels.h, grouped gather)
+		// cubic: the tap reads of two samples go out together, the next two ahead of the sums (kernels.h gather_cubic_groups; four at once spill here)
 #ifndef OCT_TEAM_GATHER_GROUP
 #define OCT_TEAM_GATHER_GROUP 2
 #endif
 #ifndef OCT_TEAM_GATHER_AHEAD
 #define OCT_TEAM_GATHER_AHEAD 1
 #endif
-		constexpr int GG = (RS == RS_CUBIC && (OCT_TEAM_GATHER_GROUP) > 1 && P % (OCT_TEAM_GATHER_GROUP) == 0) ? (OCT_TEAM_GATHER_GROUP) : 1;
+		constexpr int GG = (RS == RS_CUBIC && (OCT_TEAM_GATHER_GROUP) > 1) ? (OCT_TEAM_GATHER_GROUP) : 1;
 		if constexpr (GG > 1) {
-			constexpr int NG = P / GG;
-			constexpr bool GA = (OCT_TEAM_GATHER_AHEAD) != 0;
-			float tp[GA ? 2 : 1][GG][4];
-			auto loadg = [&](int g, int b) {
-#pragma unroll
-				for (int i = 0; i < GG; i++) {
-					lds_cfloat* t = (lds_cfloat*)(uintptr_t)(tapA[g * GG + i]);
-#pragma unroll
-					for (int k = 0; k < 4; k++) tp[b][i][k] = t[k];
-				}
-			};
-			loadg(0, 0);
-#pragma unroll
-			for (int g = 0; g < NG; g++) {
-				const int b = GA ? (g & 1) : 0;
-				if constexpr (GA) { if (g + 1 < NG) loadg(g + 1, (g + 1) & 1); }
-				__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-				for (int i = 0; i < GG; i++) {
-					const int q = g * GG + i;
-					const f32x4 cw = cwR[q];
-					v[q] = wphR[q] * __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));
-				}
-				__builtin_amdgcn_sched_barrier(0);
-				if constexpr (!GA) { if (g + 1 < NG) loadg(g + 1, 0); }
-			}
+			gather_cubic_groups<P, GG, (OCT_TEAM_GATHER_AHEAD) != 0>(tapA, cwR, wphR, v);
 		} else
 #pragma unroll
 		for (int q = 0; q < P; q++) {
