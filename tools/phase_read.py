@@ -1,11 +1,11 @@
 """Reads the per-phase cycle totals that a library built with tools/experiments/phase_timing.patch leaves in the first floats of the processed
 buffer (timing experiment: s_memtime at the four phase boundaries of oct_fused_kernel, block 7, every wave).
-usage (GPU box): OCTPIPE_LIB=<variant> python tools/phase_read.py"""
+usage (GPU box): OCTPIPE_LIB=<variant> python tools/phase_read.py [N A B]"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from octproz_amd import Pipeline, v180_benchmark_params
 from octproz_amd.virtual_oct import synthetic_raw_torch
-N, A, B = 1024, 512, 256
+N, A, B = (int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (1024, 512, 256)))
 dev = torch.device("cuda", 0)
 vols = [synthetic_raw_torch(N, A, B, dev, seed=7 + i) for i in range(4)]
 p = v180_benchmark_params(N, A, B, buffers_per_volume=4)
