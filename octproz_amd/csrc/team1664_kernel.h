@@ -159,6 +159,9 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 		// ---- k-linearisation x window x dispersion phasor: samples L + 128 q
 		__builtin_amdgcn_s_setprio(3);
 		f2 x[13];
+#ifndef OCT_TEAM1664_READS_FIRST
+#define OCT_TEAM1664_READS_FIRST 1
+#endif
 #ifndef OCT_TEAM1664_GATHER_GROUP
 #define OCT_TEAM1664_GATHER_GROUP 2
 #endif
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 		f2 v[16];
 #pragma unroll
 		for (int t = 0; t < 16; t++) v[t] = rb1[104 * t];
+		if constexpr (OCT_TEAM1664_READS_FIRST != 0) __builtin_amdgcn_sched_barrier(0);  // all sixteen reads before the first product (kernels.h 5.1 (h))
 #pragma unroll
 		for (int t = 1; t < 16; t++) v[t] = octfft::cmul(v[t], tw2[t - 1]);
 		octfft::Dft<16, 1, false>::run(&v[0]);
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 			v[2 * t] = rb2a[TM::X2_PITCH * t];
 			v[2 * t + 1] = rb2b[TM::X2_PITCH * t];
 		}
+		if constexpr (OCT_TEAM1664_READS_FIRST != 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int t = 1; t < 8; t++) {
 			v[2 * t] = octfft::cmul(v[2 * t], tw3[2 * (t - 1)]);
