@@ -327,6 +327,23 @@ __global__ __launch_bounds__(MR_WAVES * 64, 2) void oct_mixed1664_kernel(const F
 		__builtin_amdgcn_s_setprio(2);
 		mr::dft32(v);
 		// ---- stage B: twiddle, transpose through LDS
+		// (the 31 twiddles in groups of OCT_M1664_TW_GROUP: one read, one wait, one product each is a dependent LDS round trip per twiddle -- kernels.h 5.1 (h))
+#ifndef OCT_M1664_TW_GROUP
+#define OCT_M1664_TW_GROUP 8
+#endif
+		if constexpr ((OCT_M1664_TW_GROUP) > 1) {
+			constexpr int TG = OCT_M1664_TW_GROUP;
+#pragma unroll
+			for (int g = 0; g < (N1 - 1 + TG - 1) / TG; g++) {
+				f2 w[TG];
+#pragma unroll
+				for (int i = 0; i < TG; i++) { const int q = 1 + g * TG + i; if (q < N1) w[i] = twB[q * N2 + n2]; }
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int i = 0; i < TG; i++) { const int q = 1 + g * TG + i; if (q < N1) v[q] = octfft::cmul(v[q], w[i]); }
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		} else
 #pragma unroll
 		for (int q = 1; q < N1; q++) v[q] = octfft::cmul(v[q], twB[q * N2 + n2]);
 #pragma unroll
