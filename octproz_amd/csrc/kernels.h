@@ -127,6 +127,12 @@ struct FusedArgs {
 #ifndef OCT_PRIO_STAGING
 #define OCT_PRIO_STAGING 0
 #endif
+#ifndef OCT_PRIO_FFT2
+#define OCT_PRIO_FFT2 1       // N = 1024: passes 2-3 of the transform (-1: no fifth point)
+#endif
+#ifndef OCT_PRIO_EPILOGUE5
+#define OCT_PRIO_EPILOGUE5 0  // N = 1024 with the fifth point: epilogue
+#endif
 #ifndef OCT_MIRROR_AT_STAGING
 #define OCT_MIRROR_AT_STAGING 1
 #endif
@@ -442,7 +448,8 @@ constexpr int pad16c(int j) { return j + OCT_PADK * (j >> 4); }
 #ifndef OCT_TW_LDS_GROUP
 #define OCT_TW_LDS_GROUP 1
 #endif
-template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0, bool REGTW = false, bool REGTW3 = false>
+// PRIO2 >= 0: the wave's priority from behind the exchange reads of this pass on (oct_fused_kernel, N = 1024: see OCT_PRIO_FFT2)
+template <int N, int R, int NS, bool READ, bool WRITE, bool PRUNE, int PACK = 0, bool REGTW = false, bool REGTW3 = false, int PRIO2 = -1>
 OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const f32x4* twr = nullptr) {
 	constexpr int P = N / 64, NB = P / R;
 	static_assert(NB >= 1, "radix larger than points per lane");
@@ -451,6 +458,7 @@ OCT_DEV void fft_pass(f2 (&v)[N / 64], f2* xbuf, const f2* twp, int lane, const 
 #pragma unroll
 		for (int q = 0; q < P; q++) v[q] = rb[(64 + 4 * OCT_PADK) * q];
 		wave_sync_lds();
+		if constexpr (PRIO2 >= 0) __builtin_amdgcn_s_setprio(PRIO2);
 	}
 	if constexpr (PACK == 2) {
 		static_assert(PACK != 2 || (R == 16 && NS == 16 && NB == 1), "packed layout 2");
@@ -649,7 +657,7 @@ template <int LOG2N> OCT_DEV int fft_bin(int lane, int m, int u) {
 	constexpr int N = 1 << LOG2N, RL = LastRadix<LOG2N>::value;
 	return lane + 64 * m + u * (N / RL);
 }
-template <int LOG2N, bool PRUNE, bool REGTW = false, bool REGTW3 = false>
+template <int LOG2N, bool PRUNE, bool REGTW = false, bool REGTW3 = false, int PRIO2 = -1>
 OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int lane, const f32x4* twr = nullptr) {
 	constexpr int N = 1 << LOG2N;
 	typedef Plan<LOG2N> PL;
@@ -694,7 +702,7 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 	if constexpr (PL::PERM) {
 		static_assert(!PL::PERM || (R3 == 1 && R2 == 4 && R1 == 16 && P == 16), "permlane exchange: 16-point lanes, radix 16 then 4");
 		constexpr bool PX = OCT_PERM_EXCHANGE != 0;
-		fft_pass<N, R1, R0, true, !PX, false, 2, REGTW>(v, xbuf, tw, lane, twr);
+		fft_pass<N, R1, R0, true, !PX, false, 2, REGTW, false, PRIO2>(v, xbuf, tw, lane, twr);
 		if constexpr (PX) perm_exchange<P>(v);
 		fft_pass<N, R2, R0 * R1, !PX, false, PRUNE, 3, REGTW, REGTW3>(v, xbuf, tw + 8 * 16 * 2, lane, twr);
 	} else if constexpr (R3 == 1) {
@@ -1244,8 +1252,12 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 
 		// ---- inverse FFT
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_FFT);
-		fft_wave<LOG2N, !SPECTRUM, TW2, TW3>(v, xbuf, tw, lane, tw2R);
-		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_EPILOGUE);
+		// N = 1024: a fifth priority point behind the reads of the transform's one LDS exchange.  Gather 3 > first pass 2 > rest of the
+		// transform 1 > epilogue = staging 0 measured +1.3 % over gather 3 > transform 2 > epilogue 1 > staging 0 (profiles/r5bf_*, r5bg_*):
+		// a wave that is still in front of its exchange beats one that is behind it.
+		constexpr bool P5 = Cfg<LOG2N>::PRIO && LOG2N == 10 && (OCT_PRIO_FFT2) >= 0;
+		fft_wave<LOG2N, !SPECTRUM, TW2, TW3, P5 ? (OCT_PRIO_FFT2) : -1>(v, xbuf, tw, lane, tw2R);
+		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(P5 ? (OCT_PRIO_EPILOGUE5) : (OCT_PRIO_EPILOGUE));
 
 		if constexpr (SPECTRUM) {
 			f2* dst = a.spectrum + (size_t)line * N + lane;
