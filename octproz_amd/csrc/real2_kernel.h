@@ -270,7 +270,14 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 		wave_sync_lds();  // the rows are dead from here on
 
 		__builtin_amdgcn_s_setprio(2);
-		fft_wave<10, false, TW2, TW3>(v, xbuf, tw, lane, twR);  // Z[lane + 64 m + 256 u] in v[m + 4 u], all u
+		// (kernels.h OCT_PRIO_FFT2: the fifth priority point of the complex-input kernel.  Here: cubic +1.7 %, linear -1.2 %, profiles/r5bk_*)
+#ifndef OCT_R2_PRIO_FFT2
+#define OCT_R2_PRIO_FFT2 (RS == RS_CUBIC ? 1 : -1)
+#endif
+#ifndef OCT_R2_PRIO_EPILOGUE
+#define OCT_R2_PRIO_EPILOGUE 1
+#endif
+		fft_wave<10, false, TW2, TW3, OCT_R2_PRIO_FFT2>(v, xbuf, tw, lane, twR);  // Z[lane + 64 m + 256 u] in v[m + 4 u], all u
 
 		// ---- mirror exchange: Z[N - k] of the kept bins k < N/2 comes from the upper half (and Z[0] for k = 0)
 		{
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(real2_waves<RS>() * 64, real2_minw<RS>()) void oct_
 				for (int m = 0; m < 4; m++) v[m + 4 * (u + 2)] = mb[512 - (lane + 64 * m + 256 * u)];  // Z[N - k]
 			wave_sync_lds();
 		}
-		__builtin_amdgcn_s_setprio(1);
+		__builtin_amdgcn_s_setprio(OCT_R2_PRIO_EPILOGUE);
 
 		// ---- combine, mean A-line subtraction, |.|^2, log / lin scaling, two output rows
 		const unsigned line0 = 2u * pi;
