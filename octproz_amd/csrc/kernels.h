@@ -1135,6 +1135,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		// the reads of the next group before the sums of the current one.  Sample by sample (group 1, what hipcc makes of the plain loop at a
 		// register budget this tight: two reads, wait, two FMAs, wait, two FMAs) a wave pays one LDS round trip per sample, 16 in a row.
 #ifdef OCT_GATHER_GROUP
+#ifndef OCT_GATHER_AHEAD
+#define OCT_GATHER_AHEAD 0
+#endif
 		constexpr int GGW = OCT_GATHER_GROUP;
 		constexpr bool AHEAD = (OCT_GATHER_AHEAD) != 0;
 #else
