@@ -38,6 +38,7 @@ enum {
 	OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT = 2048, /* creation: the run-time compiled kernel with its first plan order and exchange layout (largest radix first, always padded) */
 	OCTPIPE_ROUTE_TINY_GRID = 1024,    /* the run-time compiled kernel and the general fused kernel on TWO persistent workgroups: every wave loops over many A-scans even of a small test buffer */
 	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256, /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
+	OCTPIPE_ROUTE_NO_FUSED_SINUS = 8192, /* sinusoidal scan correction always as the post pass (cu:1551-1554 as one gather pass), never inside the general fused kernel's image store (MODE_SINUS) */
 	OCTPIPE_ROUTE_FUSED_DISPLAY = 4096 /* display frames (one frame per view) written by the general fused kernel's image store (MODE_DISP) instead of by oct_display_frames_kernel.
 	                                      Opt-in: bit-identical frames, one launch per buffer instead of two, but not faster -- the store side costs the kernel what the extraction kernel
 	                                      cost (profiles/r5b..r5f_*_ab.txt) */
@@ -65,7 +66,8 @@ enum {
 	OCTPIPE_PATH_MIXED_RADIX   = 64,  /* mixed1664.h / mixed1664_real2.h, mixedn_kernel.h */
 	OCTPIPE_PATH_BLUESTEIN     = 128,
 	OCTPIPE_PATH_STATIC_PLAN   = 256, /* with MIXED_RADIX: the kernel compiled for this length (mixedn_static.h) instead of the run-time plan */
-	OCTPIPE_PATH_FUSED_DISPLAY = 512  /* the display frames (one frame per view) written by the image store of the fused kernel */
+	OCTPIPE_PATH_FUSED_DISPLAY = 512, /* the display frames (one frame per view) written by the image store of the fused kernel */
+	OCTPIPE_PATH_FUSED_SINUS   = 1024 /* sinusoidal scan correction inside the image store of the fused kernel (no scratch slot, no post pass) */
 };
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
 /* The same decision WITHOUT a device (csrc/route.h: derive_route_facts + choose_route, the pure functions octpipe_debug_create and
@@ -76,6 +78,13 @@ int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
  * the mean-line estimate instead of the image launch.  tests/test_route.py holds the routing table against it in the CPU suite. */
 int octpipe_debug_route(const OctPipeAcquisitionParams* acq, const OctPipeParams* params, int sampleFormat, unsigned routeFlags, int assumeFftLibrary, int assumeRtc,
                         int spectrum, unsigned* path, int* kind, int* intype, int* preparedRollW);
+
+/* The work list of the sinusoidal scan correction inside the fused kernel's store (csrc/sinus_plan.h) for `ascansPerBscan`, without a
+ * device: *entries = rows of a B-scan the store needs (0: no plan for this B-scan width, the correction stays the post pass); when
+ * `out` is not NULL and holds at least 4 x capacityEntries words, the entries {row | firstOutput << 16, frac0, frac1, 0}. */
+int octpipe_debug_sinus_plan(unsigned ascansPerBscan, unsigned* entries, uint32_t* out, size_t capacityEntries);
+/* MODE_SINUS: blocks of the work list per wave (0 = the library's default); takes effect with the next buffer */
+int octpipe_debug_set_sinus_blocks_per_wave(octpipe_t* h, unsigned blocksPerWave);
 
 /* Lengths without a dedicated kernel run a kernel compiled for them at run time (hiprtc; csrc/mixedn_rtc.hip).  Status: whether
  * the handle's length does (h may be NULL), its plan (five radices, 0 = unused), how many instances the process has compiled, the

@@ -11,11 +11,11 @@ LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")
 
 OCTPIPE_OK = 0
 # OCTPIPE_ROUTE_* (include/octpipe_debug.h, octpipe_debug_set_route / octpipe_debug_create): keep a configuration on the slower / more general of two routes
-ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED, ROUTE_NO_MIXEDN, ROUTE_MIXEDN_SIMPLE_RADICES, ROUTE_NO_MIXEDN_STATIC, ROUTE_TINY_GRID, ROUTE_MIXEDN_STATIC_OLD_LAYOUT, ROUTE_FUSED_DISPLAY = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
+ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED, ROUTE_NO_MIXEDN, ROUTE_MIXEDN_SIMPLE_RADICES, ROUTE_NO_MIXEDN_STATIC, ROUTE_TINY_GRID, ROUTE_MIXEDN_STATIC_OLD_LAYOUT, ROUTE_FUSED_DISPLAY, ROUTE_NO_FUSED_SINUS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192
 # octpipe_debug_last_path (include/octpipe_debug.h OCTPIPE_PATH_*)
 # octpipe_group_create_ex flags (include/octpipe.h)
 GROUP_PLACE_RING_SLABS, GROUP_NO_SUBMIT_THREADS, GROUP_SUBMIT_THREADS = 1, 2, 4
-PATH_PREPARED_ROWS, PATH_FUSED_BG, PATH_TEAM, PATH_REAL_INPUT, PATH_LIBRARY_FFT, PATH_ROLL_IN_KERNEL, PATH_MIXED_RADIX, PATH_BLUESTEIN, PATH_STATIC_PLAN, PATH_FUSED_DISPLAY = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+PATH_PREPARED_ROWS, PATH_FUSED_BG, PATH_TEAM, PATH_REAL_INPUT, PATH_LIBRARY_FFT, PATH_ROLL_IN_KERNEL, PATH_MIXED_RADIX, PATH_BLUESTEIN, PATH_STATIC_PLAN, PATH_FUSED_DISPLAY, PATH_FUSED_SINUS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NOT_INITIALIZED", 3: "OUT_OF_MEMORY", 4: "DEVICE", 5: "UNSUPPORTED", 6: "NO_DEVICE", 7: "IN_CALLBACK"}
 # handles whose Python object was finalised on a pipeline callback thread (the garbage collector runs wherever an allocation
 # happens): destroying them there is refused by the library (OCTPIPE_ERR_IN_CALLBACK); they are destroyed by the next call of
@@ -137,6 +137,7 @@ OCTPIPE_SYMBOLS = [
 OCTPIPE_DEBUG_SYMBOLS = [
     "octpipe_debug_spectrum", "octpipe_debug_unpack", "octpipe_debug_force_prepared", "octpipe_debug_set_route", "octpipe_debug_create",
     "octpipe_debug_read_raw_slot", "octpipe_debug_last_grid", "octpipe_debug_last_path", "octpipe_debug_rtc_status", "octpipe_debug_rtc_compile", "octpipe_debug_rtc_set_options", "octpipe_debug_rtc_disk_hits", "octpipe_debug_route", "octpipe_debug_rtc_wait_idle",
+    "octpipe_debug_sinus_plan", "octpipe_debug_set_sinus_blocks_per_wave",
 ]
 OCTHOST_SYMBOLS = [
     "octhost_buffer_create", "octhost_buffer_destroy", "octhost_buffer_allocate", "octhost_buffer_release",

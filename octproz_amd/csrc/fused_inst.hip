@@ -13,6 +13,12 @@
 #error "compile with -DOCT_LOG2N=<8..12>"
 #endif
 
+// MODE_SINUS: blocks of the work list per wave (more blocks: a wave's rows spread over the buffer like the plain kernel's; fewer: less
+// recomputed halo rows)
+#ifndef OCT_SINUS_BLOCKS_PER_WAVE
+#define OCT_SINUS_BLOCKS_PER_WAVE 2
+#endif
+
 namespace oct {
 
 namespace {
@@ -25,14 +31,31 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 	constexpr bool kRoll = (MODE & MODE_ROLL) != 0;
 	constexpr int waves = KCfg<kLog2N, RS, kRoll>::WAVES;
 	constexpr int threads = waves * 64;
-	constexpr size_t lds = block_lds_bytes<kLog2N, RS, kRoll>() + bg_lds_bytes<MODE, kN>();
+	constexpr size_t lds = block_lds_bytes<kLog2N, RS, kRoll>() + bg_lds_bytes<MODE, kN>() + sinus_lds_bytes<MODE, kLog2N, RS>();
 	static_assert(lds <= 160 * 1024, "LDS budget of a CU");
 	KernelLaunchInfo info;
 	hipError_t e = kernel_launch_info(kernel, threads, lds, &info);
 	if (e != hipSuccess) return e;
 	const int blocksPerCU = info.blocksPerCU, numCU = info.numCU;
-	const unsigned need = (a.numLines + waves - 1) / waves;
 	unsigned blocks = requestedBlocks > 0 ? (unsigned)requestedBlocks : (unsigned)(numCU * blocksPerCU);
+	if constexpr ((MODE & MODE_SINUS) != 0) {
+		// the work list of the buffer (sinTotal entries, sinus_plan.h) in blocks of sinBlk + 1 entries, neighbours sharing one: as many
+		// blocks per wave as FusedArgs::sinBlk asks for on entry (0: the default), at most 64 entries per block (one per lane)
+		if (a.sinTotal < 2 || a.sinM == 0 || a.sinEnt == nullptr) return hipErrorInvalidValue;
+		FusedArgs s = a;
+		const unsigned pairs = a.sinTotal - 1u, perWave = a.sinBlk ? a.sinBlk : (unsigned)OCT_SINUS_BLOCKS_PER_WAVE;
+		const unsigned wavesAll = blocks * (unsigned)waves;
+		unsigned len = (pairs + perWave * wavesAll - 1u) / (perWave * wavesAll);
+		if (len < 8u) len = pairs < 8u ? pairs : 8u;
+		if (len > 63u) len = 63u;
+		s.sinBlk = len;
+		const unsigned listBlocks = (pairs + len - 1u) / len, need = (listBlocks + waves - 1) / waves;
+		if (blocks > need) blocks = need;
+		if (blocksUsed) *blocksUsed = (int)blocks;
+		launch_fused_args(kernel, dim3(blocks), dim3(threads), lds, stream, s);
+		return hipGetLastError();
+	}
+	const unsigned need = (a.numLines + waves - 1) / waves;
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
 	if (blocksUsed) *blocksUsed = (int)blocks;
@@ -44,6 +67,17 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 template <int INTYPE, int RS, int ROLLBIT>
 hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, hipStream_t st, int* bu) {
 	if (spectrum) return launch_one<INTYPE, RS, ROLLBIT | MODE_SPECTRUM>(a, rb, st, bu);
+	// sinusoidal scan correction inside the image store (a.sinEnt set; MODE_SINUS): raw uint16 rows, N <= 2048, not with Lanczos
+	if (a.sinEnt) {
+		// (route.h asks for it where these hold; the cubic rolling-average variants of N = 512 and 2048 would spill registers)
+		if constexpr (INTYPE == IN_U16 && RS != RS_LANCZOS && kLog2N <= 11 && !(ROLLBIT != 0 && RS == RS_CUBIC && (kLog2N == 9 || kLog2N == 11))) {
+			if (a.dispBscan || a.dispEnFace) return hipErrorInvalidValue;
+			if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_BG | MODE_SINUS>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_BG | MODE_SINUS>(a, rb, st, bu);
+			return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_SINUS>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_SINUS>(a, rb, st, bu);
+		} else {
+			return hipErrorInvalidValue;
+		}
+	}
 	// post-process background removal inside the image store (a.bgTerm set): every container, with or without the in-kernel
 	// rolling average
 	// display frames written by the image store (a.dispBscan / a.dispEnFace set: one frame each, cu:810-912 with displayFunctionFrames <= 1)

@@ -63,6 +63,14 @@ struct FusedArgs {
 	unsigned dispBscanRow0;  // buffer-local output row of the first A-scan of the displayed B-scan; beyond the buffer: it lies in another buffer of the volume
 	unsigned dispEnFaceBin;
 	unsigned dispEnFaceLast;
+	// MODE_SINUS: the sinusoidal scan correction (cu:491-514) inside the image store (round 6).  Output A-scan a of a B-scan is
+	// f0 + (f1 - f0) frac of the (flipped) rows floor(s[a]) and floor(s[a]) + 1 of the SAME B-scan, s monotone: the rows a B-scan needs,
+	// in ascending order, are the work list of every B-scan (sinus_plan.h).  Entry i = {p | aStart << 16, frac0, frac1, 0}: row p; if
+	// frac0 >= 0 the pair (p - 1, p) produces output A-scan aStart with frac0 and, if frac1 >= 0, aStart + 1 with frac1.
+	// sinTotal = B-scans x sinM entries are cut into blocks of sinBlk + 1 consecutive entries (one shared with the next block); a wave
+	// walks its blocks, keeps the previous row's grey values and writes the blended A-scans of every pair it completes.
+	const uint32_t* sinEnt;  // [sinM][4]
+	unsigned sinM, sinTotal, sinBlk;
 };
 
 // Per-length launch shape.  WAVES = A-scans in flight per workgroup; all waves of a workgroup share
@@ -763,7 +771,23 @@ template <bool> OCT_DEV void ef_flush(const FusedArgs& a, float acc, unsigned fi
 }
 
 // MODE bits of the kernel template
-enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4, MODE_BG = 8, MODE_DISP = 16 };
+enum { MODE_ROLL = 1, MODE_SPECTRUM = 2, MODE_LOG = 4, MODE_BG = 8, MODE_DISP = 16, MODE_SINUS = 32 };
+// MODE_SINUS keeps the previous row's N/2 grey values of a wave in LDS (behind the workgroup's other tables) where the CU has room for
+// them (every variant up to N = 1024 but the rolling-average ones of N = 1024 without cubic weights, 12 waves; none at N = 2048): in
+// registers otherwise
+template <int MODE, int LOG2N, int RS> constexpr int sinus_lds_bytes() {
+	constexpr bool ROLL = (MODE & MODE_ROLL) != 0;
+	constexpr int want = KCfg<LOG2N, RS, ROLL>::WAVES * (1 << LOG2N) * 2;
+	return (MODE & MODE_SINUS) != 0 && block_lds_bytes<LOG2N, RS, ROLL>() + bg_lds_bytes<MODE, (1 << LOG2N)>() + want <= 160 * 1024 ? want : 0;
+}
+template <int MODE, int LOG2N, int RS> constexpr bool sinus_prev_lds() { return sinus_lds_bytes<MODE, LOG2N, RS>() > 0; }
+// cu:506-510 in the reference's operation order, never contracted: the blend is held bit for bit against the oracle
+OCT_DEV float sinus_blend(float f0, float f1, float frac) {
+#pragma clang fp contract(off)
+	const float d = f1 - f0;
+	const float t = d * frac;
+	return f0 + t;
+}
 
 // INTYPE: IN_U16 (raw, the hot configuration) or IN_F32 (samples prepared by oct_prepare_kernel:
 // uint8 / uint32 input and everything in front of the Lanczos variant).
@@ -778,6 +802,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	constexpr bool REGLIN = KCfg<LOG2N, RS, (MODE & 1) != 0>::REGLIN && RS != RS_LANCZOS;
 	constexpr int RL = LastRadix<LOG2N>::value, NBL = P / RL;
 	constexpr bool ROLL = (MODE & MODE_ROLL) != 0, SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
+	constexpr bool SINUS = (MODE & MODE_SINUS) != 0;
+	static_assert(!(SINUS && (SPECTRUM || (MODE & MODE_DISP) != 0 || RS == RS_LANCZOS)), "sinusoidal correction in the store: image output of the raw-row variants, display frames by the extraction kernel");
 	typedef Chunk<INTYPE, N> CH;
 	constexpr int SPL = CH::SPL, CB = CH::BYTES, NL = N / (64 * SPL);
 	static_assert(!(RS == RS_LANCZOS && INTYPE != IN_F32 && INTYPE != IN_U16), "Lanczos: prepared float buffer or raw uint16 rows");
@@ -801,6 +827,13 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 
 	// tables -> LDS, once per (persistent) workgroup
 	const float* termL = reinterpret_cast<const float*>(smem + block_lds_bytes<LOG2N, RS, ROLL>());
+	constexpr bool SINUS_PREV_LDS = sinus_prev_lds<MODE, LOG2N, RS>();
+	float* sPrevL = reinterpret_cast<float*>(smem + block_lds_bytes<LOG2N, RS, ROLL>() + bg_lds_bytes<MODE, N>()) + wave * (N / 2);
+	float sPrevR[SINUS && !SINUS_PREV_LDS ? P / 2 : 1];
+	if constexpr (SINUS && !SINUS_PREV_LDS) {
+#pragma unroll
+		for (int i = 0; i < P / 2; i++) sPrevR[i] = 0.0f;
+	}
 	if constexpr ((MODE & MODE_BG) != 0) fill_bg_term(reinterpret_cast<float*>(smem + block_lds_bytes<LOG2N, RS, ROLL>()), a.bgTerm, N / 2, tid, THREADS);
 	fill_twiddles<LOG2N>(tw, a.twiddle, tid, THREADS);
 	if constexpr (LZ_LDS) {
@@ -850,6 +883,39 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	if (OCT_XCD_REMAP != 0 && (gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
 	unsigned line = (blk * (unsigned)WAVES + (unsigned)wave) * BLK;
 	unsigned inBlock = 0;  // position of `line` inside its block
+	// MODE_SINUS: the wave's walk over the work list (FusedArgs::sinEnt; everything here is wave-uniform and lives in scalar registers).
+	// sBlk: the wave's block; sT / sTEnd: position in it and its last position.  Entries are read with scalar loads through the constant
+	// address space, two A-scans ahead of their use: sE0 = the entry of the row being processed (its pair is written by the epilogue),
+	// sE1 = the next one (its raw row is prefetched while this row is staged), sE2 = in flight.  sI2: index of sE2's entry in the list;
+	// (sBA, sBB, sFl): first row, number and flip rule of the B-scan of sE1's entry, sBA0 of sE0's.
+	typedef const __attribute__((address_space(4))) u32x4 sin_ent_t;
+	sin_ent_t* sinE = reinterpret_cast<sin_ent_t*>(reinterpret_cast<uintptr_t>(a.sinEnt));
+	unsigned sBlk = 0, sT = 0, sTEnd = 0, sI2 = 0, sBA = 0, sBA0 = 0, sBB = 0, sNext = 0xFFFFFFFFu;
+	bool sFl = false;
+	u32x4 sE0 = u32x4{0u, 0u, 0u, 0u}, sE1 = sE0, sE2 = sE0;
+	auto sin_flip = [&](unsigned bb) -> bool { return a.flip && (bb & 1u) == 0u && (bb + 2u) * a.ascansPerBscan <= a.linesInBuffer; };  // (flipped_row's rule)
+	auto sin_row = [&](unsigned ba, bool fl, uint32_t x) -> unsigned { const unsigned pp = x & 0xffffu; return ba + (fl ? a.ascansPerBscan - 1u - pp : pp); };
+	auto sin_wrap = [&](unsigned i) -> unsigned { return i + 1u == a.sinM ? 0u : i + 1u; };
+	// the first entry of block sBlk -> `line`, the following two entries under way (one exposed scalar round trip per BLOCK)
+	auto sin_enter_block = [&]() {
+		const unsigned g0 = sBlk * a.sinBlk, last = a.sinTotal - 1u;
+		sTEnd = min(a.sinBlk, last - g0);
+		sT = 0;
+		const unsigned bb = g0 / a.sinM, i0 = g0 - bb * a.sinM, i1 = sin_wrap(i0);
+		sE0 = sinE[i0];
+		sE1 = sinE[i1];
+		sI2 = sin_wrap(i1);
+		sBA0 = bb * a.ascansPerBscan;
+		line = sin_row(sBA0, sin_flip(bb), sE0.x);
+		sBB = i1 == 0u ? bb + 1u : bb;
+		sBA = sBB * a.ascansPerBscan;
+		sFl = sin_flip(sBB);
+	};
+	if constexpr (SINUS) {
+		sBlk = blk * (unsigned)WAVES + (unsigned)wave;
+		if (sBlk * a.sinBlk + 1u < a.sinTotal) sin_enter_block();
+		else line = 0xFFFFFFFFu;
+	}
 	// the A-scan this wave processes after `ln` (>= numLines: none)
 	auto next_line = [&](unsigned ln, unsigned pos) -> unsigned {
 		if (BLK > 1u && pos + 1u < BLK) return ln + 1u;   // (beyond the buffer only in the buffer's last block: nothing follows it)
@@ -868,6 +934,34 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
 		}
 	}
+	// the step to the wave's next A-scan.  MODE_SINUS: the next entry of the block; behind the block's last entry the wave's next block
+	// (its entries and its first raw row are fetched here, one exposed round trip each per BLOCK)
+	auto advance = [&]() {
+		if constexpr (SINUS) {
+			if (sT < sTEnd) {
+				sT++;
+				line = sNext;
+				sE0 = sE1; sBA0 = sBA;
+				sE1 = sE2;
+				// (sE1 is now the entry at list index sI2: index 0 is the first row of the next B-scan)
+				if (sI2 == 0u) { sBB++; sBA += a.ascansPerBscan; sFl = sin_flip(sBB); }
+				sI2 = sin_wrap(sI2);
+			} else {
+				sBlk += wavesTotal;
+				if (sBlk * a.sinBlk + 1u < a.sinTotal) {
+					sin_enter_block();
+					const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
+#pragma unroll
+					for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
+				} else {
+					line = 0xFFFFFFFFu;
+				}
+			}
+		} else {
+			line = next_line(line, inBlock);
+			inBlock = (inBlock + 1u == BLK) ? 0u : inBlock + 1u;
+		}
+	};
 	// the bins a lane finishes are the same for every A-scan it processes: its mean-line entries stay in registers
 	f2 mreg[MEAN_REGS && !SPECTRUM ? P / 2 : 1];
 	if constexpr (MEAN_REGS && !SPECTRUM) {
@@ -905,7 +999,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 	}
 	// the last pass' twiddles too where the register budget allows (plain uint16 kernel: 249 VGPRs, no spill)
-	constexpr bool TW3 = (REGTAB || REGLIN) && LOG2N == 10 && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32;
+	// (MODE_SINUS: the block's four entry registers and the blend's temporaries take their place -- 7 spilled registers otherwise)
+	constexpr bool TW3 = (REGTAB || REGLIN) && LOG2N == 10 && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32 && !(SINUS && REGTAB);
 	constexpr bool TW2 = (REGTAB || REGLIN) && LOG2N == 10 && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
 	f32x4 tw2R[TW2 ? (TW3 ? 14 : 8) : 1];
 	if constexpr (REGTAB) {
@@ -952,7 +1047,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// prefetched row is guarded for "four loads pending" (the state at loop entry) although eight stores of the previous A-scan
 	// have followed those loads in every later iteration -- vmcnt(3) instead of vmcnt(11), i.e. a wait for stores issued a moment ago.
 	prologue_wait();
-	for (; line < lineEnd; line = next_line(line, inBlock), inBlock = (inBlock + 1u == BLK) ? 0u : inBlock + 1u) {
+	while (line < lineEnd) {
+		if constexpr (SINUS) sE2 = sinE[sI2];  // (two A-scans ahead of its use)
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
 			bool staged = false;
@@ -1059,7 +1155,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					}
 				}
 			}
-			const unsigned next = next_line(line, inBlock);  // prefetch the next row of this wave
+			unsigned next;  // prefetch the next row of this wave
+			if constexpr (SINUS) { next = sT < sTEnd ? sin_row(sBA, sFl, sE1.x) : 0xFFFFFFFFu; sNext = next; }
+			else next = next_line(line, inBlock);
 			if (next < lineEnd) {
 				const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
 #pragma unroll
@@ -1271,9 +1369,28 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		} else {
 			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
 			unsigned orow = line;  // output row; only the flip needs the (B-scan, A-scan) split of the line index
-			if (a.flip) orow = flipped_row(a, line);
+			if constexpr (SINUS) orow = sBA0 + (sE0.x >> 16);  // (the first output A-scan of the pair this row completes)
+			else if (a.flip) orow = flipped_row(a, line);
 			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
 			constexpr bool BG = (MODE & MODE_BG) != 0;
+			// MODE_SINUS: what the entry of this row says (wave-uniform): the output rows of the pair (previous row, this row) and their
+			// blend fractions; nothing for the first entry of a block (the previous block wrote that pair)
+			unsigned sRow0 = 0;
+			float sF0 = 0.0f, sF1 = 0.0f;
+			bool sSt0 = false, sSt1 = false, sRaw = false;
+			__amdgpu_buffer_rsrc_t outR1 = outR, outRL = outR;
+			if constexpr (SINUS) {
+				sF0 = __builtin_bit_cast(float, sE0.y);
+				sF1 = __builtin_bit_cast(float, sE0.z);
+				sRow0 = orow;
+				sRaw = sBA0 + (sE0.x & 0xffffu) + 1u == a.linesInBuffer;
+				const bool pair = sT > 0u && sF0 >= 0.0f;
+				// (the reference's launch bound `i + width < samples`: the buffer's last A-scan is never a blended one)
+				sSt0 = pair && sRow0 + 1u != a.linesInBuffer;
+				sSt1 = pair && sF1 >= 0.0f && sRow0 + 2u != a.linesInBuffer;
+				outR1 = make_rsrc(a.out + (size_t)(sRow0 + 1u) * (N / 2), N * 2u);
+				outRL = make_rsrc(a.out + (size_t)(a.linesInBuffer - 1u) * (N / 2), N * 2u);
+			}
 			const f2* ml = meanL + lane;
 			// MODE_DISP, B-scan frame (cu:858): the rows of the displayed B-scan go out a second time, both axes reversed -- row r of
 			// the B-scan is row A - 1 - r of the frame, bin k its element N/2 - 1 - k: lane part (63 - lane), constant part >= 0
@@ -1299,6 +1416,44 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
 					o[m] = a.sA * s + a.sB;
 				}
+				if constexpr (SINUS) {
+					// the previous row's values of these bins <-> this row's; the blended A-scans of the pair (cu:506-510), then
+					// (MODE_BG) the removal that follows the correction in the reference's chain (cu:1557-1568)
+					float pv[NBL];
+					if constexpr (SINUS_PREV_LDS) {
+						if constexpr (NBL % 4 == 0) {
+#pragma unroll
+							for (int m4 = 0; m4 < NBL / 4; m4++) {
+								f32x4* q = reinterpret_cast<f32x4*>(sPrevL) + ((u * (NBL / 4) + m4) * 64 + lane);
+								const f32x4 t = *q;
+								*q = f32x4{o[4 * m4], o[4 * m4 + 1], o[4 * m4 + 2], o[4 * m4 + 3]};
+								pv[4 * m4] = t.x; pv[4 * m4 + 1] = t.y; pv[4 * m4 + 2] = t.z; pv[4 * m4 + 3] = t.w;
+							}
+						} else {
+#pragma unroll
+							for (int m = 0; m < NBL; m++) {
+								float* q = sPrevL + ((m + u * NBL) * 64 + lane);
+								pv[m] = *q;
+								*q = o[m];
+							}
+						}
+					} else {
+#pragma unroll
+						for (int m = 0; m < NBL; m++) { pv[m] = sPrevR[m + u * NBL]; sPrevR[m + u * NBL] = o[m]; }
+					}
+					if (sSt0) {
+#pragma unroll
+						for (int m = 0; m < NBL; m++) store_image<BG>(sinus_blend(pv[m], o[m], sF0), outR, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
+					}
+					if (sSt1) {
+#pragma unroll
+						for (int m = 0; m < NBL; m++) store_image<BG>(sinus_blend(pv[m], o[m], sF1), outR1, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
+					}
+					if (sRaw) {
+#pragma unroll
+						for (int m = 0; m < NBL; m++) store_image<BG>(o[m], outRL, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
+					}
+				} else
 #pragma unroll
 				for (int m = 0; m < NBL; m++) {
 					o[m] = store_image<BG>(o[m], outR, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
@@ -1333,6 +1488,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_STAGING);
 		wave_sync_lds();
+		advance();
 	}
 	if constexpr (DISP) {
 		if (a.dispEnFace && efCount) ef_flush<true>(a, efAcc, efFirst, 1u, lane, efCount);  // (the ragged last block of the buffer)

@@ -281,11 +281,16 @@ oct::RouteFacts routeFacts(const octpipe* h) {
 	return f;
 }
 
+// the plan of the IMAGE launch of a buffer with the handle's current settings (processDeviceRaw asks before it picks the destination)
+oct::RoutePlan imagePlan(const octpipe* h, bool wantBg, const DispFold* wantDisp) {
+	return oct::choose_route(routeFacts(h), h->params, false, wantBg, wantDisp != nullptr, wantDisp && wantDisp->bgPostPassFollowsUnlessFused, h->d_sinusEnt != nullptr);
+}
+
 int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt, bool wantBg = false,
                 bool* bgApplied = nullptr, const DispFold* wantDisp = nullptr, bool* dispApplied = nullptr) {
 	const OctPipeParams& p = h->params;
 	// WHICH implementation: route.h (a pure function of the handle's facts and the parameter snapshot; tests/test_route.py)
-	const oct::RoutePlan plan = oct::choose_route(routeFacts(h), p, spectrum, wantBg, wantDisp != nullptr, wantDisp && wantDisp->bgPostPassFollowsUnlessFused);
+	const oct::RoutePlan plan = oct::choose_route(routeFacts(h), p, spectrum, wantBg, wantDisp != nullptr, wantDisp && wantDisp->bgPostPassFollowsUnlessFused, h->d_sinusEnt != nullptr);
 	if (plan.error) return fail(OCTPIPE_ERR_UNSUPPORTED, plan.error);
 	oct::FusedArgs a{};
 	const int intype = plan.intype, rs = plan.rs;
@@ -309,6 +314,12 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 			h->bgTermVersion = h->bgVersion; h->bgTermWeight = p.postProcessBackgroundWeight; h->bgTermOffset = p.postProcessBackgroundOffset;
 		}
 		a.bgTerm = h->d_bgTerm;
+	}
+	if (plan.sinusFused) {  // (the caller has handed the volume slot itself as `out`: imagePlan)
+		a.sinEnt = h->d_sinusEnt;
+		a.sinM = h->sinusM;
+		a.sinTotal = h->sinusM * (unsigned)h->B;
+		a.sinBlk = h->sinusBlocksPerWave;  // (the launcher turns blocks per wave into entries per block)
 	}
 	if (plan.dispFused) {
 		a.dispBscan = wantDisp->bscan; a.dispEnFace = wantDisp->enface;
@@ -569,14 +580,18 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 
 	// with the sinusoidal correction on, the fused kernel writes a scratch slot and the post pass gathers from it into the
 	// volume (cu:1551-1554 copies the buffer device-to-device and runs a second pass instead)
+	// Round 6: where the general fused kernel runs the buffer, the correction happens inside its image store (MODE_SINUS, sinus_plan.h)
+	// and the kernel writes the volume slot itself -- no scratch slot, no second pass.
 	float* d_fusedOut = d_curr;
 	int rc;
-	if (p.sinusoidalScanCorrection) {
+	bool bgRemoval = p.postProcessBackgroundRemoval != 0;
+	const bool wantBgInStore = bgRemoval && !p.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG);
+	bool sinus = p.sinusoidalScanCorrection != 0;  // from here on: "the post pass has to apply the correction"
+	if (sinus && imagePlan(h, wantBgInStore, nullptr).sinusFused) sinus = false;
+	if (sinus) {
 		if ((rc = ensure(h, (void**)&h->d_sinusTmp, sizeof(float) * (S / 2)))) return rc;
 		d_fusedOut = h->d_sinusTmp;
 	}
-	const bool sinus = p.sinusoidalScanCorrection != 0;
-	bool bgRemoval = p.postProcessBackgroundRemoval != 0;
 	// the removal commutes with everything but the sinusoidal correction (a blend of two A-scans in front of the clamp) and has
 	// to follow a recording requested for this very buffer: otherwise it rides on the fused kernel's store
 	bool bgFused = false;
@@ -593,7 +608,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	const int modeB = oct::display_mode(p.functionFramesBscan, p.displayFunctionBscan), modeE = oct::display_mode(p.functionFramesEnFaceView, p.displayFunctionEnFaceView);
 	DispFold fold{};
 	bool foldAsked = false, dispFused = false;
-	if (wantViews && !sinus && (h->route & OCTPIPE_ROUTE_FUSED_DISPLAY) && !(h->route & OCTPIPE_ROUTE_FULL_DISPLAY) &&
+	if (wantViews && !p.sinusoidalScanCorrection && (h->route & OCTPIPE_ROUTE_FUSED_DISPLAY) && !(h->route & OCTPIPE_ROUTE_FULL_DISPLAY) &&
 	    (!p.bscanViewEnabled || modeB == oct::DISP_SINGLE) && (!p.enFaceViewEnabled || modeE == oct::DISP_SINGLE) &&
 	    !(bgRemoval && p.postProcessBackgroundRecordingRequested)) {
 		const unsigned BV = (unsigned)B * h->acq.buffersPerVolume, W = (unsigned)(N / 2), slot = h->bufferNumberInVolume;
@@ -609,8 +624,7 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 		fold.bgPostPassFollowsUnlessFused = bgRemoval;
 		foldAsked = fold.bscan || fold.enface;
 	}
-	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true,
-	                      bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG), &bgFused,
+	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true, wantBgInStore, &bgFused,
 	                      foldAsked ? &fold : nullptr, &dispFused))) return rc;
 	if (bgFused) bgRemoval = false;
 
@@ -882,6 +896,13 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 		std::vector<float> sc((size_t)h->A);
 		octhost::sinusoidal_curve((unsigned)h->A, sc.data());
 		if ((rc = uploadSync(h, h->d_sinusCurve, sc.data(), sizeof(float) * sc.size()))) return rc;
+		// ... and, where the curve allows it, the work list of the correction inside the fused kernel's store (sinus_plan.h)
+		const oct::SinusPlan sp = oct::build_sinus_plan((unsigned)h->A, sc.data());
+		if (sp.ok) {
+			if ((rc = ensure(h, (void**)&h->d_sinusEnt, sizeof(uint32_t) * sp.ent.size()))) return rc;
+			if ((rc = uploadSync(h, h->d_sinusEnt, sp.ent.data(), sizeof(uint32_t) * sp.ent.size()))) return rc;
+			h->sinusM = sp.entries;
+		}
 	}
 	// ring slots: pinned here, unpinned in octpipe_destroy (cu:1135-1136, 1200-1207)
 	void* hb[2] = {h_buffer1, h_buffer2};
@@ -919,7 +940,7 @@ int octpipe_destroy(octpipe_t* h) {
 	octpipe_unregister_streaming_buffers(h);
 	octpipe_unregister_float_streaming_buffers(h);
 	void* bufs[] = {h->d_prepared, h->d_processed, h->d_processedAlt, h->d_sinusTmp, h->d_output, h->d_lut, h->d_twiddle, h->d_meanLine,
-	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW, h->d_twMixedN, h->d_twMixedStatic, h->d_cubicW};
+	                h->d_postBg, h->d_bgTerm, h->d_sinusCurve, h->d_sinusEnt, h->d_spectrum, h->d_segs, h->d_dispBscan, h->d_dispEnFace, h->d_volumeView, h->d_filter, h->d_outChirp, h->d_lutPlain, h->d_twMixed, h->d_twTeam, h->d_lanczosW, h->d_twMixedN, h->d_twMixedStatic, h->d_cubicW};
 	for (void* b : bufs) if (b) hipFree(b);
 	// the (drained) streams of the handle go to the idle list of the device; the next handle created there takes them over
 	if (h->stream && h->ownStream && h->copyStream && h->outStream) {
@@ -1153,17 +1174,41 @@ int octpipe_debug_route(const OctPipeAcquisitionParams* acq, const OctPipeParams
 	if (rc) return fail(rc, why);
 	const OctPipeParams& p = *params;
 	const bool sinus = p.sinusoidalScanCorrection != 0, bgRemoval = p.postProcessBackgroundRemoval != 0;
-	const bool wantBg = bgRemoval && !sinus && !p.postProcessBackgroundRecordingRequested && !(routeFlags & OCTPIPE_ROUTE_NO_FUSED_BG);
+	const bool wantBg = bgRemoval && !p.postProcessBackgroundRecordingRequested && !(routeFlags & OCTPIPE_ROUTE_NO_FUSED_BG);
 	const int modeB = oct::display_mode(p.functionFramesBscan, p.displayFunctionBscan), modeE = oct::display_mode(p.functionFramesEnFaceView, p.displayFunctionEnFaceView);
 	const bool wantDisp = (p.bscanViewEnabled || p.enFaceViewEnabled) && !sinus && (routeFlags & OCTPIPE_ROUTE_FUSED_DISPLAY) && !(routeFlags & OCTPIPE_ROUTE_FULL_DISPLAY) &&
 	                      (!p.bscanViewEnabled || modeB == oct::DISP_SINGLE) && (!p.enFaceViewEnabled || modeE == oct::DISP_SINGLE) &&
 	                      !(bgRemoval && p.postProcessBackgroundRecordingRequested);
-	const oct::RoutePlan plan = oct::choose_route(f, p, spectrum != 0, spectrum ? false : wantBg, spectrum ? false : wantDisp, bgRemoval);
+	bool sinusPlan = false;
+	if (sinus) {
+		std::vector<float> sc((size_t)acq->ascansPerBscan);
+		octhost::sinusoidal_curve(acq->ascansPerBscan, sc.data());
+		sinusPlan = oct::build_sinus_plan(acq->ascansPerBscan, sc.data()).ok;
+	}
+	const oct::RoutePlan plan = oct::choose_route(f, p, spectrum != 0, spectrum ? false : wantBg, spectrum ? false : wantDisp, bgRemoval, sinusPlan);
 	if (path) *path = plan.path;
 	if (kind) *kind = plan.kind;
 	if (intype) *intype = plan.intype;
 	if (preparedRollW) *preparedRollW = plan.prepared ? plan.prepareRollW : -1;
 	if (plan.error) return fail(OCTPIPE_ERR_UNSUPPORTED, plan.error);
+	return OCTPIPE_OK;
+}
+
+int octpipe_debug_sinus_plan(unsigned ascansPerBscan, unsigned* entries, uint32_t* out, size_t capacityEntries) {
+	if (!entries || ascansPerBscan == 0) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null argument");
+	std::vector<float> sc((size_t)ascansPerBscan);
+	octhost::sinusoidal_curve(ascansPerBscan, sc.data());
+	const oct::SinusPlan sp = oct::build_sinus_plan(ascansPerBscan, sc.data());
+	*entries = sp.ok ? sp.entries : 0u;
+	if (sp.ok && out) {
+		if (capacityEntries < sp.entries) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "output buffer too small for the work list");
+		memcpy(out, sp.ent.data(), sizeof(uint32_t) * sp.ent.size());
+	}
+	return OCTPIPE_OK;
+}
+int octpipe_debug_set_sinus_blocks_per_wave(octpipe_t* h, unsigned blocksPerWave) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	h->sinusBlocksPerWave = blocksPerWave;
 	return OCTPIPE_OK;
 }
 

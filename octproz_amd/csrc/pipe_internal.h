@@ -25,6 +25,7 @@
 #include "host_luts.h"
 #include "launch.h"
 #include "route.h"
+#include "sinus_plan.h"
 
 namespace octimpl {
 
@@ -94,6 +95,8 @@ struct octpipe {
 	unsigned bgVersion = 1, bgTermVersion = 0;  // d_postBg content / what d_bgTerm was computed from
 	float bgTermWeight = 0.0f, bgTermOffset = 0.0f;
 	float* d_sinusCurve = nullptr;
+	uint32_t* d_sinusEnt = nullptr;  // work list of the correction inside the fused kernel's store (sinus_plan.h), [sinusM][4]; nullptr: no plan for this A
+	unsigned sinusM = 0, sinusBlocksPerWave = 0;
 	f2* d_spectrum = nullptr;  // FPN / debug scratch, lazily
 	size_t spectrumLines = 0;
 	float4* d_segs = nullptr;

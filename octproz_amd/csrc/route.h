@@ -62,6 +62,7 @@ struct RoutePlan {
 	int prepareRollW = 0;
 	bool bgFused = false;         // post-process background removal inside the image store
 	bool dispFused = false;       // display frames written by the image store (MODE_DISP)
+	bool sinusFused = false;      // sinusoidal scan correction inside the image store (MODE_SINUS): the kernel writes the volume slot itself
 	bool launcherTimes = false;   // the kernel's launcher binds the timing events to the dispatch itself (launch.h LaunchTiming)
 	unsigned path = 0;            // OCTPIPE_PATH_* (octpipe_debug_last_path)
 	const char* error = nullptr;  // the plan cannot run (e.g. the library route without a bound hipFFT)
@@ -96,7 +97,9 @@ inline bool route_needs_prepared(const RouteFacts& f, const OctPipeParams& p) {
 // wantBg: the caller would like the post-process background removal inside the store (it has checked that nothing sits between the
 // grey-scale mapping and the removal).  wantDisp: likewise the display frames; dispNeedsBgFused: ... which are only right if the
 // removal, where it is on, happens in the store too.
-inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool spectrum, bool wantBg, bool wantDisp, bool dispNeedsBgFused) {
+// sinusPlan: a work list for the sinusoidal correction inside the store exists for this B-scan width (sinus_plan.h) and the caller allows it.
+// With the correction on, the removal can only ride on the store if the correction does (cu:1551-1568: the removal follows it).
+inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool spectrum, bool wantBg, bool wantDisp, bool dispNeedsBgFused, bool sinusPlan = false) {
 	RoutePlan r;
 	r.rs = route_rs(p);
 	const int rs = r.rs;
@@ -137,14 +140,22 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 		roll = false;
 		r.path |= OCTPIPE_PATH_PREPARED_ROWS;
 	}
+	// sinusoidal scan correction inside the image store: the general one-wave kernel on raw uint16 rows, N = 256 ... 2048, every
+	// resampling mode but Lanczos, with or without the rolling average inside the kernel (not the two cubic rolling-average variants
+	// whose register budget it exceeds).  It outranks the real-input kernels: one kernel at ~0.9 x the rate of the general kernel
+	// against a faster kernel + a post pass that moves 12 bytes per output sample (N = 1024 without dispersion: 634 M A-scans/s that way).
+	const bool sinusOn = p.sinusoidalScanCorrection != 0;
+	const bool sinusOk = sinusOn && sinusPlan && !spectrum && !(route & OCTPIPE_ROUTE_NO_FUSED_SINUS) && !f.bluestein && !f.libfft && !f.mixed && !f.teamTables &&
+	                     f.N == (1 << f.log2n) && f.log2n >= 8 && f.log2n <= 11 && rs != RS_LANCZOS && intype == IN_U16 &&
+	                     !(roll && rs == RS_CUBIC && (f.log2n == 9 || f.log2n == 11));
 	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
 	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
 	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
-	if (wantBg && !spectrum && (!f.libfft || teamLib || mxn) && (useMixed || !f.bluestein || mxn)) {
+	if (wantBg && (!sinusOn || sinusOk) && !spectrum && (!f.libfft || teamLib || mxn) && (useMixed || !f.bluestein || mxn)) {
 		r.bgFused = true;
 		r.path |= OCTPIPE_PATH_FUSED_BG;
 	}
-	const bool realOk = intype == IN_U16 && rs != RS_LANCZOS && !roll && !disp && !(route & OCTPIPE_ROUTE_NO_REAL_INPUT);  // real FFT input: two A-scans per transform
+	const bool realOk = intype == IN_U16 && rs != RS_LANCZOS && !roll && !disp && !sinusOk && !(route & OCTPIPE_ROUTE_NO_REAL_INPUT);  // real FFT input: two A-scans per transform
 	if (mxn && mxnStatic) {
 		r.kind = ROUTE_KIND_MXS;
 		r.path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_STATIC_PLAN | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
@@ -198,9 +209,13 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 		r.kind = ROUTE_KIND_FUSED;
 		r.path |= roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0;
 		r.launcherTimes = true;
-		if (wantDisp && !spectrum && (!dispNeedsBgFused || r.bgFused)) {
+		if (wantDisp && !spectrum && !sinusOn && (!dispNeedsBgFused || r.bgFused)) {
 			r.dispFused = true;
 			r.path |= OCTPIPE_PATH_FUSED_DISPLAY;
+		}
+		if (sinusOk) {
+			r.sinusFused = true;
+			r.path |= OCTPIPE_PATH_FUSED_SINUS;
 		}
 	}
 	if (r.pair) r.path |= OCTPIPE_PATH_REAL_INPUT;

@@ -164,6 +164,10 @@ class Pipeline:
         """OCTPIPE_ROUTE_* of an existing handle (takes effect with the next buffer)"""
         check(self._lib.octpipe_debug_set_route(self._h, int(flags)))
 
+    def set_sinus_blocks_per_wave(self, k):
+        """MODE_SINUS: blocks of the work list per wave (0 = library default); measurement / test knob (octpipe_debug.h)"""
+        check(self._lib.octpipe_debug_set_sinus_blocks_per_wave(self._h, int(k)))
+
     def last_path(self):
         """_lib.PATH_* bits of the implementation the last buffer's image launch took"""
         n = C.c_uint()

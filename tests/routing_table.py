@@ -12,7 +12,24 @@ ROUTING = [
     (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 300}, 0, 0, _P.PATH_PREPARED_ROWS),
     (1024, {"backgroundRemoval": 1, "rollingAverageWindowSize": 200, "bitDepth": 16}, 0, 0, _P.PATH_PREPARED_ROWS),  # sums not exact
     (1024, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_FUSED_BG),
-    (1024, {"postProcessBackgroundRemoval": 1, "sinusoidalScanCorrection": 1}, 0, 0, 0),
+    # sinusoidal scan correction: inside the image store of the general kernel (round 6), and the removal that follows it with it
+    (1024, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_FUSED_SINUS),
+    (1024, {"postProcessBackgroundRemoval": 1, "sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_FUSED_SINUS | _P.PATH_FUSED_BG),
+    (1024, {"postProcessBackgroundRemoval": 1, "sinusoidalScanCorrection": 1}, 0, _P.ROUTE_NO_FUSED_SINUS, 0),               # both in the post pass
+    (1024, {"postProcessBackgroundRemoval": 1, "sinusoidalScanCorrection": 1}, 0, _P.ROUTE_NO_FUSED_BG, _P.PATH_FUSED_SINUS),  # the removal alone in the post pass
+    (1024, {"sinusoidalScanCorrection": 1, "dispersionCompensation": 0}, 0, 0, _P.PATH_FUSED_SINUS),                          # outranks the real-input kernel + post pass
+    (1024, {"sinusoidalScanCorrection": 1, "dispersionCompensation": 0}, 0, _P.ROUTE_NO_FUSED_SINUS, _P.PATH_REAL_INPUT),
+    (1024, {"sinusoidalScanCorrection": 1, "bscanFlip": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_FUSED_SINUS | _P.PATH_ROLL_IN_KERNEL),
+    (1024, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 2}, 0, 0, 0),                                           # Lanczos: post pass
+    (1024, {"sinusoidalScanCorrection": 1}, 1, 0, 0),                                                                          # packed 12 bit rows: post pass
+    (1024, {"sinusoidalScanCorrection": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 300}, 0, 0, _P.PATH_PREPARED_ROWS),
+    (2048, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_FUSED_SINUS),
+    (2048, {"sinusoidalScanCorrection": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_ROLL_IN_KERNEL),  # cubic + rolling at 2048: registers
+    (512, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 0}, 0, 0, _P.PATH_FUSED_SINUS),
+    (256, {"sinusoidalScanCorrection": 1, "resampling": 0}, 0, 0, _P.PATH_FUSED_SINUS),
+    (4096, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM),                                                              # team kernel + post pass
+    (1664, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM),
+    (1000, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
     (1024, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
     (4096, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
     (1664, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),

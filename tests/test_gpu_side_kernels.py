@@ -64,6 +64,83 @@ def test_post_pass_sinusoidal_and_background_bit_exact(N, A, B, sinus, bg):
     pipe.close()
 
 
+def test_the_post_pass_cases_above_took_the_store_where_it_exists():
+    """(1024, 24, 3), (256, 5, 2), (512, 130, 1) above run the correction inside the fused kernel's image store (round 6); 300 and 2046 keep the post pass"""
+    for N, A, B, want in ((1024, 24, 3, True), (256, 5, 2, True), (512, 130, 1, True), (300, 7, 2, False), (2046, 3, 2, False), (1024, 2, 4, False)):
+        p = v180_benchmark_params(N, A, B)
+        p.sinusoidalScanCorrection = 1
+        pipe = Pipeline(p, device=0)
+        pipe.process_device(_dev(synthetic_raw(N, A, B, seed=1)).data_ptr()); pipe.synchronize()
+        assert bool(pipe.last_path() & _lib.PATH_FUSED_SINUS) == want, (N, A, B)
+        pipe.close()
+
+
+SINUS_STORE_CASES = [
+    # N, A, B, settings, route flags, blocks per wave
+    (1024, 24, 3, {}, 0, 0),
+    (1024, 512, 4, {}, 0, 0),
+    (1024, 512, 4, {"bscanFlip": 1}, 0, 1),
+    (1024, 512, 3, {"bscanFlip": 1}, 0, 4),                                  # odd B-scan count: the last one is not flipped (cu:1547)
+    (1024, 500, 5, {"bscanFlip": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0),  # north_star's chain
+    (1024, 130, 2, {"postProcessBackgroundRemoval": 1}, 0, 0),
+    (1024, 130, 2, {"postProcessBackgroundRemoval": 1, "signalLogScaling": 0, "bscanFlip": 1}, 0, 2),
+    (1024, 64, 40, {"bscanFlip": 1}, _lib.ROUTE_TINY_GRID, 0),               # two persistent workgroups: every wave walks many blocks
+    (1024, 64, 40, {"backgroundRemoval": 1, "rollingAverageWindowSize": 8}, _lib.ROUTE_TINY_GRID, 3),
+    (1024, 3, 7, {"bscanFlip": 1}, 0, 0),                                    # three rows per B-scan
+    (1024, 96, 3, {"resamplingInterpolation": 0}, 0, 0),                     # linear
+    (1024, 96, 3, {"resampling": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 16}, 0, 0),  # 12 waves, previous row in registers
+    (1024, 96, 3, {"dispersionCompensation": 0, "bscanFlip": 1}, 0, 0),      # would be the real-input kernel + post pass
+    (2048, 70, 3, {"bscanFlip": 1}, 0, 0),
+    (2048, 70, 3, {"resamplingInterpolation": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 32}, 0, 0),
+    (512, 130, 3, {"bscanFlip": 1, "postProcessBackgroundRemoval": 1}, 0, 0),
+    (512, 200, 2, {"resampling": 0}, _lib.ROUTE_TINY_GRID, 0),
+    (256, 130, 4, {"bscanFlip": 1}, 0, 0),
+    (256, 33, 9, {"backgroundRemoval": 1, "rollingAverageWindowSize": 4, "resamplingInterpolation": 0}, 0, 5),
+]
+
+
+@pytest.mark.parametrize("N,A,B,settings,route,bpw", SINUS_STORE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else ",".join("%s=%s" % kv for kv in v.items()) or "v180")
+def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_own_image(N, A, B, settings, route, bpw):
+    """cu:491-514 inside the image store (MODE_SINUS) == the oracle's pass applied to the image the same kernel writes without the
+    correction, bit for bit -- and == the post-pass route: flip, rolling average, background removal behind it, every block size, the
+    buffer's last A-scan left as it is, B-scans that end inside a block"""
+    p = v180_benchmark_params(N, A, B)
+    _grey(p)
+    p.fixedPatternNoiseRemoval = 0
+    for k, v in settings.items():
+        setattr(p, k, v)
+    bg = p.postProcessBackgroundRemoval
+    p.postProcessBackgroundRemoval = 0
+    raw = synthetic_raw(N, A, B, seed=N + A + B)
+    d = _dev(raw)
+    # the kernel that will run with the correction is the general one: keep the uncorrected reference image on it too
+    plain = Pipeline(p, device=0, route=route | _lib.ROUTE_NO_REAL_INPUT)
+    plain.process_device(d.data_ptr()); plain.synchronize()
+    img = plain.processed_host()
+    plain.close()
+    W = N // 2
+    bgline = (np.random.default_rng(2).random(W) * 0.2).astype(np.float32)
+    p.sinusoidalScanCorrection, p.postProcessBackgroundRemoval = 1, bg
+    p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 0.75, 0.01
+    p.loadPostProcessingBackground(bgline)
+    want = octref.sinusoidal(img.copy(), W, A, B)
+    if bg:
+        want = octref.postproc_background_removal(want, bgline, 0.75, 0.01, W)
+    pipe = Pipeline(p, device=0, route=route)
+    pipe.set_sinus_blocks_per_wave(bpw)
+    for _ in range(2):  # (idempotent per call)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        assert pipe.last_path() & _lib.PATH_FUSED_SINUS
+        got = pipe.processed_host()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "rows that differ: %s" % np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).reshape(A * B, W).any(axis=1))[:20]
+    pipe.close()
+    post = Pipeline(p, device=0, route=route | _lib.ROUTE_NO_FUSED_SINUS | _lib.ROUTE_NO_REAL_INPUT)
+    post.process_device(d.data_ptr()); post.synchronize()
+    assert not (post.last_path() & _lib.PATH_FUSED_SINUS)
+    assert np.array_equal(post.processed_host().view(np.uint32), want.view(np.uint32))
+    post.close()
+
+
 @pytest.mark.parametrize("sinus", [0, 1])
 def test_background_recording_uses_the_corrected_first_bscan_and_fills_the_host_shadow_before_the_callback(sinus):
     N, A, B = 512, 16, 3

@@ -77,7 +77,8 @@ def test_display_frames_by_the_store_only_where_asked_and_valid():
     assert route(params(1024, {}))[1] == 0                                                       # opt-in
     assert route(params(1024, {}), flags=F)[1] == _lib.PATH_FUSED_DISPLAY
     assert route(params(1024, {"functionFramesBscan": 3}), flags=F)[1] == 0                      # averaging: not a copy of one value
-    assert route(params(1024, {"sinusoidalScanCorrection": 1}), flags=F)[1] == 0                 # a pass behind the kernel changes the volume
+    assert route(params(1024, {"sinusoidalScanCorrection": 1}), flags=F)[1] == _lib.PATH_FUSED_SINUS   # the correction in the store changes the rows: frames by the extraction kernel
+    assert route(params(1024, {"sinusoidalScanCorrection": 1}), flags=F | _lib.ROUTE_NO_FUSED_SINUS)[1] == 0  # a pass behind the kernel changes the volume
     assert route(params(1024, {"postProcessBackgroundRemoval": 1}), flags=F)[1] == _lib.PATH_FUSED_DISPLAY | _lib.PATH_FUSED_BG
     assert route(params(1024, {"postProcessBackgroundRemoval": 1}), flags=F | _lib.ROUTE_NO_FUSED_BG)[1] == 0
     assert route(params(1024, {"dispersionCompensation": 0}), flags=F)[1] == _lib.PATH_REAL_INPUT  # the real-input kernel has no MODE_DISP

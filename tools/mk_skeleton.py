@@ -27,43 +27,63 @@ OCT_DEV f32x4 opq4() { return f32x4{opq(), opq(), opq(), opq()}; }
 OCT_DEV void sink(float x) { asm volatile("" :: "v"(x)); }
 OCT_DEV void sink2(f2 x) { sink(x.x); sink(x.y); }
 OCT_DEV void sink4(f32x4 x) { sink(x.x); sink(x.y); sink(x.z); sink(x.w); }
+OCT_DEV uint32_t opqu() { uint32_t x; asm volatile("" : "=v"(x)); return x; }
+OCT_DEV void sinku(uint32_t x) { asm volatile("" :: "v"(x)); }
 '''
 
-# (old, new) per skeleton; applied to kernels.h
+# (old, new) per skeleton; applied to kernels.h.  Round 6: rewritten for the round-5 structure of the kernel (grouped gather
+# through the `loadg` lambdas, mirror tap written at staging, twiddles of N = 1024 in registers, `fft_pass` with grouped LDS
+# twiddle reads) -- the round-2 list no longer matched a line of it.
+STAGE_W = "*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = f;"
+MIRROR_W = "if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING != 0) { if (i == 0 && h == 0 && lane == 0) row[ROW_OFF - 1] = f.y; }"
+TAP_R = "for (int k = 0; k < 4; k++) tp[b][i][k] = t[k];"
+TAPSUM = "const float y = __builtin_fmaf(cw.w, tp[b][i][3], __builtin_fmaf(cw.z, tp[b][i][2], __builtin_fmaf(cw.y, tp[b][i][1], cw.x * tp[b][i][0])));"
 NOLDS = [
     # staging
-    ("*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);",
-     "{ const float4 f_ = chunk_to_float<INTYPE>(pre[i], h, shift); sink(f_.x); sink(f_.y); sink(f_.z); sink(f_.w); }"),
-    ("if (lane == 0) row[ROW_OFF - 1] = row[ROW_OFF + 1];  // n0 = |n1 - 1| mirror tap (cu:284)", ""),
-    # gather
-    ("cw = cwL[lane + 64 * q];", "cw = opq4();"),
-    ("if ((q & 1) == 0) wph2 = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];", "if ((q & 1) == 0) wph2 = opq4();"),
-    ("y = __builtin_fmaf(cw.w, t[3], __builtin_fmaf(cw.z, t[2], __builtin_fmaf(cw.y, t[1], cw.x * t[0])));",
-     "{ const float t0 = opq(), t1 = opq(), t2 = opq(), t3 = opq(); y = __builtin_fmaf(cw.w, t3, __builtin_fmaf(cw.z, t2, __builtin_fmaf(cw.y, t1, cw.x * t0))); }"),
-    # FFT
+    (STAGE_W, "{ sink(f.x); sink(f.y); sink(f.z); sink(f.w); }"),
+    (MIRROR_W, ""),
+    # gather (grouped form): tap reads, and the table reads of the variants that keep their tables in LDS (N = 2048)
+    (TAP_R, "for (int k = 0; k < 4; k++) tp[b][i][k] = opq();"),
+    ("cwG[b][i] = cwL[lane + 64 * q];", "cwG[b][i] = opq4();"),
+    ("if ((q & 1) == 0) wpG[b][i >> 1] = reinterpret_cast<const f32x4*>(wphL)[lane + 64 * (q >> 1)];", "if ((q & 1) == 0) wpG[b][i >> 1] = opq4();"),
+    # FFT: exchange through LDS (N = 1024), twiddles from the LDS tables, planar exchange (N = 2048)
     ("for (int q = 0; q < P; q++) v[q] = rb[(64 + 4 * OCT_PADK) * q];", "for (int q = 0; q < P; q++) v[q] = opq2();"),
-    ("const f32x4 w = REGTW ? twr[c] : tp[c * 16];", "const f32x4 w = opq4();"),
-    ("const f32x4 w = REGTW3 ? twr[8 + c] : tp[c * 64];", "const f32x4 w = opq4();"),
+    ("for (int c = 0; c < 4; c++) wl[c] = tp[c * 16];", "for (int c = 0; c < 4; c++) wl[c] = opq4();"),
+    ("for (int d = 4; d < 8; d++) wl[d] = tp[d * 16];", "for (int d = 4; d < 8; d++) wl[d] = opq4();"),
+    ("for (int c = 0; c < 6; c++) wl3[c] = tp[c * 64];", "for (int c = 0; c < 6; c++) wl3[c] = opq4();"),
     ("for (int u = 0; u < R; u++) wb[pad16c(u * NS)] = v[m + u * NB];", "for (int u = 0; u < R; u++) sink2(v[m + u * NB]);"),
-    # the long transforms (N = 2048: config 3): twiddles from the LDS tables, planar exchange
     ("for (int t = 1; t < R; t++) v[m + t * NB] = octfft::cmul(v[m + t * NB], tk[(t - 1) * NS]);",
      "for (int t = 1; t < R; t++) v[m + t * NB] = octfft::cmul(v[m + t * NB], opq2());"),
     ("for (int u = 0; u < R; u++) wb[u * NS + K * ((u * NS) >> 5)] = c ? v[m + u * NB].y : v[m + u * NB].x;",
      "for (int u = 0; u < R; u++) sink(c ? v[m + u * NB].y : v[m + u * NB].x);"),
     ("for (int q = 0; q < P; q++) (c ? ny : nx)[q] = rb[(64 + 2 * K) * q];", "for (int q = 0; q < P; q++) (c ? ny : nx)[q] = opq();"),
+    # rolling-average stage (MODE_ROLL): prefix array, pads, window sums, corrected row
+    ("*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + 4 * lane + 256 * i]) = uint4{p0, p1, p2, p2 + x.w};", "{ sinku(p0); sinku(p1); sinku(p2); sinku(p2 + x.w); }"),
+    ("*reinterpret_cast<uint4*>(&pfx[4 * lane]) = uint4{0u, 0u, 0u, 0u};", ""),
+    ("*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + N + 4 * lane]) = uint4{base, base, base, base};", "sinku(base);"),
+    ("for (int i = 0; i < NL; i++) { h4[i] = *reinterpret_cast<const uint4*>(hiP + 256 * i); l4[i] = *reinterpret_cast<const uint4*>(loP + 256 * i); }",
+     "for (int i = 0; i < NL; i++) { h4[i] = uint4{opqu(), opqu(), opqu(), opqu()}; l4[i] = uint4{opqu(), opqu(), opqu(), opqu()}; }"),
+    ("for (int c = 0; c < 4; c++) wsAll[i][c] = hiP[256 * i + c] - loP[256 * i + c];", "for (int c = 0; c < 4; c++) wsAll[i][c] = opqu() - opqu();"),
+    ("*reinterpret_cast<float4*>(&row[ROW_OFF + 4 * lane + 256 * i]) = float4{o[0], o[1], o[2], o[3]};", "{ sink(o[0]); sink(o[1]); sink(o[2]); sink(o[3]); }"),
+    ("if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING != 0) { if (i == 0 && lane == 0) row[ROW_OFF - 1] = o[1]; }  // mirror tap, see below", ""),
+    # epilogue: mean line from LDS (variants without MEAN_REGS)
+    ("else z = v[m + u * NBL] - ml[64 * m + u * (N / RL)];", "else z = v[m + u * NBL] - opq2();"),
 ]
 NOVALU = [
-    ("*reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = chunk_to_float<INTYPE>(pre[i], h, shift);",
-     "{ const f32x4 f_ = __builtin_bit_cast(f32x4, pre[i]); *reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = float4{f_.x, f_.y, f_.x, f_.y}; }"),
-    ("y = __builtin_fmaf(cw.w, t[3], __builtin_fmaf(cw.z, t[2], __builtin_fmaf(cw.y, t[1], cw.x * t[0])));",
-     "{ const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3]; asm volatile(\"\" :: \"v\"(t0), \"v\"(t1), \"v\"(t2), \"v\"(t3)); sink4(cw); y = opq(); }"),
-    ("v[q] = wph * y;", "{ sink2(wph); sink(y); v[q] = opq2(); }"),
+    (STAGE_W, "{ const f32x4 f_ = __builtin_bit_cast(f32x4, pre[i]); *reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = float4{f_.x, f_.y, f_.x, f_.y}; }"),
+    ("const float4 f = chunk_to_float<INTYPE>(pre[i], h, shift);", ""),
+    (MIRROR_W, "if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING != 0) { if (i == 0 && h == 0 && lane == 0) row[ROW_OFF - 1] = __builtin_bit_cast(f32x4, pre[i]).y; }"),
+    (TAPSUM, "asm volatile(\"\" :: \"v\"(tp[b][i][0]), \"v\"(tp[b][i][1]), \"v\"(tp[b][i][2]), \"v\"(tp[b][i][3])); sink4(cw); const float y = opq();"),
+    ("v[q] = wph * y;\n\t\t\t\t}\n\t\t\t\t__builtin_amdgcn_sched_barrier(0);\n\t\t\t\tif constexpr (!AHEAD) { if (g + 1 < NG) loadg(g + 1, 0); }",
+     "{ sink2(wph); sink(y); v[q] = opq2(); }\n\t\t\t\t}\n\t\t\t\t__builtin_amdgcn_sched_barrier(0);\n\t\t\t\tif constexpr (!AHEAD) { if (g + 1 < NG) loadg(g + 1, 0); }"),
     ("if (c > 0) v[2 * c] = octfft::cmul(v[2 * c], f2{w.x, w.y});", "sink4(w);"),
     ("v[2 * c + 1] = octfft::cmul(v[2 * c + 1], f2{w.z, w.w});", ""),
     ("v[i0 / 3 + (i0 % 3 + 1) * NB] = octfft::cmul(v[i0 / 3 + (i0 % 3 + 1) * NB], f2{w.x, w.y});", "sink4(w);"),
     ("v[i1 / 3 + (i1 % 3 + 1) * NB] = octfft::cmul(v[i1 / 3 + (i1 % 3 + 1) * NB], f2{w.z, w.w});", ""),
     ("for (int m = 0; m < NB; m++) octfft::Dft<R, NB, PRUNE>::run(&v[m]);", "for (int m = 0; m < NB; m++) {}"),
-    ("perm_exchange<P>(v);", ""),
+    ("if constexpr (PX) perm_exchange<P>(v);", ""),
+    # (every value the exchange reads back stays alive: with the transform gone the pruned last pass would let hipcc drop half of the reads)
+    ("for (int q = 0; q < P; q++) v[q] = rb[(64 + 4 * OCT_PADK) * q];", "for (int q = 0; q < P; q++) { v[q] = rb[(64 + 4 * OCT_PADK) * q]; }\n\t\tfor (int q = 0; q < P; q++) sink2(v[q]);"),
     # the long transforms: twiddle reads kept, products dropped; the permlane exchange of the 32 x 16 x 4 plan dropped
     ("for (int t = 1; t < R; t++) v[m + t * NB] = octfft::cmul(v[m + t * NB], tk[(t - 1) * NS]);",
      "for (int t = 1; t < R; t++) sink2(tk[(t - 1) * NS]);"),
@@ -87,7 +107,7 @@ def apply(src, subs, name):
 
 def main():
     base = open(os.path.join(CSRC, "kernels.h")).read()
-    marker = "// ------------------------------------------------------------------ raw chunk"
+    marker = "// Cubic gather with the tap weights, window x phasor and tap addresses of the lane's P samples in registers"
     assert marker in base
     for name in sys.argv[1:]:
         subs = {"valu": NOLDS, "lds": NOVALU, "io": None}[name]
@@ -95,17 +115,20 @@ def main():
         if name == "io":
             s = apply(s, NOVALU, name)
             # on top of the VALU-free kernel drop the LDS traffic (patterns that NOVALU left in place)
-            s = apply(s, [(o, n) for o, n in NOLDS if o in s and "chunk_to_float" not in o and "fmaf" not in o], name)
+            s = s.replace("for (int q = 0; q < P; q++) { v[q] = rb[(64 + 4 * OCT_PADK) * q]; }\n\t\tfor (int q = 0; q < P; q++) sink2(v[q]);", "for (int q = 0; q < P; q++) v[q] = rb[(64 + 4 * OCT_PADK) * q];")
+            s = apply(s, [(o, n) for o, n in NOLDS if o in s and o not in (STAGE_W, MIRROR_W) and "pfx" not in o and "hiP" not in o and "o[1]" not in o], name)
             s = apply(s, [("{ const f32x4 f_ = __builtin_bit_cast(f32x4, pre[i]); *reinterpret_cast<float4*>(&row[ROW_OFF + SPL * lane + 64 * SPL * i + 4 * h]) = float4{f_.x, f_.y, f_.x, f_.y}; }",
                            "{ const f32x4 f_ = __builtin_bit_cast(f32x4, pre[i]); sink(f_.x); sink(f_.y); }"),
-                          ("{ const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3]; asm volatile(\"\" :: \"v\"(t0), \"v\"(t1), \"v\"(t2), \"v\"(t3)); sink4(cw); y = opq(); }", "{ sink4(cw); y = opq(); }"),
+                          ("if constexpr (RS == RS_CUBIC && OCT_MIRROR_AT_STAGING != 0) { if (i == 0 && h == 0 && lane == 0) row[ROW_OFF - 1] = __builtin_bit_cast(f32x4, pre[i]).y; }", ""),
+                          ("asm volatile(\"\" :: \"v\"(tp[b][i][0]), \"v\"(tp[b][i][1]), \"v\"(tp[b][i][2]), \"v\"(tp[b][i][3])); sink4(cw); const float y = opq();", "sink4(cw); const float y = opq();"),
                           ("for (int t = 1; t < R; t++) sink2(tk[(t - 1) * NS]);", "for (int t = 1; t < R; t++) {}")], name)
         else:
             s = apply(s, subs, name)
         d = "/tmp/abl_skel_" + name
         os.makedirs(d, exist_ok=True)
-        for f in ("launch.h", "fused_inst.hip", "fft_regs.h", "bluestein.h", "real2n_kernel.h"):
-            open(os.path.join(d, f), "w").write(open(os.path.join(CSRC, f)).read())
+        for f in os.listdir(CSRC):
+            if (f.endswith(".h") and f != "kernels.h") or f == "fused_inst.hip":
+                open(os.path.join(d, f), "w").write(open(os.path.join(CSRC, f)).read())
         open(os.path.join(d, "kernels.h"), "w").write(s)
         print("wrote", d)
 

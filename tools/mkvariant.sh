@@ -6,7 +6,7 @@ L=$1; shift
 root=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $root/scratch/variants
 for v in "$@"; do
- ( cd /tmp/abl_$v && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -DOCT_LOG2N=$L -DOCT_FUSED_RS=${RS:-2} -Wno-inline-asm $VFLAGS -c fused_inst.hip -o v.o 2>&1 | grep -E "error|static_assert"
-   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC v.o $(ls $root/octproz_amd/csrc/build/*.o | grep -v fused_${L}_rs${RS:-2}.o) -o $root/scratch/variants/lib_$v.so -pthread ) &
+ ( cd /tmp/abl_$v && rm -f v.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -DOCT_LOG2N=$L -DOCT_FUSED_RS=${RS:-2} -Wno-inline-asm $VFLAGS -c fused_inst.hip -o v.o 2>&1 | grep -E "error|static_assert"
+   [ -f v.o ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC v.o $(ls $root/octproz_amd/csrc/build/*.o | grep -v fused_${L}_rs${RS:-2}.o) -o $root/scratch/variants/lib_$v.so -pthread ) &
 done
 wait
