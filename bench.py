@@ -30,9 +30,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide: FP32 vector (VALU) peak, 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
-# VALU-only skeleton of the headline kernel's instruction mix (every LDS / memory / scalar instruction deleted, tools/mk_skeleton.py):
-# 0.118 ms per 1024x512x256 buffer = 0.57 of the HBM roofline -- the ceiling of this algorithm on this ALU
-VALU_FLOOR = {1024: {"frac": 0.57, "kernel_ms": 0.118, "source": "profiles/r2a_ceiling_skeletons_ab.txt, profiles/r2b_pmc_base_vs_regtab_vs_valu_skeleton.txt"}}
+# VALU-only skeletons of the kernels' instruction mix (every LDS instruction deleted, everything else kept; tools/mk_skeleton.py), measured
+# in round 6 on the round's own kernels, same box interleaved with the product (profiles/r6a_ceiling_skeletons_ab.txt): what the vector
+# ALU alone allows -- the ceiling of this algorithm's instruction count on this chip, not a claim about the product
+VALU_FLOOR = {1024: {"frac": 0.615, "kernel_ms": 0.1092, "source": "profiles/r6a_ceiling_skeletons_ab.txt (same box: product 0.1477 ms = 0.454)"},
+              2048: {"frac": 0.628, "kernel_ms": 0.8545, "source": "profiles/r6a_ceiling_skeletons_ab.txt (2048x1024x512; same box: product 1.392 ms = 0.386)"}}
 
 
 def parse_args(argv=None):
@@ -579,7 +581,7 @@ def main():
                          "flops_per_ascan": flops_fft + flops_other, "flops_convention": "5 N log2 N (transform) + 30 N (unpack, cubic taps, window x phasor, |z|^2, log)",
                          "achieved_tflops": tflops, "fp32_vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "frac_fp32_vector": tflops / FP32_VECTOR_PEAK_TFLOPS,
                          "valu_floor_frac": floor["frac"] if floor else None,
-                         "valu_floor_source": (floor["source"] + ": VALU-only skeleton %.3f ms per 1024x512x256 launch" % floor["kernel_ms"]) if floor else
+                         "valu_floor_source": (floor["source"] + ": VALU-only skeleton %.4f ms per launch" % floor["kernel_ms"]) if floor else
                                               "no skeleton study for this length"},
             "preflight": pre_all,
         }

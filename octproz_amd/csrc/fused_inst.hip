@@ -14,9 +14,10 @@
 #endif
 
 // MODE_SINUS: blocks of the work list per wave (more blocks: a wave's rows spread over the buffer like the plain kernel's; fewer: less
-// recomputed halo rows)
+// recomputed halo rows).  1024 x 512 x 256, same box (profiles/r6b_sinus_in_store_sweep*.txt): 1 block 718-731 M A-scans/s, 2 blocks 716-723 M,
+// 4 blocks 700 M, 8 blocks 640 M; with the rolling average and the flip 610 / 602 / 575 / 524 M
 #ifndef OCT_SINUS_BLOCKS_PER_WAVE
-#define OCT_SINUS_BLOCKS_PER_WAVE 2
+#define OCT_SINUS_BLOCKS_PER_WAVE 1
 #endif
 
 namespace oct {

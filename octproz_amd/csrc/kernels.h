@@ -155,6 +155,11 @@ template <> struct GatherCfg<8> { static constexpr int GROUP = 4; static constex
 #ifndef OCT_PROLOGUE_WAIT
 #define OCT_PROLOGUE_WAIT 1
 #endif
+// (the immediate is the gfx9 encoding -- vmcnt in bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8 -- and the inline assembly of this file is
+//  gfx9 too: MI355X is gfx950; mixedn_rtc.hip refuses to compile this text for anything else)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "kernels.h is written for gfx9 (MI355X: gfx950)"
+#endif
 OCT_DEV void prologue_wait() {
 	if constexpr (OCT_PROLOGUE_WAIT != 0) __builtin_amdgcn_s_waitcnt(0x0F70);
 }
@@ -999,8 +1004,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 	}
 	// the last pass' twiddles too where the register budget allows (plain uint16 kernel: 249 VGPRs, no spill)
-	// (MODE_SINUS: the block's four entry registers and the blend's temporaries take their place -- 7 spilled registers otherwise)
-	constexpr bool TW3 = (REGTAB || REGLIN) && LOG2N == 10 && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32 && !(SINUS && REGTAB);
+	constexpr bool TW3 = (REGTAB || REGLIN) && LOG2N == 10 && OCT_REGTW3 != 0 && !ROLL && INTYPE != IN_F32;
 	constexpr bool TW2 = (REGTAB || REGLIN) && LOG2N == 10 && !ROLL;  // (the rolling-average variant needs the registers for its window bookkeeping)
 	f32x4 tw2R[TW2 ? (TW3 ? 14 : 8) : 1];
 	if constexpr (REGTAB) {
@@ -1380,8 +1384,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			bool sSt0 = false, sSt1 = false, sRaw = false;
 			__amdgpu_buffer_rsrc_t outR1 = outR, outRL = outR;
 			if constexpr (SINUS) {
-				sF0 = __builtin_bit_cast(float, sE0.y);
-				sF1 = __builtin_bit_cast(float, sE0.z);
+				const uint32_t f0Bits = sE0.y, f1Bits = sE0.z;  // (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)
+				sF0 = __builtin_bit_cast(float, f0Bits);
+				sF1 = __builtin_bit_cast(float, f1Bits);
 				sRow0 = orow;
 				sRaw = sBA0 + (sE0.x & 0xffffu) + 1u == a.linesInBuffer;
 				const bool pair = sT > 0u && sF0 >= 0.0f;

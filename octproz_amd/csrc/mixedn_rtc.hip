@@ -195,6 +195,8 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	}
 	*waves = W;
 	if (W < 1) { *why = "one A-scan of this length does not fit the LDS"; return false; }
+	// the kernel text carries gfx9 s_waitcnt immediates and gfx9 inline assembly (kernels.h): no other target
+	if (!arch || std::strncmp(arch, "gfx9", 4) != 0) { *why = std::string("the run-time compiled kernels are written for gfx9 (MI355X: gfx950), not for '") + (arch ? arch : "") + "'"; return false; }
 	char src[1024];
 	std::snprintf(src, sizeof src,
 	              "#include \"mixedn_static.h\"\n"

@@ -194,24 +194,22 @@ bool needsPrepared(const octpipe* h) {
 // parameter set `q` on the library's background thread -- the one `q` itself runs first, then everything ONE setting away
 // (resampling mode, dispersion compensation = one or two A-scans per transform, scaling, rolling average, background removal in
 // the store, the spectrum output of the mean-line estimate).  A variant costs hiprtc 0.5-1.2 s; compiled by the buffer that first
-// needs it, that is a second during which the processing thread stands still.  The variant rule mirrors launchFused.
+// needs it, that is a second during which the processing thread stands still.
+oct::RouteFacts routeFacts(const octpipe* h);
 void prefetchRunTimeVariants(const octpipe* h, const OctPipeParams& q0) {
 	if (!h->mixedStatic || h->arch.empty() || (h->route & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_NO_MIXEDN_STATIC))) return;
-	auto one = [h](const OctPipeParams& q) {
-		const bool plain16 = h->bytesPerSample == 2 && h->sampleFormat == OCTPIPE_FORMAT_AUTO && !h->forcePrepared;
-		const int rs = !q.resampling ? oct::RS_NONE : q.resamplingInterpolation == OCTPIPE_INTERP_CUBIC ? oct::RS_CUBIC
-		             : q.resamplingInterpolation == OCTPIPE_INTERP_LANCZOS ? oct::RS_LANCZOS : oct::RS_LINEAR;
-		const bool rollOn = q.backgroundRemoval != 0;
-		const unsigned bits = h->acq.bitDepth > 16 ? 16 : h->acq.bitDepth;
-		const uint64_t maxSample = ((1ull << bits) - 1ull) >> (q.bitshift ? 4 : 0);
-		const bool rollIn = rollOn && q.rollingAverageWindowSize > 0 && q.rollingAverageWindowSize <= oct::ROLL_PAD && 2ull * (uint64_t)q.rollingAverageWindowSize * maxSample < (1ull << 24);
-		const bool u16 = plain16 && (!rollOn || (rollIn && rs != oct::RS_LANCZOS));
-		const int intype = u16 ? oct::IN_U16 : oct::IN_F32;
-		const bool roll = u16 && rollOn;
-		const bool pair = u16 && !roll && rs != oct::RS_LANCZOS && !q.dispersionCompensation && !(h->route & OCTPIPE_ROUTE_NO_REAL_INPUT);
-		const bool bg = q.postProcessBackgroundRemoval && !q.sinusoidalScanCorrection && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG);
-		oct::mixedn_rtc_prefetch(h->mxsPlan, intype, rs, roll, pair, false, q.signalLogScaling != 0, bg, h->arch.c_str());
-		if (q.fixedPatternNoiseRemoval) oct::mixedn_rtc_prefetch(h->mxsPlan, intype, rs, roll, false, true, false, false, h->arch.c_str());
+	// WHICH variant a parameter set runs is route.h's decision (round 6, ADVICE r5: this function had its own copy of the rule, without the
+	// packed / 8-bit / int16 containers and the rows-kernel check): ask choose_route for the image launch and for the spectrum launch
+	const oct::RouteFacts facts = routeFacts(h);
+	auto one = [h, &facts](const OctPipeParams& q) {
+		const bool wantBg = q.postProcessBackgroundRemoval && !q.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG);
+		const oct::RoutePlan img = oct::choose_route(facts, q, false, wantBg, false, false, h->d_sinusEnt != nullptr);
+		if (img.kind == oct::ROUTE_KIND_MXS && !img.error)
+			oct::mixedn_rtc_prefetch(h->mxsPlan, img.intype, img.rs, img.roll, img.pair, false, q.signalLogScaling != 0, img.bgFused, h->arch.c_str());
+		if (q.fixedPatternNoiseRemoval) {
+			const oct::RoutePlan sp = oct::choose_route(facts, q, true, false, false, false, false);
+			if (sp.kind == oct::ROUTE_KIND_MXS && !sp.error) oct::mixedn_rtc_prefetch(h->mxsPlan, sp.intype, sp.rs, sp.roll, sp.pair, true, false, false, h->arch.c_str());
+		}
 	};
 	one(q0);
 	OctPipeParams q = q0;
@@ -286,8 +284,10 @@ oct::RoutePlan imagePlan(const octpipe* h, bool wantBg, const DispFold* wantDisp
 	return oct::choose_route(routeFacts(h), h->params, false, wantBg, wantDisp != nullptr, wantDisp && wantDisp->bgPostPassFollowsUnlessFused, h->d_sinusEnt != nullptr);
 }
 
+// preparedDone: the prepared float32 rows of this buffer are already in h->d_prepared (the retry on another route after a run-time
+// compilation failed: the prepare kernel is not enqueued twice)
 int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt, bool wantBg = false,
-                bool* bgApplied = nullptr, const DispFold* wantDisp = nullptr, bool* dispApplied = nullptr) {
+                bool* bgApplied = nullptr, const DispFold* wantDisp = nullptr, bool* dispApplied = nullptr, bool preparedDone = false) {
 	const OctPipeParams& p = h->params;
 	// WHICH implementation: route.h (a pure function of the handle's facts and the parameter snapshot; tests/test_route.py)
 	const oct::RoutePlan plan = oct::choose_route(routeFacts(h), p, spectrum, wantBg, wantDisp != nullptr, wantDisp && wantDisp->bgPostPassFollowsUnlessFused, h->d_sinusEnt != nullptr);
@@ -299,7 +299,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	if (plan.prepared) {
 		int rc = ensure(h, (void**)&h->d_prepared, sizeof(float) * h->S);
 		if (rc) return rc;
-		if ((rc = launchPrepare(h, d_raw, h->d_prepared, h->S, plan.prepareRollW))) return rc;
+		if (!preparedDone && (rc = launchPrepare(h, d_raw, h->d_prepared, h->S, plan.prepareRollW))) return rc;
 		a.raw = h->d_prepared;
 	}
 	if (bgApplied) *bgApplied = plan.bgFused;
@@ -385,11 +385,12 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 			// another route for the length -- the run-time-plan kernel, the library FFT, Bluestein -- takes that one from here on and
 			// says why (octpipe_debug_rtc_status); only a handle without any fails the buffer
 			const bool otherRoute = h->mixedN || (h->libfft && h->fftExecC2C) || h->bluestein;
-			if (timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+			if (timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); h->timingCounter--; }  // (the retry counts this launch again)
 			if (!otherRoute) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);
 			h->mixedStatic = false;
 			h->rtcMessage = "left the run-time compiled kernel after a failure: " + why;
-			return launchFused(h, d_raw, lines, spectrum, spectrumOut, out, timeIt, wantBg, bgApplied, wantDisp, dispApplied);
+			// (the other routes of such a length read the same prepared rows where this one did: same container rule in route.h)
+			return launchFused(h, d_raw, lines, spectrum, spectrumOut, out, timeIt, wantBg, bgApplied, wantDisp, dispApplied, plan.prepared);
 		}
 		HIP_TRY(e);
 		break;

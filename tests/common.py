@@ -50,6 +50,13 @@ def amp_rtol(n):
 # legitimately differ by a few ulps.  Callers that have the stored images pass `image_ulp_amp` (per bin: the amplitude equivalent of
 # one ulp of the stored value, ulp_amplitude_of_image below); such bins are allowed IMAGE_ULPS ulps on top of the relative bound.
 IMAGE_ULPS = 4.0
+# Round 6 (the policy is FROZEN from here on -- no further exemption): three tightenings, no loosening.
+#   * the ulp allowance is handed over only by the draws it was found on (8-bit containers with linear scaling, tests/test_gpu_fuzz.py);
+#   * the 'cancelled' rule has a buffer-wide cap again, next to the per-line one, and it counts the DC-lobe bins too (CANCEL_FRAC);
+#   * the amplitude bound keeps its form (2e-6 x log2 N: the 2 480-draw run of round 5 measured 0.70 of it, so the 1e-6 x log2 N the
+#     advisor proposed would fail draws that passed), but a DRIFT ALARM sits under it: a test session whose largest measured / allowed
+#     ratio exceeds AMP_DRIFT_ALARM fails (tests/conftest.py), i.e. a kernel change that costs a quarter of a bit shows before it costs one.
+AMP_DRIFT_ALARM = 0.85
 
 
 def ulp_amplitude_of_image(img, p):
@@ -237,6 +244,9 @@ def compare_images(got, want, p, what="", mean_line=None, strict=False, exempt_f
             per_line_allowed = max(CANCEL_MIN_BINS, int(np.ceil(CANCEL_FRAC_PER_LINE * half)))
             assert int(per_line.max()) <= per_line_allowed, "%s: %d of a line's %d bins behind the DC lobe left out of the dB comparison by the 'cancelled' rule (allowed per line: %d)" % (
                 what, int(per_line.max()), half, per_line_allowed)
+            # ... and buffer-wide, lobe bins included (round 6; largest of the 2 480 draws of profiles/r5at_fuzz_1500.txt: 1.64 %)
+            assert stats["cancelled"] <= CANCEL_FRAC * g.size, "%s: %d of %d bins left out of the dB comparison by the 'cancelled' rule (DC lobe included; allowed: %.1f %% of the buffer)" % (
+                what, stats["cancelled"], g.size, 100.0 * CANCEL_FRAC)
             strong = kept
         stats["db_checked"] = int(strong.sum())
         if strong.any():

@@ -127,6 +127,48 @@ def test_random_setting_combination_on_lengths_without_a_dedicated_kernel(seed):
     _check_draw(p, raw, what, route=_lib.ROUTE_NO_MIXEDN_STATIC if seed % 2 else 0)
 
 
+def _image_ulp(img, p):
+    """the image-resolution allowance of compare_images (common.IMAGE_ULPS) only for the draws it was found on: 8-bit containers with
+    linear scaling (round 6, ADVICE r5: until then every draw handed it over)"""
+    return common.ulp_amplitude_of_image(img, p) if (p.bitDepth <= 8 and not p.signalLogScaling) else None
+
+
+def draw_benchmark_style(seed):
+    """the reference's v1.8.0 benchmark settings (FPN removal, dispersion compensation, Hann window, log scaling, 12 bit in uint16) with
+    the curves, the window and the data moved: every draw is held to the STRICT comparison (no exemption of compare_images at all)"""
+    rng = np.random.default_rng(20000 + seed)
+    N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 1664, 1000, 4096]))
+    A = int(rng.integers(27, 65))  # (>= 27 lines: three per segment of the mean-line estimate, see draw())
+    B = int(rng.integers(1, 4))
+    p = v180_benchmark_params(N, A, B)
+    s = N / 1024.0
+    p.c1, p.c2, p.c3 = 871.817574 * s * float(rng.uniform(0.95, 1.05)), -170.633784 * s * float(rng.uniform(0.5, 1.5)), 97.249716 * s * float(rng.uniform(0.5, 1.5))
+    p.d1, p.d2, p.d3 = 97.0 * float(rng.uniform(0.5, 1.5)), -96.625 * float(rng.uniform(0.5, 1.5)), -0.375 * float(rng.uniform(0.5, 1.5))
+    p.windowFillFactor, p.windowCenter = float(rng.uniform(0.8, 1.0)), float(rng.uniform(0.45, 0.55))
+    p.resamplingInterpolation = INTERPOLATION.CUBIC if rng.random() < 0.7 else INTERPOLATION.LINEAR
+    p.bscanFlip = int(rng.random() < 0.3)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=50000 + seed)
+    what = "benchmark-style seed %d: N=%d %dx%d rs=%d flip=%d fill=%.3f" % (seed, N, A, B, int(p.resamplingInterpolation), p.bscanFlip, p.windowFillFactor)
+    return p, raw, what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_STRICT_SEEDS", "208"))))
+def test_random_benchmark_style_settings_strict(seed):
+    """a randomised leg WITHOUT any exemption -- identical -inf pattern, every bin above the dB floor compared in dB,
+    no 'cancelled' rule, no image-resolution allowance -- on the settings family the benchmark runs"""
+    import torch
+    p, raw, what = draw_benchmark_style(seed)
+    o = common.make_oracle(p)
+    want = o.process(raw)
+    pipe = Pipeline(p, device=0)
+    pipe.set_mean_line(o.mean_line(), pin=True)
+    d = torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).to("cuda:0")
+    pipe.process_device(d.data_ptr()); pipe.synchronize()
+    common.compare_images(pipe.processed_host(), want, p, what, mean_line=o.mean_line(), strict=True)
+    pipe.close(); o.close()
+
+
 def _check_draw(p, raw, what, route=0):
     import torch
     o = common.make_oracle(p)
@@ -158,7 +200,7 @@ def _check_draw(p, raw, what, route=0):
         q.signalMultiplicator, q.signalAddend = 1.0, 0.0
         unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
         common.compare_images(unscale(got0), unscale(want0), q, what + " (without the background removal)", mean_line=o0.mean_line(), cancel=True,
-                              image_ulp_amp=common.ulp_amplitude_of_image(want0, p0))
+                              image_ulp_amp=_image_ulp(want0, p0))
         half = int(p.samplesPerLine) // 2
         expect = octref.postproc_background_removal(got0, np.asarray(p.postProcessBackground, np.float32)[:half], p.postProcessBackgroundWeight,
                                                     p.postProcessBackgroundOffset, half)
@@ -169,7 +211,7 @@ def _check_draw(p, raw, what, route=0):
     q = copy.copy(p)
     q.signalMultiplicator, q.signalAddend = 1.0, 0.0
     unscale = lambda img: (img.astype(np.float64) / p.signalMultiplicator - p.signalAddend).astype(np.float32)
-    common.compare_images(unscale(got), unscale(want), q, what, mean_line=o.mean_line(), cancel=True, image_ulp_amp=common.ulp_amplitude_of_image(want, p))
+    common.compare_images(unscale(got), unscale(want), q, what, mean_line=o.mean_line(), cancel=True, image_ulp_amp=_image_ulp(want, p))
     # the second buffer through the same handle (tables resident, slot logic) gives the same image
     pipe.process_device(d.data_ptr())
     pipe.synchronize()

@@ -134,6 +134,7 @@ def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_o
         got = pipe.processed_host()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "rows that differ: %s" % np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).reshape(A * B, W).any(axis=1))[:20]
     pipe.close()
+    p.loadPostProcessingBackground(bgline)  # (the first handle's parameter sync has consumed the "updated" flag of the shared object)
     post = Pipeline(p, device=0, route=route | _lib.ROUTE_NO_FUSED_SINUS | _lib.ROUTE_NO_REAL_INPUT)
     post.process_device(d.data_ptr()); post.synchronize()
     assert not (post.last_path() & _lib.PATH_FUSED_SINUS)
