@@ -683,6 +683,25 @@ OCT_DEV void fft_wave(f2 (&v)[(1 << LOG2N) / 64], f2* xbuf, const f2* tw, int la
 		float* plane = reinterpret_cast<float*>(xbuf);
 		fft_pass<N, R0, 1, false, false, false>(v, xbuf, tw, lane);
 		exchange_planar<N, R0, 1>(v, plane, lane);
+#ifndef OCT_TW11_PRE
+#define OCT_TW11_PRE 0
+#endif
+		if constexpr (P == 32 && OCT_TW11_PRE != 0) {
+			// (experiment) N = 2048: the radix-16 pass' twiddle index k = b mod 32 is lane mod 32 for BOTH butterflies of a lane
+			// (b = lane + 64 m), i.e. 15 twiddles per lane.  Their reads go out right behind the exchange's own reads -- the LDS pipe returns in
+			// order, so they arrive with the exchanged data instead of one dependent round trip each behind it.
+			const f2* tk = tw + T1 + (lane & 31);
+			f2 w[15];
+#pragma unroll
+			for (int t = 1; t < 16; t++) w[t - 1] = tk[(t - 1) * 32];
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int m = 0; m < 2; m++)
+#pragma unroll
+				for (int t = 1; t < 16; t++) v[m + t * 2] = octfft::cmul(v[m + t * 2], w[t - 1]);
+#pragma unroll
+			for (int m = 0; m < 2; m++) octfft::Dft<16, 2, false>::run(&v[m]);
+		} else
 		fft_pass<N, R1, R0, false, false, false>(v, xbuf, tw + T1, lane);
 		if constexpr (P == 32) {
 			perm_exchange32x2(v);

@@ -256,3 +256,9 @@ def test_cancelled_rule_counts_the_bins_behind_the_dc_lobe_only():
     mean2[20] = 0.0                             # two: allowed
     common.compare_images(want.copy(), want, q, "two behind the lobe", mean_line=mean2, cancel=True)
     assert common.LAST_STATS["cancelled"] == 6 * lines and common.LAST_STATS["cancelled_in_dc_lobe"] == 4 * lines
+    # the buffer-wide cap (round 6) counts the lobe bins too: a "lobe" of seven bins on every line is over it although no line has a
+    # cancelled bin behind it
+    mean3 = np.zeros(half, np.complex128)
+    mean3[:7] = 400.0
+    with pytest.raises(AssertionError, match="allowed buffer-wide"):
+        common.compare_images(want.copy(), want, q, "a seven-bin lobe", mean_line=mean3, cancel=True)
