@@ -195,6 +195,7 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 	}
 	*waves = W;
 	if (W < 1) { *why = "one A-scan of this length does not fit the LDS"; return false; }
+	if (roll && mxs::pd_team(d) > 1) { *why = "beyond 5120 samples an A-scan belongs to a team of two waves: the rolling average comes as prepared rows there"; return false; }
 	// the kernel text carries gfx9 s_waitcnt immediates and gfx9 inline assembly (kernels.h): no other target
 	if (!arch || std::strncmp(arch, "gfx9", 4) != 0) { *why = std::string("the run-time compiled kernels are written for gfx9 (MI355X: gfx950), not for '") + (arch ? arch : "") + "'"; return false; }
 	char src[1024];
@@ -375,7 +376,7 @@ bool stale_module_error(hipError_t e) {
 // values), then the smallest sum of radices; largest radix first, an even radix last (its upper outputs are the dropped bins).
 bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out, bool oldLayout) {
 	static const int kR[15] = {20, 16, 15, 14, 13, 12, 11, 10, 8, 7, 6, 5, 4, 3, 2};
-	if (n < 8 || n > (unsigned)mxs::MXS_MAXN || (n & 1u)) return false;
+	if (n < 8 || n > (unsigned)mxs::MXS_MAXN_TEAM || (n & 1u)) return false;
 	struct Search {
 		unsigned n;
 		mxs::PlanDesc best{}, cur{};
@@ -418,10 +419,19 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out, bool oldLayout) {
 		d.radix[0] = r;
 	}
 	d.padp = oldLayout ? ((d.radix[0] % 2 == 0 && d.passes > 1) ? d.radix[0] : 0) : mxs::pd_pad_for(d.radix[0], d.passes);
+	if (mxs::pd_team(d) > 1) {
+		// a team of two waves per A-scan (5120 < N <= 8192; round 6): at least ONE A-scan per CU must fit -- no rolling average inside these
+		if (mxs::pd_values(d) > mxs::MXS_MAXVALUES || mxs::pd_waves(d, true, RS_CUBIC, false, false) < mxs::pd_team(d) || mxs::pd_waves(d, true, RS_CUBIC, false, true) < mxs::pd_team(d)) return false;
+		*out = d;
+		return true;
+	}
 	if (mxs::pd_values(d) > mxs::MXS_MAXVALUES || mxs::pd_waves(d, true, RS_CUBIC, true, false) < 2 || mxs::pd_waves(d, true, RS_CUBIC, false, true) < 2) return false;
 	*out = d;
 	return true;
 }
+
+// whether libhiprtc.so can be had in this process (no compilation)
+bool mixedn_rtc_available(std::string* why) { return bindRtc(why); }
 
 // the build check of the run-time path, without a device: compile the instance of a length for `arch`
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why) {
@@ -465,7 +475,7 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 	if (pair && (intype != IN_U16 || roll || spectrum)) return hipErrorInvalidValue;
 	if ((intype != IN_U16 && intype != IN_F32) || rs < RS_NONE || rs > RS_LANCZOS) return hipErrorInvalidValue;
 	if (rs == RS_LANCZOS && (roll || pair || !a.lanczosW)) return hipErrorInvalidValue;
-	if (roll && (intype != IN_U16 || !roll_in_kernel_ok(a))) return hipErrorInvalidValue;
+	if (roll && (intype != IN_U16 || !roll_in_kernel_ok(a) || mxs::pd_team(d) > 1)) return hipErrorInvalidValue;
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
@@ -516,7 +526,8 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 		}
 		unsigned blocks = (unsigned)m.numCU;
 		const unsigned units = pair ? (a.numLines + 1u) / 2u : a.numLines;
-		const unsigned need = (units + (unsigned)m.waves - 1u) / (unsigned)m.waves;
+		const unsigned perGroup = (unsigned)m.waves / (unsigned)mxs::pd_team(d);  // A-scans (pairs) in flight per workgroup
+		const unsigned need = (units + perGroup - 1u) / perGroup;
 		if (blocks > need) blocks = need;
 		if (maxBlocks > 0 && blocks > (unsigned)maxBlocks) blocks = (unsigned)maxBlocks;
 		if (blocks == 0) return hipSuccess;
@@ -538,7 +549,7 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 void mixedn_rtc_prefetch(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, bool bg, const char* arch) {
 	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (bg ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0);
 	if (pair && (intype != IN_U16 || roll || spectrum)) return;
-	if ((intype != IN_U16 && intype != IN_F32) || rs < RS_NONE || rs > RS_LANCZOS || (rs == RS_LANCZOS && (roll || pair)) || (roll && intype != IN_U16)) return;
+	if ((intype != IN_U16 && intype != IN_F32) || rs < RS_NONE || rs > RS_LANCZOS || (rs == RS_LANCZOS && (roll || pair)) || (roll && (intype != IN_U16 || mxs::pd_team(d) > 1))) return;
 	Cache& c = cache();
 	const std::string a = arch ? arch : "";
 	{

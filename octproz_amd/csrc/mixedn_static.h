@@ -69,6 +69,15 @@ OCT_DEV void buf_store64(f2 v, __amdgpu_buffer_rsrc_t r, int vbase, int c) {
 	__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vbase + (c & 4095), c & ~4095, 0);
 }
 
+// the fence between two phases of an in-place exchange: one wave per A-scan -- the wave's own issue order (kernels.h wave_sync_lds);
+// a team of waves -- every wave's LDS operations complete, then s_barrier (only the LDS counter is drained: the table requests and the image
+// stores of the lane stay in flight).  The workgroup holds W / T teams and the barrier is the workgroup's: teams wait for each other too
+// (they run the same number of phases per A-scan; a team that has left the persistent loop no longer takes part).
+template <int T> OCT_DEV void team_sync() {
+	if constexpr (T == 1) wave_sync_lds();
+	else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // where the last pass delivers: the output row (PAIR: both rows) or the spectrum row of the current A-scan, the grey-scale mapping
 struct Sink {
 	__amdgpu_buffer_rsrc_t out0, out1, spec, lanczos;
@@ -79,7 +88,7 @@ struct Sink {
 template <class P, int p, int RS, int MODE, int MEANN>
 OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
 	constexpr PlanDesc D = P::D;
-	constexpr int N = D.N, R = D.radix[p], NB = N / R, NS = pd_ns(D, p), ITS = pd_its(D, p), PADP = pd_padp(D);
+	constexpr int N = D.N, R = D.radix[p], NB = N / R, NS = pd_ns(D, p), ITS = pd_its(D, p), PADP = pd_padp(D), LN = pd_lanes(D), T = pd_team(D);  // (`lane`: the lane of the TEAM, 0 .. LN - 1)
 	constexpr bool FIRST = p == 0, LAST = p == D.passes - 1;
 	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, PAIR = (MODE & MODE_PAIR) != 0;
 	f2 x[ITS][R];
@@ -91,8 +100,8 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 	bool active[ITS];
 #pragma unroll
 	for (int it = 0; it < ITS; it++) {
-		active[it] = (it + 1) * 64 <= NB || lane + 64 * it < NB;
-		bIn[it] = active[it] ? lane + 64 * it : NB - 1;
+		active[it] = (it + 1) * LN <= NB || lane + LN * it < NB;
+		bIn[it] = active[it] ? lane + LN * it : NB - 1;
 	}
 	if constexpr (FIRST) {
 		// k-linearisation x window x dispersion phasor (cu:213-295, cu:341-489): sample b + t NB, its table entry through L1 / L2.  The
@@ -202,7 +211,7 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 			for (int t = 0; t < R; t++) x[it][t] = src[t * TS];
 		}
 	}
-	wave_sync_lds();
+	team_sync<T>();
 	// ---- twiddles, butterflies
 #pragma unroll
 	for (int it = 0; it < ITS; it++) {
@@ -227,7 +236,7 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 				for (int u = 0; u < R; u++) dst[u * US] = x[it][u];
 			}
 		}
-		wave_sync_lds();
+		team_sync<T>();
 	} else if constexpr (SPECTRUM) {
 #pragma unroll
 		for (int it = 0; it < ITS; it++) {
@@ -245,7 +254,7 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 #pragma unroll
 			for (int u = R / 2; u < R; u++) mb[bIn[it] + (u - R / 2) * NB] = x[it][u];
 		if (lane == 0) mb[N / 2] = x[0][0];
-		wave_sync_lds();
+		team_sync<T>();
 #pragma unroll
 		for (int it = 0; it < ITS; it++) {
 			const f2* mp = mb + (N / 2 - bIn[it]);
@@ -299,11 +308,15 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	static_assert(!PAIR || (INTYPE == IN_U16 && !ROLL && !(MODE & MODE_SPECTRUM) && RS != RS_LANCZOS), "two A-scans per transform: raw uint16 rows, image output");
 	static_assert(!(RS == RS_LANCZOS && ROLL), "Lanczos taps cross line borders: the rolling average of the neighbour rows comes prepared");
 	f2* twL = reinterpret_cast<f2*>(smem);
-	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	// T waves per A-scan (pd_team: 1 up to N = 5120, 2 beyond): `lane` is the lane of the TEAM (0 .. LN - 1), `wave` the team's index in the workgroup
+	constexpr int T = pd_team(D), LN = pd_lanes(D);
+	static_assert(W % T == 0, "whole teams per workgroup");
+	static_assert(T == 1 || !ROLL, "the rolling average of the team lengths comes as prepared rows (its prefix scan is the wave's)");
+	const int tid = threadIdx.x, lane = T == 1 ? (tid & 63) : (tid % LN), wave = __builtin_amdgcn_readfirstlane(tid / LN);
 	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D, ROLL, PAIR);
 	float* row = reinterpret_cast<float*>(slice);
 	f2* xb = reinterpret_cast<f2*>(slice);
-	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + W * pd_slice_bytes(D, ROLL, PAIR));
+	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + (W / T) * pd_slice_bytes(D, ROLL, PAIR));
 	if constexpr (BG) fill_bg_term(termL, a.bgTerm, HALF, tid, W * 64);
 	for (int i = tid; i < pd_twelems(D); i += W * 64) twL[i] = a.twiddle[i];
 	// the lane's share of the mean A-line (cu:492-520) for the whole persistent loop: bins b + u NB of the last pass (PAIR: twice the
@@ -313,7 +326,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	for (int it = 0; it < pd_its(D, LP); it++)
 #pragma unroll
 		for (int u = 0; u < (RL + 1) / 2; u++) {
-			const int bin = lane + 64 * it + u * NBL;
+			const int bin = lane + LN * it + u * NBL;
 			const f2 m = (a.subtractMean && bin < HALF) ? a.meanLine[bin] : f2{0.0f, 0.0f};
 			mean[it * ((RL + 1) / 2) + u] = PAIR ? m * 2.0f : m;
 		}
@@ -327,7 +340,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	sink.sB = PAIR && LOGSCALE ? a.sB - 2.0f * a.sA : a.sB;
 	sink.lanczos = make_rsrc(a.lanczosW, RS == RS_LANCZOS ? N * 64 : 0);
 
-	constexpr int LOADS = (HALF + 63) / 64;
+	constexpr int LOADS = (HALF + LN - 1) / LN;
 	typedef typename RawWord<INTYPE>::T RawT;
 	RawT w[LOADS], w1[PAIR ? LOADS : 1];
 	// Rolling-average DC removal inside the kernel (MODE_ROLL; cu:165-211: mean over [j - W + 1, j + W] clipped to the A-scan), the scheme
@@ -345,7 +358,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 			if (roll_edge_load(N, m)) {
 #pragma unroll
 				for (int c = 0; c < 2; c++) {
-					const int j = 2 * (lane + 64 * m) + c;
+					const int j = 2 * (lane + LN * m) + c;
 					const int lo = max(0, j - a.rollingW + 1), hi = min(N - 1, j + a.rollingW);
 					const float cnt = (float)max(hi - lo + 1, 1);
 					cntE[roll_edge_index(N, m)][c] = cnt;
@@ -356,7 +369,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	// one unit of work per wave and iteration: an A-scan, or (PAIR) the A-scans 2 i and 2 i + 1 (an odd last one: a row of zeros as partner)
 	const unsigned units = PAIR ? (a.numLines + 1u) / 2u : a.numLines;
 	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
-	for (unsigned unit = blockIdx.x * W + wave; unit < units; unit += gridDim.x * W) {
+	for (unsigned unit = blockIdx.x * (W / T) + wave; unit < units; unit += gridDim.x * (W / T)) {
 		const unsigned line = PAIR ? 2u * unit : unit;
 		if constexpr (RS == RS_LANCZOS) {
 			// Lanczos taps cross line borders (cu:313-321): stage [off - 8, off + N + 8) of the BUFFER, off = clamp(line N, 8, S - 9) (the
@@ -370,8 +383,8 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 			const __amdgpu_buffer_rsrc_t haloR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (off - 8) * IN_BYTES, (uint32_t)(left < want ? left : want));
 			constexpr int PER = INTYPE == IN_U16 ? 8 : 4, UNITS = (N + 16 + PER - 1) / PER;
 #pragma unroll
-			for (int i = 0; i < (UNITS + 63) / 64; i++) {
-				const int u = lane + 64 * i;
+			for (int i = 0; i < (UNITS + LN - 1) / LN; i++) {
+				const int u = lane + LN * i;
 				if (u < UNITS) {
 					if constexpr (INTYPE == IN_U16) {
 						const u32x4 c = __builtin_bit_cast(u32x4, buf_load128(haloR, u * 16, 0));
@@ -393,9 +406,9 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 			const __amdgpu_buffer_rsrc_t rawR1 = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)(line + 1u) * N * IN_BYTES, (PAIR && line + 1u < a.numLines) ? N * IN_BYTES : 0);
 #pragma unroll
 			for (int m = 0; m < LOADS; m++) {
-				if constexpr (INTYPE == IN_U16) w[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
-				else w[m] = buf_load64(rawR, lane * 8, m * 512);
-				if constexpr (PAIR) w1[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR1, lane * 4 + ((m * 256) & 4095), (m * 256) & ~4095, OCT_LOAD_AUX);
+				if constexpr (INTYPE == IN_U16) w[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR, lane * 4 + ((m * LN * 4) & 4095), (m * LN * 4) & ~4095, OCT_LOAD_AUX);
+				else w[m] = buf_load64(rawR, lane * 8, m * LN * 8);
+				if constexpr (PAIR) w1[m] = __builtin_amdgcn_raw_buffer_load_b32(rawR1, lane * 4 + ((m * LN * 4) & 4095), (m * LN * 4) & ~4095, OCT_LOAD_AUX);
 			}
 		}
 		if constexpr (PAIR) {
@@ -404,7 +417,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 			for (int m = 0; m < LOADS; m++) {
 				const uint32_t u0 = __builtin_bit_cast(uint32_t, w[m]), u1 = __builtin_bit_cast(uint32_t, w1[m]);
 				const float4 v = float4{(float)((u0 & 0xffffu) >> shift), (float)((u1 & 0xffffu) >> shift), (float)((u0 >> 16) >> shift), (float)((u1 >> 16) >> shift)};
-				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<float4*>(&rp[ROW_OFF + 2 * (lane + 64 * m)]) = v;
+				if ((m + 1) * LN <= HALF || lane + LN * m < HALF) *reinterpret_cast<float4*>(&rp[ROW_OFF + 2 * (lane + LN * m)]) = v;
 				if (RS == RS_CUBIC && m == 0 && lane == 0) rp[ROW_OFF - 1] = f2{v.z, v.w};  // n0 = |n1 - 1| mirror tap (cu:284): sample 1 of both rows
 			}
 		} else if constexpr (ROLL) {
@@ -450,12 +463,12 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 				f2 v;
 				if constexpr (INTYPE == IN_U16) v = f2{(float)((w[m] & 0xffffu) >> shift), (float)((w[m] >> 16) >> shift)};
 				else v = __builtin_bit_cast(f2, w[m]);
-				if ((m + 1) * 64 <= HALF || lane + 64 * m < HALF) *reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + 64 * m)]) = v;
+				if ((m + 1) * LN <= HALF || lane + LN * m < HALF) *reinterpret_cast<f2*>(&row[ROW_OFF + 2 * (lane + LN * m)]) = v;
 				if (RS == RS_CUBIC && m == 0 && lane == 0) row[ROW_OFF - 1] = v.y;  // n0 = |n1 - 1| mirror tap (cu:284): sample 1
 			}
 		}
 		}
-		wave_sync_lds();
+		team_sync<T>();
 		unsigned orow[2] = {line, line + 1u};
 		if (a.flip) {
 #pragma unroll
@@ -468,7 +481,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 		sink.out1 = make_rsrc(a.out + (size_t)orow[1] * HALF, (PAIR && line + 1u < a.numLines) ? HALF * 4 : 0);
 		sink.spec = make_rsrc(a.spectrum + (size_t)line * N, (MODE & MODE_SPECTRUM) ? N * 8 : 0);
 		passes_from<P, 0, RS, MODE, MEANN>(row, xb, twL, lutR, sink, mean, termL, lane);
-		wave_sync_lds();  // the last pass' reads of the slice precede the next row
+		team_sync<T>();  // the last pass' reads of the slice precede the next row
 	}
 }
 

@@ -8,7 +8,8 @@ namespace mxs {
 
 constexpr int MAXPASSES = 5;
 constexpr int MODE_PAIR = 16;        // MODE bit of the static-plan kernel only: two A-scans per transform (real FFT input; mixedn_static.h)
-constexpr int MXS_MAXN = 5120;       // longest length planned (N / 64 complex values per lane)
+constexpr int MXS_MAXN = 5120;       // longest length ONE wave holds (N / 64 complex values per lane)
+constexpr int MXS_MAXN_TEAM = 8192;  // longest length planned: beyond MXS_MAXN an A-scan belongs to a TEAM of two waves (N / 128 values per lane; round 6)
 constexpr int MXS_MAXVALUES = 80;    // values a lane may hold in a pass (idle butterfly slots included): 160 of its 256 registers
 struct PlanDesc {
 	int N, passes, radix[MAXPASSES];
@@ -24,13 +25,18 @@ struct PlanDesc {
 // 20 x 3 x 20 -- they rank behind the two-way radices)
 constexpr int pd_first_radix_rank(int r) { return (r == 10 || r == 14 || r == 11 || r == 13 || r == 15) ? 0 : (r == 20 || r == 12 || r == 6 || r == 7 || r == 5) ? 1 : r == 16 ? 3 : 2; }
 constexpr int pd_pad_for(int r0, int passes) { return (passes > 1 && (r0 == 8 || r0 == 16)) ? r0 : 0; }
+// Round 6: the even smooth lengths in 5120 < N <= 8192 -- until then the reference's own pass structure through hipFFT -- run the same
+// kernel with TWO waves per A-scan: butterfly b = teamLane + 128 it, every "64" of the one-wave mapping becomes pd_lanes, the in-place
+// exchanges are fenced with s_barrier instead of the wave's own issue order.  The team size is a function of N alone.
+constexpr int pd_team(const PlanDesc& d) { return d.N > MXS_MAXN ? 2 : 1; }
+constexpr int pd_lanes(const PlanDesc& d) { return 64 * pd_team(d); }
 constexpr int pd_ns(const PlanDesc& d, int p) { int s = 1; for (int i = 0; i < p; i++) s *= d.radix[i]; return s; }
 constexpr int pd_padp(const PlanDesc& d) { return d.padp; }
 constexpr int pd_xelems(const PlanDesc& d) { return d.N + (pd_padp(d) ? d.N / pd_padp(d) : 0); }
 constexpr int pd_tws(const PlanDesc& d, int p) { return (d.radix[p] - 1) | 1; }  // row pitch of pass p's twiddle table: odd
 constexpr int pd_twoff(const PlanDesc& d, int p) { int o = 0; for (int q = 1; q < p; q++) o += pd_ns(d, q) * pd_tws(d, q); return o; }
 constexpr int pd_twelems(const PlanDesc& d) { return pd_twoff(d, d.passes); }
-constexpr int pd_its(const PlanDesc& d, int p) { return (d.N / d.radix[p] + 63) / 64; }
+constexpr int pd_its(const PlanDesc& d, int p) { return (d.N / d.radix[p] + pd_lanes(d) - 1) / pd_lanes(d); }
 constexpr int pd_values(const PlanDesc& d) { int v = 0; for (int p = 0; p < d.passes; p++) { const int w = pd_its(d, p) * d.radix[p]; v = w > v ? w : v; } return v; }
 constexpr int pd_row_bytes(const PlanDesc& d) { return ((d.N + 2 * ROW_OFF) * 4 + 15) & ~15; }
 // (roll: the rolling average inside the kernel keeps a [ROLL_PAD | N | ROLL_PAD] array of prefix sums behind the staged row;
@@ -45,6 +51,15 @@ constexpr int pd_tw_bytes(const PlanDesc& d) { return (pd_twelems(d) * 8 + 15) &
 // cubic 16 waves 298 M A-scans/s (51 registers spilled), 12 waves 340 M, 8 waves 315 M; linear / none 464 / 420 / 362 M.
 constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bool pair = false) {
 	const int room = 160 * 1024 - pd_tw_bytes(d) - (bg ? d.N * 2 : 0);
+	if (pd_team(d) > 1) {
+		// teams: as many A-scans in flight as the LDS holds, at most two waves per SIMD (N / 128 <= 64 values per lane + tables of the gather: the
+		// 256-register budget; 0 when not even one slice fits)
+		int teams = room / pd_slice_bytes(d, roll, pair);
+		const int v = pd_values(d) + (rs == RS_CUBIC || rs == RS_LANCZOS ? 8 : 0) + (pair ? 4 : 0);
+		const int maxWaves = v <= 52 ? 8 : 4;  // (the one-wave rule below: 60 values and more spill at 256 registers)
+		if (teams > maxWaves / pd_team(d)) teams = maxWaves / pd_team(d);
+		return teams * pd_team(d);
+	}
 	int w = room / pd_slice_bytes(d, roll, pair);
 #ifdef OCT_MXS_WCAP
 	const int cap = OCT_MXS_WCAP;
@@ -56,7 +71,7 @@ constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bo
 	if (w > cap) w = cap;
 	return w;
 }
-constexpr int pd_lds_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false, bool pair = false) { return pd_tw_bytes(d) + waves * pd_slice_bytes(d, roll, pair) + (bg ? d.N * 2 : 0); }
+constexpr int pd_lds_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false, bool pair = false) { return pd_tw_bytes(d) + (waves / pd_team(d)) * pd_slice_bytes(d, roll, pair) + (bg ? d.N * 2 : 0); }
 
 }  // namespace mxs
 }  // namespace oct

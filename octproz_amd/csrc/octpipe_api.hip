@@ -80,6 +80,11 @@ int ensure(octpipe* h, void** p, size_t bytes) {
 // gather -> batched inverse C2C -> epilogue for `lines` A-scans of the prepared float32 buffer (cufftExecC2C cu:1514-1515)
 int launchLibFft(octpipe* h, const oct::FusedArgs& a, int rs, bool spectrum, bool logScale) {
 	const size_t lines = a.numLines, N = (size_t)h->N;
+	if (!h->fftExecC2C) {  // (deferred at creation: a length with a kernel compiled for it)
+		h->fftLazy = false;
+		const int brc = bindFftLibrary(h);
+		if (brc) return brc;
+	}
 	int rc = ensure(h, (void**)&h->d_cplx, sizeof(f2) * (size_t)h->A * h->B * N);
 	if (rc) return rc;
 	f2* work = spectrum ? a.spectrum : h->d_cplx;
@@ -273,7 +278,7 @@ oct::RouteFacts routeFacts(const octpipe* h) {
 	oct::RouteFacts f;
 	f.N = h->N; f.log2n = h->log2n; f.bytesPerSample = h->bytesPerSample; f.sampleFormat = h->sampleFormat;
 	f.bitDepth = h->acq.bitDepth; f.route = h->route; f.S = h->S;
-	f.libfft = h->libfft; f.fftLibBound = h->fftExecC2C != nullptr; f.bluestein = h->bluestein; f.mixed = h->mixed;
+	f.libfft = h->libfft; f.fftLibBound = h->fftExecC2C != nullptr || h->fftLazy; f.bluestein = h->bluestein; f.mixed = h->mixed;
 	f.mixedN = h->mixedN; f.mixedStatic = h->mixedStatic; f.teamTables = h->d_twTeam != nullptr && !h->mixed; f.forcePrepared = h->forcePrepared;
 	f.rowsLds = rowsKernelLds(h);
 	return f;
@@ -384,6 +389,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 			// this variant cannot be had now (the compiler or the module loader failed: nothing of it is cached).  A handle with
 			// another route for the length -- the run-time-plan kernel, the library FFT, Bluestein -- takes that one from here on and
 			// says why (octpipe_debug_rtc_status); only a handle without any fails the buffer
+			if (h->libfft && !h->fftExecC2C && h->fftLazy) { h->fftLazy = false; if (bindFftLibrary(h) != OCTPIPE_OK) (void)octpipe_last_error(); }
 			const bool otherRoute = h->mixedN || (h->libfft && h->fftExecC2C) || h->bluestein;
 			if (timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); h->timingCounter--; }  // (the retry counts this launch again)
 			if (!otherRoute) return fail(OCTPIPE_ERR_DEVICE, "run-time compilation of the kernel for samplesPerLine = " + std::to_string(h->N) + " failed: " + why);
@@ -774,7 +780,15 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 	oct::RouteFacts facts;
 	{
 		std::string why;
-		const int frc = oct::derive_route_facts(*acq, sampleFormat, createRoute, fftLibraryAvailable(), true, 0, &facts, &why);
+		// libhipfft.so is looked for only where a length can need it (round 6): not for the lengths with a dedicated kernel, and not -- yet --
+		// for those with a plan of the run-time compiled kernel (even, 2-3-5-7-11-13-smooth, up to 8192): there the library is bound by the first
+		// launch that takes the library route (hiprtc missing, a failed compilation, a test's route flag), or never
+		const unsigned n0 = acq->samplesPerLine;
+		const bool noKernel = !oct::fused_supported(n0) && n0 != oct::kMixedLength;
+		oct::mxs::PlanDesc probePlan{};
+		const bool planned = noKernel && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT | OCTPIPE_ROUTE_NO_MIXEDN_STATIC)) && oct::mixedn_rtc_plan(n0, &probePlan) && oct::mixedn_rtc_available(nullptr);
+		const bool fftAvailable = planned ? true : ((noKernel || (createRoute & OCTPIPE_ROUTE_FORCE_LIBFFT)) ? fftLibraryAvailable() : false);
+		const int frc = oct::derive_route_facts(*acq, sampleFormat, createRoute, fftAvailable, true, 0, &facts, &why);
 		if (frc) return fail(frc, why);
 	}
 	int count = 0;
@@ -851,7 +865,7 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 		for (int i = 0; i < 8; ++i) h->mxnRadix[i] = facts.mxnRadix[i];
 		if ((rc = uploadMixedNTable(h))) return rc;
 	}
-	// ... and, up to 4096, the static-plan kernel compiled for this very length at run time (mixedn_static.h, mixedn_rtc.hip), if hiprtc
+	// ... and, up to 8192, the static-plan kernel compiled for this very length at run time (mixedn_static.h, mixedn_rtc.hip), if hiprtc
 	// can be had in this process: a probe launch of zero A-scans compiles the most likely instance now, so that a process without a
 	// working hiprtc keeps its other route for the length and says why (octpipe_debug_rtc_status)
 	if (facts.mixedStatic) {  // (a plan exists; the probe says whether an instance of it can be had here)
@@ -881,7 +895,9 @@ int octpipe_debug_create(octpipe_t** out, int device, const OctPipeAcquisitionPa
 			h->rtcMessage = e == hipErrorNotSupported ? why : std::string(hipGetErrorString(e));
 		}
 	}
-	if (h->libfft) {
+	if (h->libfft && h->mixedStatic) {
+		h->fftLazy = true;  // (see above: bound by the first launch that needs it)
+	} else if (h->libfft) {
 		rc = bindFftLibrary(h);
 		// (with a mixed-radix plan only Lanczos needs the library, with a kernel compiled for the length nothing does: a variant that
 		// needs the library fails when it is asked for)

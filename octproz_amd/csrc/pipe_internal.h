@@ -107,6 +107,7 @@ struct octpipe {
 	bool libfft = false;       // no fused kernel for this length: gather -> hipFFT -> epilogue through a complex buffer (side_kernels.h)
 	f2* d_cplx = nullptr;      // libfft: [A*B][N] complex
 	void* fftLib = nullptr;
+	bool fftLazy = false;      // libhipfft.so not bound yet: the length runs a kernel compiled for it; bound on the first launch that needs the library route
 	int (*fftPlan1d)(void**, int, int, int) = nullptr;       // hipfftHandle is an opaque pointer
 	int (*fftSetStream)(void*, hipStream_t) = nullptr;
 	int (*fftExecC2C)(void*, void*, void*, int) = nullptr;

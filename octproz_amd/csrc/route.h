@@ -128,7 +128,8 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 	// length; plain uint16 rows directly (the compiled kernel also runs the rolling average itself), the rest through prepared rows
 	const bool mxnStatic = f.mixedStatic && !(route & OCTPIPE_ROUTE_NO_MIXEDN_STATIC);
 	const bool mxn = ((f.mixedN && rs != RS_LANCZOS) || mxnStatic) && !(route & OCTPIPE_ROUTE_NO_MIXEDN);
-	const bool mxnDirect = mxn && plain16 && (!roll || (rollInKernel && mxnStatic && rs != RS_LANCZOS));
+	// (the two-wave team form of that kernel, 5120 < N <= 8192: no rolling average inside -- prepared rows)
+	const bool mxnDirect = mxn && plain16 && (!roll || (rollInKernel && mxnStatic && rs != RS_LANCZOS && f.N <= mxs::MXS_MAXN));
 	int intype = IN_U16;
 	if (packedDirect) intype = f.sampleFormat == OCTPIPE_FORMAT_UINT12_PACKED ? IN_P12U : IN_P12S;
 	if (u8Direct) intype = IN_U8;
@@ -156,11 +157,11 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 		r.path |= OCTPIPE_PATH_FUSED_BG;
 	}
 	const bool realOk = intype == IN_U16 && rs != RS_LANCZOS && !roll && !disp && !sinusOk && !(route & OCTPIPE_ROUTE_NO_REAL_INPUT);  // real FFT input: two A-scans per transform
-	if (mxn && mxnStatic) {
+	if (mxn && mxnStatic && !teamLib) {  // (N = 8192: the dedicated team kernel keeps what it covers; the compiled kernel takes the rest, e.g. the spectrum)
 		r.kind = ROUTE_KIND_MXS;
 		r.path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_STATIC_PLAN | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
 		r.pair = realOk && !spectrum;
-	} else if (mxn) {
+	} else if (mxn && !teamLib) {
 		r.kind = ROUTE_KIND_MXN;
 		r.path |= OCTPIPE_PATH_MIXED_RADIX;
 	} else if (teamLib && team_real2_supported(f.log2n) && realOk) {
@@ -263,7 +264,7 @@ inline int derive_route_facts(const OctPipeAcquisitionParams& acq, int sampleFor
 	// tables fit the LDS (mixedn_plan); the library route / Bluestein stay for Lanczos and for every other length
 	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT)))
 		f.mixedN = mixedn_plan(n, &f.mxnPasses, f.mxnRadix, (createRoute & OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES) != 0);
-	// ... and, up to 5120, the static-plan kernel compiled for this very length at run time, if hiprtc can be had in this process
+	// ... and, up to 8192 (beyond 5120: two waves per A-scan), the static-plan kernel compiled for this very length at run time, if hiprtc can be had in this process
 	if (noFused && !(createRoute & (OCTPIPE_ROUTE_NO_MIXEDN | OCTPIPE_ROUTE_FORCE_LIBFFT | OCTPIPE_ROUTE_NO_MIXEDN_STATIC)) &&
 	    mixedn_rtc_plan(n, &f.mxsPlan, (createRoute & OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT) != 0))
 		f.mixedStatic = rtcAvailable;

@@ -52,7 +52,8 @@ ROUTING = [
     (8192, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),
     (8192, {"bitDepth": 16}, 4, 0, _P.PATH_TEAM | _P.PATH_PREPARED_ROWS),                      # int16 comes prepared at this length
     (8192, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_TEAM),
-    (8192, {"resamplingInterpolation": 2}, 0, _P.ROUTE_NO_TEAM, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
+    (8192, {"resamplingInterpolation": 2}, 0, _P.ROUTE_NO_TEAM, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),   # round 6: the compiled kernel on a team of two waves takes what the dedicated team kernel leaves
+    (8192, {"resamplingInterpolation": 2}, 0, _P.ROUTE_NO_TEAM | _P.ROUTE_NO_MIXEDN, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
     (8192, {"resamplingInterpolation": 2, "dispersionCompensation": 0}, 0, 0, _P.PATH_TEAM),
     (1664, {}, 0, 0, _P.PATH_TEAM),
     (1664, {"resamplingInterpolation": 0}, 0, 0, _P.PATH_MIXED_RADIX),
@@ -83,7 +84,15 @@ ROUTING = [
     (3000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                               # 20 x 15 x 10: beyond the run-time plan's 2304
     (3000, {}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),
     (5000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                               # 20 x 10 x 5 x 5: the longest lengths (<= 5120) run two A-scans per CU
-    (6000, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # beyond the registers of one wave
+    # 5120 < N <= 8192, even and 2-3-5-7-11-13-smooth (round 6): the same kernel on a TEAM of two waves per A-scan -- no hipFFT any more
+    (6000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                               # 15 x 20 x 20
+    (6144, {"dispersionCompensation": 0}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_REAL_INPUT),
+    (6144, {"resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),   # Lanczos
+    (6144, {"backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_PREPARED_ROWS),  # the team has no rolling average inside
+    (6144, {"postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_FUSED_BG),
+    (8000, {}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
+    (6000, {}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),     # ... the route of a process without hiprtc
+    (6002, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # 2 x 3001: a prime factor above 13 -- the library route that is left
     (1234, {}, 0, 0, _P.PATH_LIBRARY_FFT | _P.PATH_PREPARED_ROWS),                             # 2 x 617: no plan
 ]
 

@@ -366,7 +366,7 @@ MIXEDN_CASES = {
 
 
 MIXEDN_LENGTHS = [1000, 1200, 1536, 2000, 2304, 130, 182, 2002, 1260, 64, 48]
-MIXEDN_STATIC_ONLY = [2500, 3000, 4050, 5120]  # (4050 = 2 x 3^4 x 5^2: 15 x 15 x 9 has no radix 9 -> 15 x 15 x 6 x 3)
+MIXEDN_STATIC_ONLY = [2500, 3000, 4050, 5120, 5376, 6000, 6144, 8000]  # (4050 = 2 x 3^4 x 5^2: 15 x 15 x 9 has no radix 9 -> 15 x 15 x 6 x 3; beyond 5120: two waves per A-scan, round 6)
 
 
 # long lengths on five cases (the oracle's DFT is O(N^2)); the run-time plan (up to 2304; the route of a process without hiprtc) on six
@@ -393,8 +393,9 @@ def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case
     assert pipe.last_path() & _lib.PATH_MIXED_RADIX and not pipe.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_BLUESTEIN), hex(pipe.last_path())
     assert bool(pipe.last_path() & _lib.PATH_STATIC_PLAN) == (plan == "static"), (hex(pipe.last_path()), pipe.rtc_status())
     rolling = case.startswith("rolling")
-    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == ((rolling and plan == "runtime") or case == "lanczos_rolling_flip")
-    assert bool(pipe.last_path() & _lib.PATH_ROLL_IN_KERNEL) == (rolling and plan == "static")
+    team = N > 5120  # (the two-wave form of the compiled kernel takes its rolling average as prepared rows)
+    assert bool(pipe.last_path() & _lib.PATH_PREPARED_ROWS) == ((rolling and (plan == "runtime" or team)) or case == "lanczos_rolling_flip")
+    assert bool(pipe.last_path() & _lib.PATH_ROLL_IN_KERNEL) == (rolling and plan == "static" and not team)
     # (without dispersion compensation the run-time compiled kernel transforms two A-scans at once: real FFT input)
     assert bool(pipe.last_path() & _lib.PATH_REAL_INPUT) == (plan == "static" and not p.dispersionCompensation and not rolling), hex(pipe.last_path())
     p.postProcessBackgroundUpdated = True
@@ -528,8 +529,10 @@ def test_lengths_without_a_fused_kernel_take_the_library_fft_route(N, case):
 @pytest.mark.parametrize("variant", ["v180", "linear_flip_lin", "none_bitshift", "no_dispersion", "no_fpn_bg", "rolling", "rolling256_linear", "lanczos", "lanczos_rolling_flip"])
 def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B):
     """N = 8192: one A-scan per team of EIGHT waves (team_kernel.h: plan 16 x 16 x 16 x 2, three exchanges fenced with
-    s_barrier); OCTPIPE_ROUTE_NO_TEAM keeps the library route (gather -> hipFFT -> epilogue).  Both against the oracle's O(N^2)
-    float64 DFT and against each other; ragged line counts, a single line, more lines than persistent teams."""
+    s_barrier); OCTPIPE_ROUTE_NO_TEAM | NO_MIXEDN keeps the library route (gather -> hipFFT -> epilogue); OCTPIPE_ROUTE_NO_TEAM alone
+    the kernel compiled for the length on a team of TWO waves (round 6: what runs the spectrum of the mean-line estimate at this
+    length).  All three against the oracle's O(N^2) float64 DFT and against each other; ragged line counts, a single line, more lines
+    than persistent teams."""
     N = 8192
     p = v180_benchmark_params(N, A, B)
     p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
@@ -551,29 +554,41 @@ def test_team_kernel_of_8192_matches_oracle_and_the_library_route(variant, A, B)
     raw = synthetic_raw(N, A, B, seed=A + B, msb_aligned=bool(p.bitshift))
     o, pipe, d, want, got = run_both(p, raw)
     p.postProcessBackgroundUpdated = True
-    lib = Pipeline(p, device=0, route=_lib.ROUTE_NO_TEAM)
+    lib = Pipeline(p, device=0, route=_lib.ROUTE_NO_TEAM | _lib.ROUTE_NO_MIXEDN)
     if p.fixedPatternNoiseRemoval:
         lib.set_mean_line(o.mean_line(), pin=True)
     lib.process_device(d.data_ptr()); lib.synchronize()
     ref = lib.processed_host()
+    assert lib.last_path() & _lib.PATH_LIBRARY_FFT
+    p.postProcessBackgroundUpdated = True
+    mx = Pipeline(p, device=0, route=_lib.ROUTE_NO_TEAM)
+    if p.fixedPatternNoiseRemoval:
+        mx.set_mean_line(o.mean_line(), pin=True)
+    mx.process_device(d.data_ptr()); mx.synchronize()
+    two = mx.processed_host()
+    assert mx.last_path() & _lib.PATH_STATIC_PLAN and not mx.last_path() & (_lib.PATH_LIBRARY_FFT | _lib.PATH_TEAM), (hex(mx.last_path()), mx.rtc_status())
     if p.postProcessBackgroundRemoval:
-        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3
+        assert np.abs(got - want).max() < 1e-3 and np.abs(ref - want).max() < 1e-3 and np.abs(two - want).max() < 1e-3
         assert got.min() >= 0.0 and got.max() <= 1.0
     else:
         common.compare_images(ref, want, p, "library route %s" % variant, mean_line=o.mean_line())
         common.compare_images(got, want, p, "team kernel %s" % variant, mean_line=o.mean_line())
+        common.compare_images(two, want, p, "compiled kernel on two waves %s" % variant, mean_line=o.mean_line())
         common.compare_images(got, ref, p, "team vs library route %s" % variant, mean_line=o.mean_line())
     assert not np.array_equal(got, ref)
-    pipe.close(); lib.close(); o.close()
+    pipe.close(); lib.close(); mx.close(); o.close()
 
 
-def test_library_fft_route_determines_its_own_mean_line():
+@pytest.mark.parametrize("route", [0, _lib.ROUTE_NO_MIXEDN])
+def test_library_fft_route_determines_its_own_mean_line(route):
+    """N = 8192, mean line unpinned: the spectra of the estimate (cu:1518-1525) come from the kernel compiled for the length on a team of
+    two waves (round 6, default) or -- OCTPIPE_ROUTE_NO_MIXEDN, a process without hiprtc -- from the library route"""
     N, A, B = 8192, 24, 2
     p = v180_benchmark_params(N, A, B)
     p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N
     p.update_all_curves()
     raw = synthetic_raw(N, A, B, seed=81)
-    pipe = Pipeline(p, device=0)
+    pipe = Pipeline(p, device=0, route=route)
     d = to_device(raw)
     pipe.process_device(d.data_ptr()); pipe.synchronize()
     common.check_min_variance_mean(pipe.mean_line(), pipe.debug_spectrum(d.data_ptr(), A), N, "N=8192 mean line")

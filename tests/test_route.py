@@ -40,7 +40,7 @@ def test_routing_table_without_a_device(N, settings, fmt, flags, want):
 def test_kernel_family_per_length():
     """the family behind the path bits (route.h RouteKind) for the benchmark settings and the reference's defaults"""
     want = {256: ("fused", "real2n"), 512: ("fused", "real2n"), 1024: ("fused", "real2"), 2048: ("fused", "real2n"), 4096: ("team", "team_real2"), 8192: ("team", "team_real2"),
-            1664: ("team1664", "mixed1664_real2"), 1000: ("mxs", "mxs"), 3000: ("mxs", "mxs"), 6000: ("libfft", "libfft"), 1234: ("libfft", "libfft"), 16384: ("libfft", "libfft")}
+            1664: ("team1664", "mixed1664_real2"), 1000: ("mxs", "mxs"), 3000: ("mxs", "mxs"), 6000: ("mxs", "mxs"), 7168: ("mxs", "mxs"), 1234: ("libfft", "libfft"), 16384: ("libfft", "libfft")}
     for N, (with_disp, without) in want.items():
         assert route(params(N, {}))[2] == with_disp, N
         assert route(params(N, {"dispersionCompensation": 0}))[2] == without, N
@@ -66,7 +66,9 @@ def test_spectrum_launch_of_the_mean_line_estimate():
     assert route(params(1024, {}), spectrum=1)[2] == "fused"
     assert route(params(1024, {"dispersionCompensation": 0}), spectrum=1)[2] == "fused"      # no pairs: the spectra of single A-scans
     assert route(params(4096, {}), spectrum=1)[2] == "fused"
-    assert route(params(8192, {}), spectrum=1)[2] == "libfft"
+    assert route(params(8192, {}), spectrum=1)[2] == "mxs"                                    # round 6: the compiled kernel on a team of two waves (was: hipFFT)
+    assert route(params(8192, {}), spectrum=1, rtc=0)[2] == "libfft"
+    assert route(params(8192, {"resamplingInterpolation": 2}))[2] == "team"                   # the dedicated team kernel keeps its image variants
     assert route(params(1664, {}), spectrum=1)[2] == "mixed1664"
     assert route(params(1000, {}), spectrum=1)[1:3] == (_lib.PATH_MIXED_RADIX | _lib.PATH_STATIC_PLAN, "mxs")
     assert route(params(1000, {"dispersionCompensation": 0}), spectrum=1)[1] & _lib.PATH_REAL_INPUT == 0

@@ -37,7 +37,8 @@ needs_hiprtc = pytest.mark.skipif(not _hiprtc_present(), reason="libhiprtc.so is
 
 @needs_hiprtc
 @pytest.mark.parametrize("n,plan", [(1000, [10, 10, 10]), (2000, [10, 20, 10]), (1536, [12, 16, 8]), (3000, [15, 20, 10]), (4000, [20, 20, 10]),
-                                    (2500, [10, 5, 5, 10]), (2002, [13, 11, 14]), (130, [13, 10]), (24, [6, 4]), (5120, None), (5000, None)])
+                                    (2500, [10, 5, 5, 10]), (2002, [13, 11, 14]), (130, [13, 10]), (24, [6, 4]), (5120, None), (5000, None),
+                                    (6000, [15, 20, 20]), (6144, None), (7168, None), (8000, [20, 20, 20]), (8192, None)])  # beyond 5120: two waves per A-scan (round 6)
 def test_static_plan_kernel_compiles_for_gfx950_without_a_device(n, plan):
     rc, radices, waves, code, sec, err = _compile(n)
     assert rc == 0, err
@@ -80,6 +81,19 @@ def test_lanczos_instances_compile(n, intype):
 
 
 @needs_hiprtc
+@pytest.mark.parametrize("n", [6000, 6144, 8192])
+def test_team_instances_compile(n):
+    """5120 < N <= 8192: two waves per A-scan (mixedn_static_plan.h pd_team) -- raw and prepared rows, every resampling mode incl. Lanczos, spectrum,
+    background removal, two A-scans per transform; the rolling average inside the kernel is refused there (prepared rows carry it)"""
+    for intype, rs, mode in ((IN_U16, RS_CUBIC, MODE_LOG), (IN_F32, RS_LINEAR, MODE_LOG | MODE_BG), (IN_U16, RS_NONE, MODE_SPECTRUM), (IN_F32, 3, MODE_LOG),
+                             (IN_U16, RS_CUBIC, MODE_LOG | 16), (IN_U16, RS_NONE, 16)):
+        rc, radices, waves, code, sec, err = _compile(n, intype, rs, mode)
+        assert rc == 0 and waves >= 2 and waves % 2 == 0, (intype, rs, mode, err)
+    rc, radices, waves, code, sec, err = _compile(n, IN_U16, RS_CUBIC, MODE_LOG | 1)
+    assert rc != 0
+
+
+@needs_hiprtc
 @pytest.mark.parametrize("n", [48, 1000, 2304, 5120])
 @pytest.mark.parametrize("rs", [RS_NONE, RS_LINEAR, RS_CUBIC])
 def test_two_ascans_per_transform_instances_compile(n, rs):
@@ -89,9 +103,9 @@ def test_two_ascans_per_transform_instances_compile(n, rs):
         assert rc == 0 and waves >= 2, err
 
 
-@pytest.mark.parametrize("n", [1234, 4094, 1001, 6000, 8190, 7])
+@pytest.mark.parametrize("n", [1234, 4094, 1001, 6002, 8186, 8194, 9000, 7])
 def test_lengths_without_a_static_plan_are_refused(n):
-    """2 x 617, 2 x 23 x 89: a prime factor above 13; odd lengths (N / 2 bins); beyond 5120 / the registers of one wave"""
+    """2 x 617, 2 x 23 x 89, 2 x 3001, 2 x 4093: a prime factor above 13; odd lengths (N / 2 bins); beyond 8192 (the registers of a team of two waves)"""
     rc, radices, waves, code, sec, err = _compile(n)
     assert rc == 5 and "no static plan" in err, (rc, err)  # OCTPIPE_ERR_UNSUPPORTED
 
