@@ -56,7 +56,9 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 		launch_fused_args(kernel, dim3(blocks), dim3(threads), lds, stream, s);
 		return hipGetLastError();
 	}
-	const unsigned need = (a.numLines + waves - 1) / waves;
+	// (MODE_DISP: a wave takes OCT_DISP_BLOCK consecutive A-scans at a time)
+	constexpr unsigned perWave = (MODE & MODE_DISP) != 0 ? (unsigned)OCT_DISP_BLOCK : 1u;
+	const unsigned need = (a.numLines + waves * perWave - 1) / (waves * perWave);
 	if (blocks > need) blocks = need;
 	if (blocks == 0) return hipSuccess;
 	if (blocksUsed) *blocksUsed = (int)blocks;
@@ -83,8 +85,13 @@ hipError_t launch_out(bool spectrum, bool logScale, const FusedArgs& a, int rb, 
 	// rolling average
 	// display frames written by the image store (a.dispBscan / a.dispEnFace set: one frame each, cu:810-912 with displayFunctionFrames <= 1)
 	if (a.dispBscan || a.dispEnFace) {
-		if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_BG | MODE_DISP>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_BG | MODE_DISP>(a, rb, st, bu);
-		return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_DISP>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_DISP>(a, rb, st, bu);
+		// (route.h grants it up to N = 2048, not with the rolling average there: those variants spill registers -- ADVICE r5)
+		if constexpr (kLog2N <= 11 && !(ROLLBIT != 0 && kLog2N == 11)) {
+			if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_BG | MODE_DISP>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_BG | MODE_DISP>(a, rb, st, bu);
+			return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_DISP>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_DISP>(a, rb, st, bu);
+		} else {
+			return hipErrorInvalidValue;
+		}
 	}
 	if (a.bgTerm) return logScale ? launch_one<INTYPE, RS, ROLLBIT | MODE_LOG | MODE_BG>(a, rb, st, bu) : launch_one<INTYPE, RS, ROLLBIT | MODE_BG>(a, rb, st, bu);
 	if (logScale) return launch_one<INTYPE, RS, ROLLBIT | MODE_LOG>(a, rb, st, bu);

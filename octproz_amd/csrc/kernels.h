@@ -1431,6 +1431,22 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 #pragma unroll
 			for (int u = 0; u < RL / 2; u++) {
 				float o[NBL];
+				// MODE_SINUS: the previous row's values of these bins are requested BEFORE this row's are computed (their LDS round trip rides behind the
+				// logarithms instead of in front of the blend), and replaced by this row's afterwards
+				float pv[SINUS ? NBL : 1];
+				if constexpr (SINUS && SINUS_PREV_LDS) {
+					if constexpr (NBL % 4 == 0) {
+#pragma unroll
+						for (int m4 = 0; m4 < NBL / 4; m4++) {
+							const f32x4 t = *(reinterpret_cast<const f32x4*>(sPrevL) + ((u * (NBL / 4) + m4) * 64 + lane));
+							pv[4 * m4] = t.x; pv[4 * m4 + 1] = t.y; pv[4 * m4 + 2] = t.z; pv[4 * m4 + 3] = t.w;
+						}
+					} else {
+#pragma unroll
+						for (int m = 0; m < NBL; m++) pv[m] = sPrevL[(m + u * NBL) * 64 + lane];
+					}
+					__builtin_amdgcn_sched_barrier(0);  // (hipcc sinks the read to its use otherwise)
+				}
 #pragma unroll
 				for (int m = 0; m < NBL; m++) {
 					f2 z;
@@ -1441,25 +1457,16 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					o[m] = a.sA * s + a.sB;
 				}
 				if constexpr (SINUS) {
-					// the previous row's values of these bins <-> this row's; the blended A-scans of the pair (cu:506-510), then
-					// (MODE_BG) the removal that follows the correction in the reference's chain (cu:1557-1568)
-					float pv[NBL];
+					// the blended A-scans of the pair (cu:506-510), then (MODE_BG) the removal that follows the correction in the reference's
+					// chain (cu:1557-1568)
 					if constexpr (SINUS_PREV_LDS) {
 						if constexpr (NBL % 4 == 0) {
 #pragma unroll
-							for (int m4 = 0; m4 < NBL / 4; m4++) {
-								f32x4* q = reinterpret_cast<f32x4*>(sPrevL) + ((u * (NBL / 4) + m4) * 64 + lane);
-								const f32x4 t = *q;
-								*q = f32x4{o[4 * m4], o[4 * m4 + 1], o[4 * m4 + 2], o[4 * m4 + 3]};
-								pv[4 * m4] = t.x; pv[4 * m4 + 1] = t.y; pv[4 * m4 + 2] = t.z; pv[4 * m4 + 3] = t.w;
-							}
+							for (int m4 = 0; m4 < NBL / 4; m4++)
+								*(reinterpret_cast<f32x4*>(sPrevL) + ((u * (NBL / 4) + m4) * 64 + lane)) = f32x4{o[4 * m4], o[4 * m4 + 1], o[4 * m4 + 2], o[4 * m4 + 3]};
 						} else {
 #pragma unroll
-							for (int m = 0; m < NBL; m++) {
-								float* q = sPrevL + ((m + u * NBL) * 64 + lane);
-								pv[m] = *q;
-								*q = o[m];
-							}
+							for (int m = 0; m < NBL; m++) sPrevL[(m + u * NBL) * 64 + lane] = o[m];
 						}
 					} else {
 #pragma unroll

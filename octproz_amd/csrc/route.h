@@ -10,6 +10,9 @@
 // both without any device call, so the routing table of tests/test_route.py runs in the CPU suite (octpipe_debug_route) and the
 // GPU suite only has to confirm that the device took the route the function names (octpipe_debug_last_path).
 // launchFused (octpipe_api.hip) executes the plan: one switch over RoutePlan::kind.
+// Round 6: the library route (ROUTE_KIND_LIBFFT) is what runs ONLY odd lengths, lengths with a prime factor above 13 and lengths beyond 8192 --
+// and, in a process without libhiprtc.so, the lengths of the run-time compiled kernel beyond the run-time plan's 2304.  Every even
+// 2-3-5-7-11-13-smooth samplesPerLine up to 8192 has a hand-written transform.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -210,7 +213,7 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 		r.kind = ROUTE_KIND_FUSED;
 		r.path |= roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0;
 		r.launcherTimes = true;
-		if (wantDisp && !spectrum && !sinusOn && (!dispNeedsBgFused || r.bgFused)) {
+		if (wantDisp && !spectrum && !sinusOn && (!dispNeedsBgFused || r.bgFused) && f.log2n <= 11 && !(roll && f.log2n == 11)) {
 			r.dispFused = true;
 			r.path |= OCTPIPE_PATH_FUSED_DISPLAY;
 		}
