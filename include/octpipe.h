@@ -174,6 +174,13 @@ int octpipe_destroy(octpipe_t* h);
  * call destroys every idle set now -- e.g. before the host application resets the device.  Sets the runtime no longer
  * recognises (hipStreamQuery fails) are never handed out. */
 int octpipe_release_idle_streams(void);
+/* The variants of the run-time compiled kernels a handle can reach next are compiled on ONE background thread of the library.  This
+ * call stops it: what is still queued is dropped, the compilation under way is waited for (up to ~2 s), nothing is prefetched afterwards
+ * (a launch that needs a variant compiles it itself).  The library does the same from an atexit handler; a host should call it BEFORE it
+ * leaves main() (the Python layer does, from its own atexit hook): compiler libraries construct function-local statics during their first
+ * compilation, i.e. AFTER the library's handler was registered -- at process exit those are destroyed first, under a compilation that is
+ * still running.  Idempotent, callable from any thread but a callback. */
+int octpipe_shutdown(void);
 /* A-scan lengths without a dedicated kernel get a kernel compiled FOR the length at run time (0.5-1.2 s per variant, once per
  * process and device).  By default nothing is written to disk.  With a directory set here the compiled code
  * objects are also kept there -- one file per (kernel sources, options, architecture, plan, variant), written atomically,

@@ -119,7 +119,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_calibration_size", "octpipe_export_calibration", "octpipe_import_calibration",
     "octpipe_process", "octpipe_process_async", "octpipe_wait_input", "octpipe_process_device", "octpipe_synchronize",
     "octpipe_get_processed_device", "octpipe_copy_processed_to_host", "octpipe_get_stream", "octpipe_set_stream",
-    "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_release_idle_streams", "octpipe_set_kernel_cache_dir",
+    "octpipe_get_mean_line", "octpipe_set_mean_line", "octpipe_min_variance_mean", "octpipe_release_idle_streams", "octpipe_shutdown", "octpipe_set_kernel_cache_dir",
     "octpipe_register_streaming_buffers", "octpipe_unregister_streaming_buffers",
     "octpipe_register_float_streaming_buffers", "octpipe_unregister_float_streaming_buffers",
     "octpipe_set_callbacks",
@@ -237,6 +237,10 @@ def lib():
         L.octpipe_debug_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
         L.octpipe_debug_read_raw_slot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.octpipe_release_idle_streams.argtypes = []
+        L.octpipe_shutdown.argtypes = []
+        # (include/octpipe.h: stop the library's background compilation thread while every library it uses is still intact)
+        import atexit
+        atexit.register(L.octpipe_shutdown)
         L.octpipe_debug_last_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.octpipe_debug_last_path.argtypes = [C.c_void_p, C.c_void_p]
         L.octhost_system_set_copy_threads.argtypes = [C.c_void_p, C.c_uint]

@@ -146,6 +146,7 @@ bool mixedn_plan(unsigned n, int* passes, int* radix, bool simpleRadicesOnly = f
 // (hipErrorNotSupported + *why when that is impossible in this process)
 bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* d, bool oldLayout = false);
 bool mixedn_rtc_available(std::string* why);
+void mixedn_rtc_shutdown();  // stop the background compilation thread (octpipe_shutdown)
 void mixedn_static_twiddles(const mxs::PlanDesc& d, std::vector<f2>& tw);
 hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why, int maxBlocks = 0);
 int mixedn_rtc_compiled_count(double* seconds, std::string* lastMessage);

@@ -430,6 +430,8 @@ bool mixedn_rtc_plan(unsigned n, mxs::PlanDesc* out, bool oldLayout) {
 	return true;
 }
 
+void mixedn_rtc_shutdown() { shutdown_background(); }
+
 // whether libhiprtc.so can be had in this process (no compilation)
 bool mixedn_rtc_available(std::string* why) { return bindRtc(why); }
 

@@ -1159,6 +1159,10 @@ int octpipe_debug_read_raw_slot(octpipe_t* h, int slot, void* dst, size_t bytes)
 	HIP_TRY(hipStreamSynchronize(h->copyStream));
 	return downloadSync(h, dst, h->d_raw[slot], bytes);
 }
+int octpipe_shutdown(void) {
+	oct::mixedn_rtc_shutdown();
+	return OCTPIPE_OK;
+}
 int octpipe_release_idle_streams(void) {
 	std::map<int, std::vector<IdleStreams>> byDevice;
 	{
