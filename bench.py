@@ -61,7 +61,7 @@ def parse_args(argv=None):
                     "launch costs the stream 2-4 us, i.e. the measurement itself would take 2 %% off the step rate it is reported next to")
     ap.add_argument("--blocks", type=int, default=8, help="after the timed region: this many more blocks of --steps steps, alternately with and without the per-launch HIP events, "
                     "reported as medians next to the contract's single timed block (a 20-step block is 3 ms: box noise is +-2-4 %%)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the host_loop, real_input and rolling_average records (A/B runs, profiler passes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host_loop, real_input, rolling_average and north_star_chain records (A/B runs, profiler passes)")
     ap.add_argument("--host-loop-seconds", type=float, default=3.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
     ap.add_argument("--group", action="store_true",
@@ -636,6 +636,21 @@ def main():
                                   "roofline_frac": (4.0 * N * A * B / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rms > 0 else None,
                                   "what": "same workload, v1.8.0 settings plus the rolling-average DC removal (cu:165-211, W = 64) inside the fused kernel"}
         rp.close()
+        # (i'') ... and the whole chain north_star spells out: rolling background subtraction + B-scan flip + sinusoidal-scan reorder.  Since
+        # round 6 the reorder happens inside the fused kernel's image store where that kernel runs the length (MODE_SINUS; `path` says so)
+        q = v180_benchmark_params(N, A, B, buffers_per_volume=slots)
+        q.backgroundRemoval, q.rollingAverageWindowSize, q.bscanFlip, q.sinusoidalScanCorrection = 1, 64, 1, 1
+        q.update_all_curves()
+        rp = Pipeline(q, device=local_rank)
+        rp.process_device(vols[0].data_ptr()); rp.synchronize()
+        rdt, rms, rl = timed_run(rp, vols, max(args.steps, 200), 5, min(args.warmup_seconds, 0.5))
+        from octproz_amd import _lib as _l2
+        out["north_star_chain"] = {"value": A * B * max(args.steps, 200) / rdt, "unit": "A-scans/s", "kernel_ms": rms,
+                                   "roofline_frac": (4.0 * N * A * B / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rms > 0 else None,
+                                   "sinusoidal_correction_in_the_store": bool(rp.last_path() & _l2.PATH_FUSED_SINUS),
+                                   "what": "same workload, v1.8.0 settings plus rolling-average DC removal (W = 64), B-scan flip and sinusoidal scan correction "
+                                           "(cu:165-211, cu:787-807, cu:491-514): every stage north_star names, one kernel per buffer"}
+        rp.close()
         # (ii) the host loop incl. H2D, the reference's own metric definition
         if args.host_loop_seconds > 0:
             try:
@@ -648,7 +663,7 @@ def main():
         out["cpu_baseline"] = None
         out["cpu_baseline_note"] = "timed on rank 0 of the N = 1 run only" if ranks > 1 else "skipped (--no-cpu-baseline)"
         if ranks > 1:
-            out["extras_note"] = "real_input / rolling_average / host_loop records belong to the N = 1 run"
+            out["extras_note"] = "real_input / rolling_average / north_star_chain / host_loop records belong to the N = 1 run"
 
     if distributed:
         dist.barrier()

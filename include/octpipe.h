@@ -336,9 +336,12 @@ int octpipe_group_copy_processed_to_host(octpipe_group_t* g, float* dst /* S/2 f
 
 /* ------------------------------------------------------------------ measurement helper
  * Average duration in ms of the dominant (fused) kernel since the last reset, measured with HIP
- * events on the handle's own stream around each launch when timing is enabled (enable = 1), or around every n-th
- * launch (enable = n > 1: a timed launch costs the stream 2-4 us on MI355X, profiles/r5f_fold_flush16_ab.txt). */
+ * events on the handle's own stream around each launch while timing is enabled (enable != 0: a boolean).
+ * octpipe_set_kernel_timing_stride(h, n): only every n-th launch carries events from then on (a timed launch costs the stream 2-4 us on
+ * MI355X, profiles/r5f_fold_flush16_ab.txt); n = 1 (the default after every enable) times each launch.  (Until round 5 `enable = n > 1`
+ * meant the stride: a caller passing any non-zero value as a boolean silently got sparse timing -- ADVICE r5.) */
 int octpipe_enable_kernel_timing(octpipe_t* h, int enable);
+int octpipe_set_kernel_timing_stride(octpipe_t* h, unsigned everyNth);
 int octpipe_kernel_timing(octpipe_t* h, double* avgMs, unsigned* launches, int reset);
 
 #ifdef __cplusplus

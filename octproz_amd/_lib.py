@@ -125,7 +125,7 @@ OCTPIPE_SYMBOLS = [
     "octpipe_set_callbacks",
     "octpipe_change_displayed_bscan_frame", "octpipe_change_displayed_enface_frame", "octpipe_get_display_buffers",
     "octpipe_get_volume_view_buffer", "octpipe_register_gl_buffer_bscan", "octpipe_register_gl_buffer_enface_view", "octpipe_register_gl_buffer_volume_view",
-    "octpipe_enable_kernel_timing", "octpipe_kernel_timing",
+    "octpipe_enable_kernel_timing", "octpipe_set_kernel_timing_stride", "octpipe_kernel_timing",
     "octpipe_group_create", "octpipe_group_create_ex", "octpipe_group_destroy", "octpipe_group_size", "octpipe_group_member", "octpipe_group_slab",
     "octpipe_group_set_submit_threads", "octpipe_group_info", "octpipe_group_serial_submit_count",
     "octpipe_group_backend", "octpipe_group_broadcast_count", "octpipe_group_last_error", "octpipe_group_set_params",
@@ -278,6 +278,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.octhost_processing_run_group.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]
         L.octpipe_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        L.octpipe_set_kernel_timing_stride.argtypes = [C.c_void_p, C.c_uint]
         L.octpipe_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.octpipe_polynomial_curve.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
         L.octpipe_resample_curve.argtypes = [C.c_float] * 4 + [C.c_uint, C.c_void_p]

@@ -1071,7 +1071,12 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// have followed those loads in every later iteration -- vmcnt(3) instead of vmcnt(11), i.e. a wait for stores issued a moment ago.
 	prologue_wait();
 	while (line < lineEnd) {
-		if constexpr (SINUS) sE2 = sinE[sI2];  // (two A-scans ahead of its use)
+		// OCT_SINUS_LOAD_AT (experiment switch): where the scalar load of the entry two A-scans ahead is issued -- 0: at the top of the iteration
+		// (default), 1: between the gather and the transform.  While it is in flight every LDS wait of the wave is a full lgkmcnt(0).
+#ifndef OCT_SINUS_LOAD_AT
+#define OCT_SINUS_LOAD_AT 0
+#endif
+		if constexpr (SINUS && OCT_SINUS_LOAD_AT == 0) sE2 = sinE[sI2];  // (two A-scans ahead of its use)
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
 			bool staged = false;
@@ -1374,6 +1379,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 		wave_sync_lds();  // the row is dead from here on; its LDS is reused by the FFT
 
+		if constexpr (SINUS && OCT_SINUS_LOAD_AT == 1) sE2 = sinE[sI2];
 		// ---- inverse FFT
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_FFT);
 		// N = 1024: a fifth priority point behind the reads of the transform's one LDS exchange.  Gather 3 > first pass 2 > rest of the
@@ -1472,6 +1478,13 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 #pragma unroll
 						for (int m = 0; m < NBL; m++) { pv[m] = sPrevR[m + u * NBL]; sPrevR[m + u * NBL] = o[m]; }
 					}
+#ifdef OCT_SINUS_TIMING_ONE_STORE  // (timing experiment, wrong image: every row stored once, unblended -- what the blend + the variable store count cost)
+					{
+#pragma unroll
+						for (int m = 0; m < NBL; m++) store_image<BG>(o[m] + pv[m] * 0.0f, outR, termL, lane * 4, (64 * m + u * (N / RL)) * 4);
+						continue;
+					}
+#endif
 					if (sSt0) {
 #pragma unroll
 						for (int m = 0; m < NBL; m++) store_image<BG>(sinus_blend(pv[m], o[m], sF0), outR, termL, lane * 4, (64 * m + u * (N / RL)) * 4);

@@ -1346,7 +1346,13 @@ int octpipe_register_gl_buffer_volume_view(unsigned) { return fail(OCTPIPE_ERR_U
 int octpipe_enable_kernel_timing(octpipe_t* h, int enable) {
 	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
 	h->timing = enable != 0;
-	h->timingStride = enable > 1 ? (unsigned)enable : 1u;  // enable = n > 1: every n-th launch only (the events cost 2-4 us per timed launch)
+	h->timingStride = 1u;
+	h->timingCounter = 0;
+	return OCTPIPE_OK;
+}
+int octpipe_set_kernel_timing_stride(octpipe_t* h, unsigned everyNth) {
+	if (!h) return fail(OCTPIPE_ERR_INVALID_ARGUMENT, "null handle");
+	h->timingStride = everyNth > 1u ? everyNth : 1u;  // (the events cost 2-4 us per timed launch)
 	h->timingCounter = 0;
 	return OCTPIPE_OK;
 }

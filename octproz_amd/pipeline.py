@@ -251,7 +251,9 @@ class Pipeline:
 
     def enable_kernel_timing(self, on=True, every=1):
         """HIP events around the dominant kernel of every launch (`every` = n > 1: of every n-th launch only)"""
-        check(self._lib.octpipe_enable_kernel_timing(self._h, (max(1, int(every)) if on else 0)))
+        check(self._lib.octpipe_enable_kernel_timing(self._h, 1 if on else 0))
+        if on and int(every) > 1:
+            check(self._lib.octpipe_set_kernel_timing_stride(self._h, int(every)))
 
     def kernel_timing(self, reset=True):
         ms, n = C.c_double(), C.c_uint()
