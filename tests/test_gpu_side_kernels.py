@@ -142,6 +142,36 @@ def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_o
     post.close()
 
 
+def test_sinusoidal_correction_in_the_store_with_several_buffers_per_volume():
+    """the in-store correction writes the volume SLOT of the buffer (cu:1530-1535): three buffers of a two-slot volume, each slot holds the
+    oracle's pass over the same kernel's uncorrected image of the buffer that went there last"""
+    N, A, B = 1024, 70, 3
+    p = v180_benchmark_params(N, A, B, buffers_per_volume=2)
+    _grey(p)
+    p.fixedPatternNoiseRemoval, p.bscanFlip = 0, 1
+    raws = [synthetic_raw(N, A, B, seed=40 + i) for i in range(3)]
+    devs = [_dev(r) for r in raws]
+    plain = Pipeline(p, device=0)
+    imgs = []
+    for d in devs:
+        plain.process_device(d.data_ptr()); plain.synchronize()
+        imgs.append(plain.processed_host().copy())  # (the slot written last)
+    plain.close()
+    p.sinusoidalScanCorrection = 1
+    pipe = Pipeline(p, device=0)
+    for d in devs:
+        pipe.process_device(d.data_ptr())
+    pipe.synchronize()
+    assert pipe.last_path() & _lib.PATH_FUSED_SINUS
+    W = N // 2
+    # buffers 0, 1, 2 went to slots 1, 0, 1 (bufferNumberInVolume starts at bpv - 1, cu:1530)
+    for slot, k in ((0, 1), (1, 2)):
+        want = octref.sinusoidal(imgs[k].copy(), W, A, B)
+        got = pipe.processed_host(slot=slot)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (slot, k)
+    pipe.close()
+
+
 @pytest.mark.parametrize("sinus", [0, 1])
 def test_background_recording_uses_the_corrected_first_bscan_and_fills_the_host_shadow_before_the_callback(sinus):
     N, A, B = 512, 16, 3

@@ -83,3 +83,21 @@ def test_isa_sequence_tool_reads_the_same_file(asm):
     import isa_sequence
     seq = isa_sequence.sequence(asm, "oct_fused_kernelILi10ELi1ELi2ELi4EE")
     assert "P3" in seq and "P2" in seq and seq.count("r") >= 40
+
+
+def test_in_store_sinusoidal_variants_have_no_scratch_and_read_their_work_list_with_scalar_loads(asm):
+    """MODE_SINUS (round 6): the four image variants of the N = 1024 cubic kernel and the four with the rolling average fit their register
+    budget without scratch, and the work-list entries arrive by s_load_dwordx4 (constant address space) -- not by a vector load per lane"""
+    text = open(asm).read()
+    for mode in (32, 36, 40, 44, 33, 37, 41, 45):
+        name = "_ZN3oct16oct_fused_kernelILi10ELi1ELi2ELi%dEEEvNS_9FusedArgsE" % mode
+        assert name + ":" in text, "MODE %d is not instantiated" % mode
+        start = text.index(name + ":")
+        end = text.index("s_endpgm", start)
+        meta = text[end:end + 20000]
+        assert int(re.search(r"; ScratchSize: (\d+)", meta).group(1)) == 0, mode
+        assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 256, mode
+        body = text[start:end]
+        assert len(re.findall(r"\bs_load_dwordx4\b", body)) >= 3, "work-list entries are not read with scalar loads (mode %d)" % mode
+        # the correction's blend is never contracted into an FMA with the difference: v_sub, v_mul, v_add per value (cu:506-510 bit for bit)
+        assert "v_sub_f32" in body and "v_mul_f32" in body
