@@ -164,8 +164,8 @@ def test_sinusoidal_correction_in_the_store_with_several_buffers_per_volume():
     pipe.synchronize()
     assert pipe.last_path() & _lib.PATH_FUSED_SINUS
     W = N // 2
-    # buffers 0, 1, 2 went to slots 1, 0, 1 (bufferNumberInVolume starts at bpv - 1, cu:1530)
-    for slot, k in ((0, 1), (1, 2)):
+    # buffers 0, 1, 2 went to slots 0, 1, 0 (bufferNumberInVolume starts at bpv - 1 and is advanced in front of the chain, cu:1530-1532)
+    for slot, k in ((0, 2), (1, 1)):
         want = octref.sinusoidal(imgs[k].copy(), W, A, B)
         got = pipe.processed_host(slot=slot)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (slot, k)
