@@ -300,6 +300,59 @@ q.close()
     assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".co")]) == n0
 
 
+def test_hipfft_is_bound_by_the_first_launch_that_needs_it_and_shutdown_is_survivable():
+    """Round 6: a length with a kernel compiled for it (here 3000 and 6144) does not look for libhipfft.so when the handle is created; a route
+    flag set LATER that asks for the library route binds it then, and the image agrees with the compiled kernel's.  octpipe_shutdown() stops
+    the background compilation thread (include/octpipe.h): afterwards a variant that was never prefetched is compiled by the launch that
+    needs it, and the process exits cleanly while nothing compiles behind its back.  In a child process: both are process-wide."""
+    code = r"""
+import sys, ctypes as C, numpy as np
+from octproz_amd import Pipeline, _lib, synthetic_raw, v180_benchmark_params   # (no torch in this process: libtorch_hip.so links libhipfft.so itself)
+sys.path.insert(0, sys.argv[1])
+import common
+L = _lib.lib()
+hip = C.CDLL("libamdhip64.so")
+class Dev:
+    def __init__(self, a):
+        self.p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(self.p), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(self.p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+    def data_ptr(self):
+        return self.p.value
+def mapped():
+    return any("hipfft" in l for l in open("/proc/self/maps"))
+assert "torch" not in sys.modules
+for N in (3000, 6144):
+    A, B = 24, 2
+    p = v180_benchmark_params(N, A, B); p.c0, p.c1, p.c2, p.c3 = 0.5, 0.85 * N, -0.17 * N, 0.09 * N; p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=N)
+    d = Dev(np.ascontiguousarray(raw))
+    q = Pipeline(p, device=0)
+    q.process_device(d.data_ptr()); q.synchronize()
+    assert q.last_path() & _lib.PATH_STATIC_PLAN, q.rtc_status()
+    if N == 3000:
+        assert not mapped(), "libhipfft.so was loaded for a length that runs a kernel compiled for it"
+    ml, img = q.mean_line(), q.processed_host()
+    q.set_mean_line(ml, pin=True)
+    q.set_route(_lib.ROUTE_NO_MIXEDN)
+    q.process_device(d.data_ptr()); q.synchronize()
+    assert q.last_path() & _lib.PATH_LIBRARY_FFT and mapped()
+    common.compare_images(img, q.processed_host(), p, "compiled kernel vs library route bound late, N=%d" % N, mean_line=ml)
+    q.set_route(0)
+    if N == 6144:
+        assert L.octpipe_shutdown() == 0 and L.octpipe_shutdown() == 0
+        p.signalLogScaling, p.signalGrayscaleMax, p.signalGrayscaleMin = 0, 900.0, 0.0   # a variant nobody compiled yet
+        p.resamplingInterpolation = 0
+        q.process_device(d.data_ptr()); q.synchronize()
+        assert q.last_path() & _lib.PATH_STATIC_PLAN and np.isfinite(q.processed_host()).all()
+    q.close()
+print("RESULT ok")
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code, os.path.dirname(os.path.abspath(__file__))], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "RESULT ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2500:])
+
+
 def test_a_failed_run_time_compilation_is_reported_and_survivable():
     """csrc/mixedn_rtc.hip: (1) a handle whose probe instance does not compile keeps its other HIP route for the length and says why
     (octpipe_debug_rtc_status) -- its images are still the oracle's; (2) round 5: a handle that HAS a run-time compiled
