@@ -32,15 +32,18 @@ DB_FLOOR = 1e-6
 # comparison does not resolve: a bin at 1e-6 of the line maximum in power may be off by 1 % in amplitude, not by 1000 %.
 # Round 5: the bound follows the transform length instead of sitting 4 % above the largest value ever measured (9.6e-6 in a
 # 1500-seed run against a flat 1e-5): a float32 FFT's rounding error grows like eps x log2 N relative to the line's largest
-# amplitude, so AMP_RTOL(N) = 2e-6 x log2 N -- 1.1e-5 at N = 48, 2.0e-5 at 1024, 2.4e-5 at 4096 -- about 17 eps per pass, twice the
+# amplitude, so AMP_RTOL(N) = 2e-6 x log2 N (round 6: 1.5e-6 x log2 N, see below) -- 1.1e-5 at N = 48, 2.0e-5 at 1024, 2.4e-5 at 4096 -- about 17 eps per pass, twice the
 # measured maxima; beyond N = 4096 the round-4 rule 1e-5 x N / 4096 (found at 8192 / 16384 on the library route) still applies
 # where it is the larger one.  The ledger reports the measured maximum and the largest measured / allowed ratio.
 AMP_RTOL = 1e-5  # (the value at N = 32: the floor of amp_rtol below; kept under its old name for the tests that quote it)
 
 
+AMP_RTOL_PER_PASS = 1.5e-6  # round 6: 2e-6 until then; the advisor's 1e-6 would fail draws of the recorded 2 480-draw run (largest: 1.40e-6 x log2 N)
+
+
 def amp_rtol(n):
     n = int(n)
-    return max(2e-6 * np.log2(max(n, 32)), 1e-5 * n / 4096.0)
+    return max(AMP_RTOL_PER_PASS * np.log2(max(n, 32)), 1e-5 * n / 4096.0)
 
 
 # A float32 IMAGE cannot carry an amplitude more finely than one unit in its last place: with linear scaling, a grey-scale range much
@@ -54,10 +57,12 @@ IMAGE_ULPS = 4.0
 #   * the ulp allowance is handed over only by the draws it was found on (8-bit containers with linear scaling, tests/test_gpu_fuzz.py);
 #   * the 'cancelled' rule has a buffer-wide cap again, next to the per-line one, and it counts the DC-lobe bins too (CANCEL_FRAC,
 #     DC_LOBE_MAX_BINS);
-#   * the amplitude bound keeps its form (2e-6 x log2 N: the 2 480-draw run of round 5 measured 0.70 of it, so the 1e-6 x log2 N the
-#     advisor proposed would fail draws that passed), but a DRIFT ALARM sits under it: a test session whose largest measured / allowed
-#     ratio exceeds AMP_DRIFT_ALARM fails (tests/conftest.py), i.e. a kernel change that costs a quarter of a bit shows before it costs one.
-AMP_DRIFT_ALARM = 0.85
+#   * the amplitude bound keeps its form and is tightened from 2e-6 to 1.5e-6 x log2 N (1.5e-5 at N = 1024): the 2 480-draw run of round 5
+#     measured 0.70 of the old bound = 0.94 of this one (every recorded draw passes; the 1e-6 x log2 N the advisor proposed would fail
+#     draws that passed), and a DRIFT ALARM sits under it: a test session of the standard size (no OCT_FUZZ_* override; the GPU suite
+#     measures 0.41 of the bound) whose largest measured / allowed ratio exceeds AMP_DRIFT_ALARM fails (tests/conftest.py), i.e. a kernel
+#     change that costs half a bit shows before it costs one.  Long randomised hunts (OCT_FUZZ_SEEDS=1000 ...) have only the bound itself.
+AMP_DRIFT_ALARM = 0.6
 
 
 def ulp_amplitude_of_image(img, p):

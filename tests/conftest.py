@@ -58,6 +58,11 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def _standard_size():
+    """no OCT_FUZZ_* override in the environment: the session draws the standard number of randomised cases"""
+    return not any(k.startswith("OCT_FUZZ_") for k in os.environ)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """drift alarm of the amplitude bound (tests/common.py AMP_DRIFT_ALARM): the session fails when the largest measured / allowed ratio
     of its image comparisons has crept up to the bound, before a draw fails it"""
@@ -65,7 +70,7 @@ def pytest_sessionfinish(session, exitstatus):
         import common
     except Exception:
         return
-    if common.LEDGER["calls"] and common.LEDGER["max_amp_over_allowed"] > common.AMP_DRIFT_ALARM and session.exitstatus == 0:
+    if _standard_size() and common.LEDGER["calls"] and common.LEDGER["max_amp_over_allowed"] > common.AMP_DRIFT_ALARM and session.exitstatus == 0:
         session.exitstatus = 1
 
 
@@ -83,9 +88,9 @@ def pytest_terminal_summary(terminalreporter):
     tr.write_sep("-", "tolerance ledger (tests/common.py compare_images)")
     tr.write_line("%d image comparisons (%d strict), %d bins; every bin under the linear-power bound: max %.3e of the line maximum (bound %.0e)" % (
         L["calls"], L["strict_calls"], L["bins"], L["max_rel"], common.POWER_RTOL))
-    tr.write_line("every bin under the amplitude bound: max %.3e of the line's largest amplitude (bound 2e-6 x log2 N, or 1e-5 x N/4096 beyond 4096: 2.0e-5 at N = 1024); "
+    tr.write_line("every bin under the amplitude bound: max %.3e of the line's largest amplitude (bound 1.5e-6 x log2 N, or 1e-5 x N/4096 beyond 4096: 1.5e-5 at N = 1024); "
                   "largest measured / allowed: %.3f" % (L["max_amp"], L["max_amp_over_allowed"]))
-    if L["max_amp_over_allowed"] > common.AMP_DRIFT_ALARM:
+    if _standard_size() and L["max_amp_over_allowed"] > common.AMP_DRIFT_ALARM:
         tr.write_line("DRIFT ALARM: largest measured / allowed amplitude error %.3f > %.2f -- the session is marked failed (tests/common.py AMP_DRIFT_ALARM)" % (L["max_amp_over_allowed"], common.AMP_DRIFT_ALARM), red=True)
     tr.write_line("normalised dB compared on %d bins (%.4f %% of all): max %.3e (bound %.0e)" % (
         L["db_checked"], 100.0 * L["db_checked"] / max(1, L["bins"]), L["max_db"], common.DB_ATOL))
