@@ -37,8 +37,8 @@ enum {
 	OCTPIPE_ERR_NOT_INITIALIZED = 2,   /* reference: "Cuda: Device buffers are not initialized!" cu:1391-1394 */
 	OCTPIPE_ERR_OUT_OF_MEMORY = 3,     /* reference: initializeCuda returns false, cu:975-1015 */
 	OCTPIPE_ERR_DEVICE = 4,            /* any HIP runtime error (reference: checkCudaErrors -> exit) */
-	OCTPIPE_ERR_UNSUPPORTED = 5,       /* e.g. samplesPerLine outside 8..65536 (fused kernels: 256..4096 and 1664; Bluestein: other lengths
-	                                      up to 2047; everything else through hipFFT, loaded at run time) */
+	OCTPIPE_ERR_UNSUPPORTED = 5,       /* e.g. samplesPerLine outside 8..65536 (dedicated kernels: 256..8192 and 1664; every other even 2-3-5-7-11-13-smooth
+	                                      length up to 8192: a kernel compiled for it at run time; the rest through hipFFT, loaded at run time, or Bluestein up to 2047) */
 	OCTPIPE_ERR_NO_DEVICE = 6,         /* no HIP device: the product path never falls back to a CPU */
 	OCTPIPE_ERR_IN_CALLBACK = 7        /* a device-touching entry point was called from inside a data / event callback (see below) */
 };
