@@ -1224,6 +1224,67 @@ def test_full_size_config2_1024x512x256():
     _full_size(1024, 512, 256)
 
 
+@pytest.mark.parametrize("settings", [dict(), dict(backgroundRemoval=1, rollingAverageWindowSize=64, bscanFlip=1)], ids=["v180", "north_star_chain"])
+def test_full_size_sinusoidal_correction_in_the_store_1024x512x256(settings):
+    """BASELINE's buffer with the sinusoidal scan correction on (and, second case, every stage north_star names): the correction inside the
+    fused kernel's image store (round 6: one kernel, rows the correction never reads are not computed) against the post-pass route
+    (OCTPIPE_ROUTE_NO_FUSED_SINUS: scratch slot + gather pass, cu:1551-1554) -- the two are different code paths that must agree BIT FOR
+    BIT on all 131 072 output A-scans; idempotent; and the oracle's pass (cu:491-514) on the kernel's own uncorrected image of a whole B-scan
+    block at both ends of the buffer (incl. the buffer's last A-scan, which the reference leaves uncorrected)"""
+    import ctypes
+    import torch
+    from oracle import octref
+    from octproz_amd.virtual_oct import synthetic_raw_torch
+    N, A, B = 1024, 512, 256
+    W = N // 2
+
+    def params(sinus):
+        q = v180_benchmark_params(N, A, B)
+        for k, v in settings.items():
+            setattr(q, k, v)
+        q.sinusoidalScanCorrection = sinus
+        q.update_all_curves()
+        return q
+    d = synthetic_raw_torch(N, A, B, torch.device("cuda:0"), seed=77)
+    torch.cuda.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def device_image(pipe):
+        ptr, _, nr = pipe.processed_device()
+        t = torch.empty((B * A, W), dtype=torch.float32, device=d.device)
+        assert hip.hipMemcpy(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(ptr + nr * B * A * W * 4), ctypes.c_size_t(t.numel() * 4), 3) == 0
+        return t
+    plain = Pipeline(params(0), device=0)
+    plain.process_device(d.data_ptr()); plain.synchronize()
+    mean = plain.mean_line()
+    img = device_image(plain)
+    plain.close()
+    store = Pipeline(params(1), device=0)
+    store.set_mean_line(mean, pin=True)
+    store.process_device(d.data_ptr()); store.synchronize()
+    assert store.last_path() & _lib.PATH_FUSED_SINUS
+    got = device_image(store)
+    store.process_device(d.data_ptr()); store.synchronize()
+    assert torch.equal(device_image(store).view(torch.int32), got.view(torch.int32)), "not idempotent"
+    store.close()
+    post = Pipeline(params(1), device=0, route=_lib.ROUTE_NO_FUSED_SINUS)
+    post.set_mean_line(mean, pin=True)
+    post.process_device(d.data_ptr()); post.synchronize()
+    assert not post.last_path() & _lib.PATH_FUSED_SINUS
+    ref = device_image(post)
+    post.close()
+    diff = (got.view(torch.int32) != ref.view(torch.int32)).any(dim=1)
+    assert not bool(diff.any()), "rows that differ between the store and the post pass: %s" % torch.nonzero(diff).flatten()[:16].tolist()
+    # the oracle's pass on whole B-scans of the uncorrected image (the correction never leaves its B-scan for A > 2): first two, last two
+    for b0 in (0, B - 2):
+        part = img[b0 * A:(b0 + 2) * A].cpu().numpy().reshape(-1).copy()
+        want = octref.sinusoidal(part, W, A, 2)
+        have = got[b0 * A:(b0 + 2) * A].cpu().numpy().reshape(-1)
+        if b0 != B - 2:  # (inside the buffer the last A-scan of the block IS corrected -- its pair lies inside its own B-scan -- the oracle called on a 2-B-scan block leaves it)
+            want, have = want[:-W], have[:-W]
+        assert np.array_equal(have.view(np.uint32), want.view(np.uint32)), "B-scans %d..%d differ from the oracle's pass on the kernel's own image" % (b0, b0 + 1)
+
+
 def test_full_size_real_input_kernel_1024x512x256():
     """the same buffer on the reference's default-style settings (no dispersion compensation): real-input kernel,
     sharded == unsharded bit for bit (pairs never straddle a slab), idempotent, oracle on sampled B-scans.
