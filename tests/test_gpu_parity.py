@@ -373,6 +373,8 @@ MIXEDN_STATIC_ONLY = [2500, 3000, 4050, 5120, 5376, 6000, 6144, 8000]  # (4050 =
 # lengths and without Lanczos (its kernel leaves that to the library route)
 @pytest.mark.parametrize("N,case,plan", [(N, case, plan) for plan in ("static", "runtime") for N in MIXEDN_LENGTHS + MIXEDN_STATIC_ONLY for case in MIXEDN_CASES
                                          if not (N > 1600 and case not in ("v180", "lin_scale_flip", "no_fpn_bg", "rolling256_linear", "lanczos"))
+                                         # (the two-wave lengths: all five on 6144, two on 6000 / 8000, one on 5376 -- the oracle's O(N^2) DFT sets the suite's run time there)
+                                         and not (N in (6000, 8000) and case not in ("v180", "rolling256_linear")) and not (N == 5376 and case != "v180")
                                          and not (plan == "runtime" and (N not in (1000, 1536, 2304, 130, 2002, 64) or case.startswith("lanczos")))])
 def test_generic_mixed_radix_kernel_matches_oracle_and_the_library_route(N, case, plan):
     """plan = static: mixedn_static.h, the kernel compiled for the length at run time (hiprtc, mixedn_rtc.hip) -- one wave per A-scan,
