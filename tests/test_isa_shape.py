@@ -101,3 +101,14 @@ def test_in_store_sinusoidal_variants_have_no_scratch_and_read_their_work_list_w
         assert len(re.findall(r"\bs_load_dwordx4\b", body)) >= 3, "work-list entries are not read with scalar loads (mode %d)" % mode
         # the correction's blend is never contracted into an FMA with the difference: v_sub, v_mul, v_add per value (cu:506-510 bit for bit)
         assert "v_sub_f32" in body and "v_mul_f32" in body
+
+
+def test_display_fold_variants_of_the_headline_object_have_no_scratch(asm):
+    """MODE_DISP (the opt-in display frames from the image store, OCTPIPE_ROUTE_FUSED_DISPLAY): ADVICE r5 found variants that spill at N = 2048 /
+    4096 -- those are no longer instantiated (fused_inst.hip, route.h); the ones of this object stay inside their register budget"""
+    text = open(asm).read()
+    for mode in (16, 20, 24, 28, 17, 21, 25, 29):
+        name = "_ZN3oct16oct_fused_kernelILi10ELi1ELi2ELi%dEEEvNS_9FusedArgsE" % mode
+        assert name + ":" in text, "MODE %d is not instantiated" % mode
+        end = text.index("s_endpgm", text.index(name + ":"))
+        assert int(re.search(r"; ScratchSize: (\d+)", text[end:end + 20000]).group(1)) == 0, mode
