@@ -172,6 +172,35 @@ def test_sinusoidal_correction_in_the_store_with_several_buffers_per_volume():
     pipe.close()
 
 
+def test_sinusoidal_correction_toggled_between_buffers_of_one_handle():
+    """the GUI's checkbox between two buffers (octalgorithmparameters.cpp setters): one handle switched off -> on (store) -> on + flip ->
+    post-pass route -> off gives, buffer by buffer, what a fresh handle with those settings gives (no state of the in-store walk survives
+    a buffer, the scratch slot of the post pass does not leak into the store route)"""
+    N, A, B = 1024, 48, 4
+    p = v180_benchmark_params(N, A, B)
+    _grey(p)
+    p.fixedPatternNoiseRemoval = 0
+    d = _dev(synthetic_raw(N, A, B, seed=5))
+    steps = [dict(sinusoidalScanCorrection=0), dict(sinusoidalScanCorrection=1), dict(sinusoidalScanCorrection=1, bscanFlip=1),
+             dict(sinusoidalScanCorrection=1, bscanFlip=1, _route=_lib.ROUTE_NO_FUSED_SINUS), dict(sinusoidalScanCorrection=0, bscanFlip=1),
+             dict(sinusoidalScanCorrection=1, bscanFlip=0, backgroundRemoval=1, rollingAverageWindowSize=16)]
+    pipe = Pipeline(p, device=0)
+    for st in steps:
+        route = st.pop("_route", 0)
+        for k, v in st.items():
+            setattr(p, k, v)
+        pipe.set_route(route)
+        pipe.process_device(d.data_ptr()); pipe.synchronize()
+        got = pipe.processed_host()
+        assert bool(pipe.last_path() & _lib.PATH_FUSED_SINUS) == bool(p.sinusoidalScanCorrection and not route), (st, hex(pipe.last_path()))
+        import copy
+        fresh = Pipeline(copy.copy(p), device=0, route=route)
+        fresh.process_device(d.data_ptr()); fresh.synchronize()
+        assert np.array_equal(fresh.processed_host().view(np.uint32), got.view(np.uint32)), st
+        fresh.close()
+    pipe.close()
+
+
 @pytest.mark.parametrize("sinus", [0, 1])
 def test_background_recording_uses_the_corrected_first_bscan_and_fills_the_host_shadow_before_the_callback(sinus):
     N, A, B = 512, 16, 3
