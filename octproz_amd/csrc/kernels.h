@@ -813,6 +813,79 @@ OCT_DEV float sinus_blend(float f0, float f1, float frac) {
 	return f0 + t;
 }
 
+// The walk over the work list of MODE_SINUS as an object, for the kernels beside oct_fused_kernel that run the correction in their store
+// (team_kernel.h; oct_fused_kernel keeps its own, identical, hand-inlined copy -- its code generation is pinned by tests/test_isa_shape.py).
+// Everything is wave-uniform and lives in scalar registers; entries arrive by scalar loads through the constant address space, two A-scans
+// ahead of their use: e0 = the entry of the row being processed (its pair is written by the epilogue), e1 = the next one (its raw row is
+// prefetched meanwhile), e2 = in flight.  `units` = walkers in the grid (waves, or teams): walker w takes blocks w, w + units, ...
+struct SinusWalk {
+	typedef const __attribute__((address_space(4))) u32x4 ent_t;
+	ent_t* ent;
+	unsigned M, total, blk, A, lines, units;
+	int flip;
+	unsigned sBlk, sT, sTEnd, sI2, sBA, sBA0, sBB, next;
+	bool sFl;
+	u32x4 e0, e1, e2;
+	OCT_DEV bool flipped(unsigned bb) const { return flip && (bb & 1u) == 0u && (bb + 2u) * A <= lines; }  // (flipped_row's rule)
+	OCT_DEV unsigned row(unsigned ba, bool fl, uint32_t x) const { const unsigned pp = x & 0xffffu; return ba + (fl ? A - 1u - pp : pp); }
+	OCT_DEV unsigned wrap(unsigned i) const { return i + 1u == M ? 0u : i + 1u; }
+	OCT_DEV bool valid() const { return sBlk * blk + 1u < total; }
+	// the raw line of the first entry of block sBlk; the following two entries under way
+	OCT_DEV unsigned enter() {
+		const unsigned g0 = sBlk * blk, last = total - 1u;
+		sTEnd = min(blk, last - g0);
+		sT = 0;
+		const unsigned bb = g0 / M, i0 = g0 - bb * M, i1 = wrap(i0);
+		e0 = ent[i0];
+		e1 = ent[i1];
+		sI2 = wrap(i1);
+		sBA0 = bb * A;
+		sBB = i1 == 0u ? bb + 1u : bb;
+		sBA = sBB * A;
+		sFl = flipped(sBB);
+		return row(sBA0, flipped(bb), e0.x);
+	}
+	// first line of the walker `first` (0xFFFFFFFF: it has no block)
+	OCT_DEV unsigned begin(const FusedArgs& a, unsigned first, unsigned unitsInGrid) {
+		ent = reinterpret_cast<ent_t*>(reinterpret_cast<uintptr_t>(a.sinEnt));
+		M = a.sinM; total = a.sinTotal; blk = a.sinBlk; A = a.ascansPerBscan; lines = a.linesInBuffer; flip = a.flip; units = unitsInGrid;
+		sBlk = first; sT = sTEnd = sI2 = sBA = sBA0 = sBB = 0; next = 0xFFFFFFFFu; sFl = false;
+		e0 = e1 = e2 = u32x4{0u, 0u, 0u, 0u};
+		return valid() ? enter() : 0xFFFFFFFFu;
+	}
+	OCT_DEV void load_ahead() { e2 = ent[sI2]; }                                                       // top of an iteration
+	OCT_DEV unsigned peek_next() { next = sT < sTEnd ? row(sBA, sFl, e1.x) : 0xFFFFFFFFu; return next; }  // the line whose raw row is prefetched now
+	// the step behind an iteration: the next line (0xFFFFFFFF: none), *newBlock = its raw row has NOT been prefetched
+	OCT_DEV unsigned advance(bool* newBlock) {
+		*newBlock = false;
+		if (sT < sTEnd) {
+			sT++;
+			e0 = e1; sBA0 = sBA;
+			e1 = e2;
+			if (sI2 == 0u) { sBB++; sBA += A; sFl = flipped(sBB); }
+			sI2 = wrap(sI2);
+			return next;
+		}
+		sBlk += units;
+		if (!valid()) return 0xFFFFFFFFu;
+		*newBlock = true;
+		return enter();
+	}
+	// what the entry of the current row says: first output row of the pair (previous row, this row), its blend fractions, which of the
+	// two stores happen, and whether this row is the buffer's last A-scan (stored as it is: the reference's launch bound)
+	OCT_DEV unsigned out_row() const { return sBA0 + (e0.x >> 16); }
+	OCT_DEV void pair(float* f0, float* f1, bool* st0, bool* st1, bool* raw) const {
+		const uint32_t b0 = e0.y, b1 = e0.z;  // (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)
+		*f0 = __builtin_bit_cast(float, b0);
+		*f1 = __builtin_bit_cast(float, b1);
+		const unsigned r0 = out_row();
+		const bool p = sT > 0u && *f0 >= 0.0f;
+		*st0 = p && r0 + 1u != lines;
+		*st1 = p && *f1 >= 0.0f && r0 + 2u != lines;
+		*raw = sBA0 + (e0.x & 0xffffu) + 1u == lines;
+	}
+};
+
 // INTYPE: IN_U16 (raw, the hot configuration) or IN_F32 (samples prepared by oct_prepare_kernel:
 // uint8 / uint32 input and everything in front of the Lanczos variant).
 // RS: resampling mode (RS_*).  MODE: MODE_ROLL = rolling-average DC removal inside the kernel

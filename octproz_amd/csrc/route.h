@@ -149,13 +149,17 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 	// whose register budget it exceeds).  It outranks the real-input kernels: one kernel at ~0.9 x the rate of the general kernel
 	// against a faster kernel + a post pass that moves 12 bytes per output sample (N = 1024 without dispersion: 634 M A-scans/s that way).
 	const bool sinusOn = p.sinusoidalScanCorrection != 0;
-	const bool sinusOk = sinusOn && sinusPlan && !spectrum && !(route & OCTPIPE_ROUTE_NO_FUSED_SINUS) && !f.bluestein && !f.libfft && !f.mixed && !f.teamTables &&
-	                     f.N == (1 << f.log2n) && f.log2n >= 8 && f.log2n <= 11 && rs != RS_LANCZOS && intype == IN_U16 &&
-	                     !(roll && rs == RS_CUBIC && (f.log2n == 9 || f.log2n == 11));
+	const bool sinusWanted = sinusOn && sinusPlan && !spectrum && !(route & OCTPIPE_ROUTE_NO_FUSED_SINUS) && rs != RS_LANCZOS && intype == IN_U16;
+	const bool sinusGeneral = sinusWanted && !f.bluestein && !f.libfft && !f.mixed && !f.teamTables && f.N == (1 << f.log2n) && f.log2n >= 8 && f.log2n <= 11 &&
+	                          !(roll && rs == RS_CUBIC && (f.log2n == 9 || f.log2n == 11));
+	// ... and the team kernels of N = 4096 / 8192 (team_kernel.h MODE_SINUS; not cubic resampling together with the rolling average: registers)
+	const bool sinusTeam = sinusWanted && f.teamTables && !f.mixed && !(route & OCTPIPE_ROUTE_NO_TEAM) && (teamLib || !f.libfft) && !(roll && rs == RS_CUBIC);
+	const bool sinusOk = sinusGeneral || sinusTeam;
 	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
 	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
 	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
-	if (wantBg && (!sinusOn || sinusOk) && !spectrum && (!f.libfft || teamLib || mxn) && (useMixed || !f.bluestein || mxn)) {
+	// (N = 8192 with the correction in the store: the background term does not fit the LDS next to the previous row -- post pass)
+	if (wantBg && (!sinusOn || (sinusOk && !(sinusTeam && f.log2n >= 13))) && !spectrum && (!f.libfft || teamLib || mxn) && (useMixed || !f.bluestein || mxn)) {
 		r.bgFused = true;
 		r.path |= OCTPIPE_PATH_FUSED_BG;
 	}
@@ -174,6 +178,7 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 	} else if (teamLib) {
 		r.kind = ROUTE_KIND_TEAM;
 		r.path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
+		if (sinusTeam) { r.sinusFused = true; r.path |= OCTPIPE_PATH_FUSED_SINUS; }
 	} else if (f.libfft) {
 		r.kind = ROUTE_KIND_LIBFFT;
 		r.path |= OCTPIPE_PATH_LIBRARY_FFT;
@@ -205,6 +210,7 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 		// N = 4096: one A-scan per team of four waves; every raw container the general kernel reads directly and the prepared rows
 		r.kind = ROUTE_KIND_TEAM;
 		r.path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
+		if (sinusTeam) { r.sinusFused = true; r.path |= OCTPIPE_PATH_FUSED_SINUS; }
 	} else if ((f.log2n == 10 || real2n_supported(f.log2n)) && realOk && !spectrum) {
 		r.kind = f.log2n == 10 ? ROUTE_KIND_REAL2 : ROUTE_KIND_REAL2N;
 		r.pair = true;
@@ -217,12 +223,14 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 			r.dispFused = true;
 			r.path |= OCTPIPE_PATH_FUSED_DISPLAY;
 		}
-		if (sinusOk) {
+		if (sinusGeneral) {
 			r.sinusFused = true;
 			r.path |= OCTPIPE_PATH_FUSED_SINUS;
 		}
 	}
 	if (r.pair) r.path |= OCTPIPE_PATH_REAL_INPUT;
+	// (the removal follows the correction, cu:1551-1568: never inside the store in front of a correction that runs as the post pass)
+	if (sinusOn && r.bgFused && !r.sinusFused) { r.bgFused = false; r.path &= ~(unsigned)OCTPIPE_PATH_FUSED_BG; }
 	r.intype = intype;
 	r.roll = roll;
 	return r;

@@ -21,6 +21,20 @@ hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
 	hipError_t e = kernel_launch_info(kernel, Team<LOG2N>::LANES, lds, &info);
 	if (e != hipSuccess) return e;
 	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);  // persistent teams: 256 VGPRs per lane -> 8 waves per CU
+	if constexpr ((MODE & MODE_SINUS) != 0) {
+		// the work list of the buffer in blocks of sinBlk + 1 entries, one block per team by default (fused_inst.hip launch_one: the same rule)
+		if (a.sinTotal < 2 || a.sinM == 0 || a.sinEnt == nullptr) return hipErrorInvalidValue;
+		FusedArgs s = a;
+		const unsigned pairs = a.sinTotal - 1u, perTeam = a.sinBlk ? a.sinBlk : 1u;
+		unsigned len = (pairs + perTeam * blocks - 1u) / (perTeam * blocks);
+		if (len < 8u) len = pairs < 8u ? pairs : 8u;
+		if (len > 63u) len = 63u;
+		s.sinBlk = len;
+		const unsigned listBlocks = (pairs + len - 1u) / len;
+		if (blocks > listBlocks) blocks = listBlocks;
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(Team<LOG2N>::LANES), lds, stream, s);
+		return hipGetLastError();
+	}
 	if (blocks > a.numLines) blocks = a.numLines;
 	if (blocks == 0) return hipSuccess;
 	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(Team<LOG2N>::LANES), lds, stream, a);
@@ -28,6 +42,26 @@ hipError_t launch_team_one(const FusedArgs& a, hipStream_t stream) {
 }
 template <int LOG2N, int RS>
 hipError_t launch_team_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (a.sinEnt) {  // sinusoidal scan correction inside the image store (MODE_SINUS; route.h grants it for raw uint16 rows, not with Lanczos)
+		if constexpr (kIn == IN_U16 && LOG2N >= 12 && RS != RS_LANCZOS) {
+			// (N = 8192: the background term and the previous row together do not fit the LDS next to the mean line: route.h leaves the removal to the post pass there)
+			if (roll) {  // (not with cubic resampling: those variants would spill registers)
+				if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
+				if constexpr (RS != RS_CUBIC) {
+					if (a.bgTerm) {
+						if constexpr (LOG2N <= 12) return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL | MODE_BG | MODE_SINUS>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL | MODE_BG | MODE_SINUS>(a, stream);
+						else return hipErrorInvalidValue;
+					}
+					return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_ROLL | MODE_SINUS>(a, stream) : launch_team_one<LOG2N, RS, MODE_ROLL | MODE_SINUS>(a, stream);
+				} else return hipErrorInvalidValue;
+			}
+			if (a.bgTerm) {
+				if constexpr (LOG2N <= 12) return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_BG | MODE_SINUS>(a, stream) : launch_team_one<LOG2N, RS, MODE_BG | MODE_SINUS>(a, stream);
+				else return hipErrorInvalidValue;
+			}
+			return logScale ? launch_team_one<LOG2N, RS, MODE_LOG | MODE_SINUS>(a, stream) : launch_team_one<LOG2N, RS, MODE_SINUS>(a, stream);
+		} else return hipErrorInvalidValue;
+	}
 	if (roll) {  // rolling average inside the team: uint16 rows (in front of Lanczos the host prepares the rows)
 		if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
 		if constexpr (kIn == IN_U16 && LOG2N >= 12 && RS != RS_LANCZOS) {

@@ -99,8 +99,11 @@ template <int STRIDE> OCT_DEV void team_read16(f2 (&v)[16], const f2* base) {
 #endif
 }
 constexpr int TEAM_ROLL_BYTES = 256;  // wave totals of the in-team rolling average: [chunk][wave], at most 4 x 16
+// (MODE_SINUS, round 6: the previous row's N / 2 grey values of the team behind the background term; the rolling average's scratch stays last)
+template <int LOG2N, int MODE> constexpr int team_sinus_bytes() { return (MODE & 32 /* MODE_SINUS */) ? (1 << LOG2N) * 2 : 0; }
 template <int LOG2N, int MODE> constexpr int team_lds_bytes() {
-	return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + Team<LOG2N>::MEAN_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>() + ((MODE & 1 /* MODE_ROLL */) ? TEAM_ROLL_BYTES : 0);
+	return Team<LOG2N>::ROW_BYTES + Team<LOG2N>::X_BYTES + Team<LOG2N>::MEAN_BYTES + bg_lds_bytes<MODE, (1 << LOG2N)>() + team_sinus_bytes<LOG2N, MODE>() +
+	       ((MODE & 1 /* MODE_ROLL */) ? TEAM_ROLL_BYTES : 0);
 }
 
 // LDS traffic of the team's waves is ordered by s_barrier; only the LDS counter is drained in front of it (a __syncthreads()
@@ -200,6 +203,10 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	typedef Team<LOG2N> TM;
 	constexpr int N = TM::N, P = TM::P, T = TM::LANES, R3 = TM::R3, NB3 = TM::NB3, NBINS = 8;
 	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, FOUR = TM::FOUR, ROLL = (MODE & MODE_ROLL) != 0;
+	// MODE_SINUS (round 6): the sinusoidal scan correction inside the image store, as in oct_fused_kernel (kernels.h: the team walks blocks of the
+	// work list, keeps the previous row's grey values in LDS and writes the blended A-scans of every pair it completes)
+	constexpr bool SINUS = (MODE & MODE_SINUS) != 0;
+	static_assert(!(SINUS && RS == RS_LANCZOS), "sinusoidal correction in the store: not with Lanczos");
 	static_assert(!ROLL || INTYPE == IN_U16, "in-team rolling average: uint16 rows");
 	static_assert((N + 2 * ROLL_PAD) * 4 <= TM::X_BYTES, "the prefix array borrows the exchange buffer");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	f2* meanL = reinterpret_cast<f2*>(smem + TM::ROW_BYTES + TM::X_BYTES);
 	const float* termL = reinterpret_cast<const float*>(smem + TM::ROW_BYTES + TM::X_BYTES + TM::MEAN_BYTES);
 	const int L = threadIdx.x;  // 0 .. T-1: "lane" of the team
+	float* sPrevL = reinterpret_cast<float*>(smem + TM::ROW_BYTES + TM::X_BYTES + TM::MEAN_BYTES + bg_lds_bytes<MODE, N>()) + L;  // value k of the lane at sPrevL[k T]
 	if constexpr (BG) fill_bg_term(reinterpret_cast<float*>(smem + TM::ROW_BYTES + TM::X_BYTES + TM::MEAN_BYTES), a.bgTerm, N / 2, L, T);
 	if constexpr (FOUR) {
 		for (int i = L; i < N / 2; i += T) meanL[i] = a.subtractMean ? a.meanLine[i] : f2{0.0f, 0.0f};
@@ -266,6 +274,8 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	const unsigned rowBytes = (unsigned)(N / SPL) * CB;
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 	unsigned line = blockIdx.x;
+	SinusWalk sw;
+	if constexpr (SINUS) line = sw.begin(a, blockIdx.x, gridDim.x);  // (every wave of the team walks the same list: uniform over the workgroup)
 	// Lanczos: 16-byte units of the window [off - 8, off + N + 8) of the buffer, off = clamp(line N, 8, S - 9) (cu:313-314), through a
 	// descriptor that ends with the buffer (reads past it return 0; N x element size and 16 are multiples of 16: aligned)
 	constexpr int SPU = INTYPE == IN_U16 ? 8 : 4, UNITS = (N + 16) / SPU, NLZ = (UNITS + T - 1) / T;
@@ -296,7 +306,8 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 	f2* wb2 = xbuf + (256 * (L >> 4) + (L & 15));            // pass 2 output 256 (L >> 4) + (L & 15) + 16 u at wb2[16 u]
 
 	if constexpr (LOG2N == 12) prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop; N = 4096 +2.5 %, N = 8192 -1.2 %: profiles/r5ah_*)
-	for (; line < a.numLines; line += gridDim.x) {
+	while (line < a.numLines) {
+		if constexpr (SINUS) sw.load_ahead();
 		// ---- stage the raw row as float32 (cu:119-121 / 139-141), minus the rolling average (cu:165-211)
 		if constexpr (ROLL) {
 			team_roll_stage<T, N, NL>(pre, shift, a.rollingW, reinterpret_cast<uint32_t*>(xbuf),
@@ -326,7 +337,11 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 				}
 			}
 		}
-		if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
+		{
+			unsigned nxt;
+			if constexpr (SINUS) nxt = sw.peek_next(); else nxt = line + gridDim.x;
+			if (nxt < a.numLines) prefetch(nxt);
+		}
 		team_barrier();  // the row is complete
 
 		// ---- k-linearisation x window x dispersion phasor
@@ -422,18 +437,38 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 
 		// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address (as in the general kernel)
 		unsigned orow = line;
-		if (a.flip) {
+		if constexpr (SINUS) {
+			orow = sw.out_row();
+		} else if (a.flip) {
 			const unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
 			if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
 		}
 		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
+		// MODE_SINUS: the pair (previous row, this row) of the work list: blended output A-scans orow and orow + 1 (cu:506-510, sinus_blend), the
+		// buffer's last A-scan as it is; every value goes through store_image, i.e. through the background removal that follows the correction
+		float sF0 = 0.0f, sF1 = 0.0f;
+		bool sSt0 = false, sSt1 = false, sRaw = false;
+		__amdgpu_buffer_rsrc_t outR1 = outR, outRL = outR;
+		if constexpr (SINUS) {
+			sw.pair(&sF0, &sF1, &sSt0, &sSt1, &sRaw);
+			outR1 = make_rsrc(a.out + (size_t)(orow + 1u) * (N / 2), N * 2u);
+			outRL = make_rsrc(a.out + (size_t)(a.linesInBuffer - 1u) * (N / 2), N * 2u);
+		}
+		auto sinus_store = [&](float o, int k, int vbase, int c) {  // value k of the lane (bin at byte vbase + c of the row)
+			const float pv = sPrevL[k * T];
+			sPrevL[k * T] = o;
+			if (sSt0) store_image<BG>(sinus_blend(pv, o, sF0), outR, termL, vbase, c);
+			if (sSt1) store_image<BG>(sinus_blend(pv, o, sF1), outR1, termL, vbase, c);
+			if (sRaw) store_image<BG>(o, outRL, termL, vbase, c);
+		};
 		if constexpr (FOUR) {
 #pragma unroll
 			for (int m = 0; m < 8; m++) {
 				const f2 z = v[m] - meanL[L + T * m];
 				const float p = z.x * z.x + z.y * z.y;
 				const float s = LOGSCALE ? __builtin_amdgcn_logf(p) : __builtin_amdgcn_sqrtf(p);
-				store_image<BG>(a.sA * s + a.sB, outR, termL, L * 4, T * m * 4);
+				if constexpr (SINUS) sinus_store(a.sA * s + a.sB, m, L * 4, T * m * 4);
+				else store_image<BG>(a.sA * s + a.sB, outR, termL, L * 4, T * m * 4);
 			}
 		} else
 #pragma unroll
@@ -447,9 +482,19 @@ __global__ __launch_bounds__(Team<LOG2N>::LANES, 2) void oct_team_kernel(const F
 				o[m] = a.sA * s + a.sB;
 			}
 #pragma unroll
-			for (int m = 0; m < NB3; m++) store_image<BG>(o[m], outR, termL, L * 4, (T * m + 256 * u) * 4);
+			for (int m = 0; m < NB3; m++) {
+				if constexpr (SINUS) sinus_store(o[m], m + NB3 * u, L * 4, (T * m + 256 * u) * 4);
+				else store_image<BG>(o[m], outR, termL, L * 4, (T * m + 256 * u) * 4);
+			}
 		}
 		__builtin_amdgcn_s_setprio(0);
+		if constexpr (SINUS) {
+			bool newBlock;
+			line = sw.advance(&newBlock);
+			if (newBlock && line < a.numLines) prefetch(line);  // (inside a block the row was prefetched while its predecessor was staged)
+		} else {
+			line += gridDim.x;
+		}
 	}
 }
 

@@ -27,7 +27,15 @@ ROUTING = [
     (2048, {"sinusoidalScanCorrection": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_ROLL_IN_KERNEL),  # cubic + rolling at 2048: registers
     (512, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 0}, 0, 0, _P.PATH_FUSED_SINUS),
     (256, {"sinusoidalScanCorrection": 1, "resampling": 0}, 0, 0, _P.PATH_FUSED_SINUS),
-    (4096, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM),                                                              # team kernel + post pass
+    (4096, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),                                        # inside the team kernel's store too (round 6)
+    (4096, {"sinusoidalScanCorrection": 1, "dispersionCompensation": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),           # outranks the real-input team kernel + post pass
+    (4096, {"sinusoidalScanCorrection": 1, "postProcessBackgroundRemoval": 1, "resamplingInterpolation": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0,
+     _P.PATH_TEAM | _P.PATH_FUSED_SINUS | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
+    (4096, {"sinusoidalScanCorrection": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_ROLL_IN_KERNEL),  # cubic + rolling average: registers -> post pass
+    (4096, {"sinusoidalScanCorrection": 1}, 0, _P.ROUTE_NO_FUSED_SINUS, _P.PATH_TEAM),
+    (4096, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 2}, 0, 0, _P.PATH_TEAM),                                # Lanczos: post pass
+    (8192, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),
+    (8192, {"sinusoidalScanCorrection": 1, "postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),     # the removal as the post pass there (LDS)
     (1664, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM),
     (1000, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
     (1024, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),

@@ -96,6 +96,14 @@ SINUS_STORE_CASES = [
     (512, 200, 2, {"resampling": 0}, _lib.ROUTE_TINY_GRID, 0),
     (256, 130, 4, {"bscanFlip": 1}, 0, 0),
     (256, 33, 9, {"backgroundRemoval": 1, "rollingAverageWindowSize": 4, "resamplingInterpolation": 0}, 0, 5),
+    # the team kernels (team_kernel.h MODE_SINUS): N = 4096 on four waves, N = 8192 on eight
+    (4096, 70, 3, {"bscanFlip": 1}, 0, 0),
+    (4096, 130, 2, {"postProcessBackgroundRemoval": 1, "signalLogScaling": 0}, 0, 2),
+    (4096, 24, 5, {"resamplingInterpolation": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 32, "bscanFlip": 1}, 0, 0),
+    (4096, 600, 3, {"dispersionCompensation": 0}, 0, 0),                      # more rows than persistent teams: several blocks per team
+    (8192, 40, 3, {"bscanFlip": 1}, 0, 0),
+    (8192, 24, 2, {"postProcessBackgroundRemoval": 1}, 0, 0),                 # removal as the post pass behind the in-store correction
+    (8192, 24, 2, {"resampling": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 16}, 0, 3),
 ]
 
 
