@@ -38,6 +38,7 @@ enum {
 	OCTPIPE_ROUTE_MIXEDN_STATIC_OLD_LAYOUT = 2048, /* creation: the run-time compiled kernel with its first plan order and exchange layout (largest radix first, always padded) */
 	OCTPIPE_ROUTE_TINY_GRID = 1024,    /* the run-time compiled kernel and the general fused kernel on TWO persistent workgroups: every wave loops over many A-scans even of a small test buffer */
 	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256, /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
+	OCTPIPE_ROUTE_TEAM1664_ALWAYS = 16384, /* samplesPerLine = 1664: the two-wave team kernel for every resampling mode it has (by default linear / no resampling run on the one-wave kernel, faster there); A/Bs and the parity of the in-store correction, which always runs on the team kernel */
 	OCTPIPE_ROUTE_NO_FUSED_SINUS = 8192, /* sinusoidal scan correction always as the post pass (cu:1551-1554 as one gather pass), never inside the general fused kernel's image store (MODE_SINUS) */
 	OCTPIPE_ROUTE_FUSED_DISPLAY = 4096 /* display frames (one frame per view) written by the general fused kernel's image store (MODE_DISP) instead of by oct_display_frames_kernel.
 	                                      Opt-in: bit-identical frames, one launch per buffer instead of two, but not faster -- the store side costs the kernel what the extraction kernel

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OCTPIPE_LIB") or os.path.join(_HERE, "liboctpipe.so")
 
 OCTPIPE_OK = 0
 # OCTPIPE_ROUTE_* (include/octpipe_debug.h, octpipe_debug_set_route / octpipe_debug_create): keep a configuration on the slower / more general of two routes
-ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED, ROUTE_NO_MIXEDN, ROUTE_MIXEDN_SIMPLE_RADICES, ROUTE_NO_MIXEDN_STATIC, ROUTE_TINY_GRID, ROUTE_MIXEDN_STATIC_OLD_LAYOUT, ROUTE_FUSED_DISPLAY, ROUTE_NO_FUSED_SINUS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192
+ROUTE_NO_REAL_INPUT, ROUTE_NO_FUSED_BG, ROUTE_FULL_DISPLAY, ROUTE_NO_TEAM, ROUTE_NO_LIBFFT, ROUTE_FORCE_LIBFFT, ROUTE_NO_MIXED, ROUTE_NO_MIXEDN, ROUTE_MIXEDN_SIMPLE_RADICES, ROUTE_NO_MIXEDN_STATIC, ROUTE_TINY_GRID, ROUTE_MIXEDN_STATIC_OLD_LAYOUT, ROUTE_FUSED_DISPLAY, ROUTE_NO_FUSED_SINUS, ROUTE_TEAM1664_ALWAYS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
 # octpipe_debug_last_path (include/octpipe_debug.h OCTPIPE_PATH_*)
 # octpipe_group_create_ex flags (include/octpipe.h)
 GROUP_PLACE_RING_SLABS, GROUP_NO_SUBMIT_THREADS, GROUP_SUBMIT_THREADS = 1, 2, 4

@@ -154,7 +154,9 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 	                          !(roll && rs == RS_CUBIC && (f.log2n == 9 || f.log2n == 11));
 	// ... and the team kernels of N = 4096 / 8192 (team_kernel.h MODE_SINUS; not cubic resampling together with the rolling average: registers)
 	const bool sinusTeam = sinusWanted && f.teamTables && !f.mixed && !(route & OCTPIPE_ROUTE_NO_TEAM) && (teamLib || !f.libfft) && !(roll && rs == RS_CUBIC);
-	const bool sinusOk = sinusGeneral || sinusTeam;
+	// ... and the two-wave team kernel of N = 1664 (team1664_kernel.h MODE_SINUS: every resampling mode it has, with or without the rolling average)
+	const bool sinus1664 = sinusWanted && f.mixed && mixedDirect && !(route & OCTPIPE_ROUTE_NO_TEAM);
+	const bool sinusOk = sinusGeneral || sinusTeam || sinus1664;
 	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
 	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
 	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
@@ -188,12 +190,14 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 			r.kind = ROUTE_KIND_MIXED1664_REAL2;
 			r.pair = true;
 			r.path |= OCTPIPE_PATH_MIXED_RADIX;
-		} else if (!spectrum && (rs == RS_CUBIC || (roll && rs != RS_LANCZOS)) && !(route & OCTPIPE_ROUTE_NO_TEAM)) {
+		} else if (!spectrum && (rs == RS_CUBIC || (roll && rs != RS_LANCZOS) || sinus1664 || ((route & OCTPIPE_ROUTE_TEAM1664_ALWAYS) && rs != RS_LANCZOS && mixedDirect)) && !(route & OCTPIPE_ROUTE_NO_TEAM)) {
 			// cubic: two waves per A-scan, the tap weights of all 13 samples of a lane in registers (team1664_kernel.h; +5 %).  Linear and
 			// no resampling are faster on the one-wave kernel (its 32 fractions per lane fit in registers): 354 vs 390 M, 366 vs 398 M.
 			// (`roll` still set: uint16 rows whose rolling average runs inside the team -- every resampling mode then)
+			// (the sinusoidal correction inside the store: this kernel for every resampling mode)
 			r.kind = ROUTE_KIND_TEAM1664;
 			r.path |= OCTPIPE_PATH_TEAM | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
+			if (sinus1664) { r.sinusFused = true; r.path |= OCTPIPE_PATH_FUSED_SINUS; }
 		} else {
 			r.kind = ROUTE_KIND_MIXED1664;
 			r.path |= OCTPIPE_PATH_MIXED_RADIX;

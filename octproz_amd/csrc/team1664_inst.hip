@@ -14,6 +14,20 @@ hipError_t launch_team1664_one(const FusedArgs& a, hipStream_t stream) {
 	hipError_t e = kernel_launch_info(kernel, Team1664::T, lds, &info);
 	if (e != hipSuccess) return e;
 	unsigned blocks = (unsigned)(info.numCU * info.blocksPerCU);
+	if constexpr ((MODE & MODE_SINUS) != 0) {
+		// the work list of the buffer in blocks of sinBlk + 1 entries, one block per team by default (team_inst.hip launch_team_one: the same rule)
+		if (a.sinTotal < 2 || a.sinM == 0 || a.sinEnt == nullptr) return hipErrorInvalidValue;
+		FusedArgs s = a;
+		const unsigned pairs = a.sinTotal - 1u, perTeam = a.sinBlk ? a.sinBlk : 1u;
+		unsigned len = (pairs + perTeam * blocks - 1u) / (perTeam * blocks);
+		if (len < 8u) len = pairs < 8u ? pairs : 8u;
+		if (len > 63u) len = 63u;
+		s.sinBlk = len;
+		const unsigned listBlocks = (pairs + len - 1u) / len;
+		if (blocks > listBlocks) blocks = listBlocks;
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(Team1664::T), lds, stream, s);
+		return hipGetLastError();
+	}
 	if (blocks > a.numLines) blocks = a.numLines;
 	if (blocks == 0) return hipSuccess;
 	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(Team1664::T), lds, stream, a);
@@ -21,6 +35,17 @@ hipError_t launch_team1664_one(const FusedArgs& a, hipStream_t stream) {
 }
 template <int INTYPE, int RS>
 hipError_t launch_team1664_mode(bool roll, bool logScale, const FusedArgs& a, hipStream_t stream) {
+	if (a.sinEnt) {  // sinusoidal scan correction inside the image store (MODE_SINUS; route.h grants it for raw uint16 rows)
+		if constexpr (INTYPE == IN_U16) {
+			if (roll) {
+				if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
+				if (a.bgTerm) return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_ROLL | MODE_BG | MODE_SINUS>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_ROLL | MODE_BG | MODE_SINUS>(a, stream);
+				return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_ROLL | MODE_SINUS>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_ROLL | MODE_SINUS>(a, stream);
+			}
+			if (a.bgTerm) return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_BG | MODE_SINUS>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_BG | MODE_SINUS>(a, stream);
+			return logScale ? launch_team1664_one<INTYPE, RS, MODE_LOG | MODE_SINUS>(a, stream) : launch_team1664_one<INTYPE, RS, MODE_SINUS>(a, stream);
+		} else return hipErrorInvalidValue;
+	}
 	if (roll) {  // rolling average inside the team: uint16 rows
 		if (!roll_in_kernel_ok(a)) return hipErrorInvalidValue;
 		if constexpr (INTYPE == IN_U16) {

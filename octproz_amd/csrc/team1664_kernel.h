@@ -41,6 +41,7 @@ struct Team1664 {
 	// FusedArgs::twiddle: [t-1][r] of pass 2 (15 x 13, angle 2 pi t r / 208), then [t-1][b] of pass 3 (7 x 208, angle 2 pi t b / 1664)
 	static constexpr int TW_PASS3 = 15 * 13, TW_COUNT = TW_PASS3 + 7 * 208;
 };
+// (MODE_SINUS, round 6: the previous row's grey values stay in the lanes' registers, eight each -- the LDS of four teams per CU has no room for them)
 template <int MODE> constexpr int team1664_lds_bytes() { return Team1664::FIXED_BYTES + bg_lds_bytes<MODE, Team1664::N>() + ((MODE & 1 /* MODE_ROLL */) ? TEAM_ROLL_BYTES : 0); }
 
 template <int INTYPE, int RS, int MODE>
@@ -50,7 +51,11 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 	typedef Team1664 TM;
 	constexpr int N = TM::N, T = TM::T, P = TM::P;
 	constexpr bool LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0;
-	constexpr bool EARLY = !ROLL && OCT_TEAM_EARLY != 0;
+	// MODE_SINUS (round 6): the sinusoidal scan correction inside the image store, as in oct_team_kernel (the team walks blocks of the work list:
+	// kernels.h SinusWalk); the next row is then staged at the top of the loop
+	constexpr bool SINUS = (MODE & MODE_SINUS) != 0;
+	static_assert(!SINUS || INTYPE == IN_U16, "sinusoidal correction in the store: raw uint16 rows");
+	constexpr bool EARLY = !ROLL && !SINUS && OCT_TEAM_EARLY != 0;
 	static_assert(!ROLL || INTYPE == IN_U16, "in-team rolling average: uint16 rows");
 	static_assert((TM::N + 2 * ROLL_PAD) * 4 <= TM::X2_BYTES, "the prefix array borrows the second exchange buffer");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,6 +119,9 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 	const unsigned rowBytes = (unsigned)N * (INTYPE == IN_U16 ? 2u : 4u);
 	const uint32_t shift = a.bitshift ? 4u : 0u;
 	unsigned line = blockIdx.x;
+	SinusWalk sw;
+	if constexpr (SINUS) line = sw.begin(a, blockIdx.x, gridDim.x);  // (both waves walk the same list)
+	float sPrev[SINUS ? 8 : 1] = {};
 	u32x4 pre[NL];
 	auto prefetch = [&](unsigned ln) {
 		const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)ln * rowBytes, rowBytes);
@@ -143,16 +151,21 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 	}
 
 	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
-	for (; line < a.numLines; line += gridDim.x) {
+	while (line < a.numLines) {
+		unsigned nxt = line + gridDim.x;  // the row to request while this one is staged
+		if constexpr (SINUS) {
+			sw.load_ahead();
+			nxt = sw.peek_next();
+		}
 		if constexpr (ROLL) {
 			// ---- the raw row minus the rolling average (cu:165-211; team_kernel.h): three barriers of its own
 			team_roll_stage<T, N, NL>(pre, shift, a.rollingW, reinterpret_cast<uint32_t*>(x2),
 			                          reinterpret_cast<uint32_t*>(smem + team1664_lds_bytes<MODE>() - TEAM_ROLL_BYTES), row, L, RS == RS_CUBIC);
-			if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
+			if (nxt < a.numLines) prefetch(nxt);
 			team_barrier();  // the row is complete
 		} else if constexpr (!EARLY) {
 			stage();
-			if (line + gridDim.x < a.numLines) prefetch(line + gridDim.x);
+			if (nxt < a.numLines) prefetch(nxt);
 			team_barrier();  // the row is complete
 		}
 
@@ -228,11 +241,34 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 
 		// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address (as in the general kernel)
 		unsigned orow = line;
-		if (a.flip) {
+		if constexpr (SINUS) {
+			orow = sw.out_row();
+		} else if (a.flip) {
 			const unsigned b = line / a.ascansPerBscan, as = line - b * a.ascansPerBscan;
 			if ((b & 1u) == 0u && (b + 2u) * a.ascansPerBscan <= a.linesInBuffer) orow = b * a.ascansPerBscan + (a.ascansPerBscan - 1u - as);
 		}
 		const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
+		// MODE_SINUS: the pair (previous row, this row) of the work list -> blended output A-scans orow and orow + 1 (cu:506-510, sinus_blend), the buffer's
+		// last A-scan as it is; every value through store_image, i.e. through the background removal that follows the correction
+		float sF0 = 0.0f, sF1 = 0.0f;
+		bool sSt0 = false, sSt1 = false, sRaw = false;
+		__amdgpu_buffer_rsrc_t outR1 = outR, outRL = outR;
+		if constexpr (SINUS) {
+			sw.pair(&sF0, &sF1, &sSt0, &sSt1, &sRaw);
+			outR1 = make_rsrc(a.out + (size_t)(orow + 1u) * (N / 2), N * 2u);
+			outRL = make_rsrc(a.out + (size_t)(a.linesInBuffer - 1u) * (N / 2), N * 2u);
+		}
+		auto put = [&](float o, int k, int c) {  // value k of the lane: the bin at byte L * 4 + c of the row
+			if constexpr (SINUS) {
+				const float pv = sPrev[k];
+				sPrev[k] = o;
+				if (sSt0) store_image<BG>(sinus_blend(pv, o, sF0), outR, termL, L * 4, c);
+				if (sSt1) store_image<BG>(sinus_blend(pv, o, sF1), outR1, termL, L * 4, c);
+				if (sRaw) store_image<BG>(o, outRL, termL, L * 4, c);
+			} else {
+				store_image<BG>(o, outR, termL, L * 4, c);
+			}
+		};
 		float o[8];
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
@@ -242,12 +278,19 @@ __global__ __launch_bounds__(Team1664::T, 2) void oct_team1664_kernel(const Fuse
 			o[i] = a.sA * s + a.sB;
 		}
 #pragma unroll
-		for (int u = 0; u < 4; u++) store_image<BG>(o[2 * u], outR, termL, L * 4, 208 * u * 4);
+		for (int u = 0; u < 4; u++) put(o[2 * u], 2 * u, 208 * u * 4);
 		if (two) {
 #pragma unroll
-			for (int u = 0; u < 4; u++) store_image<BG>(o[2 * u + 1], outR, termL, L * 4, (128 + 208 * u) * 4);
+			for (int u = 0; u < 4; u++) put(o[2 * u + 1], 2 * u + 1, (128 + 208 * u) * 4);
 		}
 		__builtin_amdgcn_s_setprio(0);
+		if constexpr (SINUS) {
+			bool newBlock;
+			line = sw.advance(&newBlock);
+			if (newBlock && line < a.numLines) prefetch(line);  // (inside a block the row was requested while its predecessor was staged)
+		} else {
+			line += gridDim.x;
+		}
 	}
 }
 

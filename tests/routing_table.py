@@ -36,7 +36,16 @@ ROUTING = [
     (4096, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 2}, 0, 0, _P.PATH_TEAM),                                # Lanczos: post pass
     (8192, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),
     (8192, {"sinusoidalScanCorrection": 1, "postProcessBackgroundRemoval": 1}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),     # the removal as the post pass there (LDS)
-    (1664, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM),
+    (1664, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),                                        # the reference recording's length: the two-wave team kernel (round 6)
+    (1664, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),          # ... for every resampling mode it has
+    (1664, {"sinusoidalScanCorrection": 1, "dispersionCompensation": 0, "resampling": 0}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_SINUS),
+    (1664, {"sinusoidalScanCorrection": 1, "postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0,
+     _P.PATH_TEAM | _P.PATH_FUSED_SINUS | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
+    (1664, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 0}, 0, _P.ROUTE_NO_FUSED_SINUS, _P.PATH_MIXED_RADIX),
+    (1664, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 0}, 0, _P.ROUTE_NO_TEAM, _P.PATH_MIXED_RADIX),
+    (1664, {"resamplingInterpolation": 0}, 0, _P.ROUTE_TEAM1664_ALWAYS | _P.ROUTE_NO_REAL_INPUT, _P.PATH_TEAM),
+    (1664, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX),                         # Lanczos: post pass
+    (1664, {"sinusoidalScanCorrection": 1}, 1, 0, _P.PATH_TEAM | _P.PATH_PREPARED_ROWS),                                      # packed 12 bit rows: prepared, post pass
     (1000, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
     (1024, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
     (4096, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),

@@ -104,6 +104,12 @@ SINUS_STORE_CASES = [
     (8192, 40, 3, {"bscanFlip": 1}, 0, 0),
     (8192, 24, 2, {"postProcessBackgroundRemoval": 1}, 0, 0),                 # removal as the post pass behind the in-store correction
     (8192, 24, 2, {"resampling": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 16}, 0, 3),
+    # N = 1664 (team1664_kernel.h MODE_SINUS, the previous row in registers): every resampling mode of the two-wave kernel
+    (1664, 512, 2, {"bscanFlip": 1}, _lib.ROUTE_TEAM1664_ALWAYS, 0),
+    (1664, 130, 3, {"resamplingInterpolation": 0, "postProcessBackgroundRemoval": 1}, _lib.ROUTE_TEAM1664_ALWAYS, 2),
+    (1664, 70, 3, {"resampling": 0, "dispersionCompensation": 0, "bscanFlip": 1, "signalLogScaling": 0}, _lib.ROUTE_TEAM1664_ALWAYS, 0),
+    (1664, 500, 5, {"bscanFlip": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64, "postProcessBackgroundRemoval": 1}, _lib.ROUTE_TEAM1664_ALWAYS, 0),
+    (1664, 600, 4, {"resamplingInterpolation": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 16}, _lib.ROUTE_TEAM1664_ALWAYS, 1),  # more rows than teams
 ]
 
 

@@ -112,3 +112,25 @@ def test_display_fold_variants_of_the_headline_object_have_no_scratch(asm):
         assert name + ":" in text, "MODE %d is not instantiated" % mode
         end = text.index("s_endpgm", text.index(name + ":"))
         assert int(re.search(r"; ScratchSize: (\d+)", text[end:end + 20000]).group(1)) == 0, mode
+
+
+def test_in_store_sinusoidal_variants_of_the_1664_team_kernel_have_no_scratch(tmp_path):
+    """team1664_kernel.h MODE_SINUS keeps the previous row's grey values in eight registers per lane (the LDS of four teams per CU has no room for
+    them): all 24 variants -- cubic resampling with its 52 tap weights in registers included -- stay inside 256 VGPRs without scratch or AGPR copies"""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "team1664.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-inline-asm", "-Wno-pass-failed", "-Wno-unused-value", "-S", "--cuda-device-only",
+                           "-o", out, "team1664_inst.hip"], cwd=CSRC, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    seen = 0
+    for m in re.finditer(r"^(_ZN3oct19oct_team1664_kernelILi1ELi(\d)ELi(\d+)EEEvNS_9FusedArgsE):", text, re.M):
+        if not int(m.group(3)) & 32:
+            continue
+        seen += 1
+        end = text.index("s_endpgm", m.end())
+        meta = text[end:end + 20000]
+        assert int(re.search(r"; ScratchSize: (\d+)", meta).group(1)) == 0, m.group(1)
+        assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 256 and int(re.search(r"; NumAgprs: (\d+)", meta).group(1)) == 0, m.group(1)
+        assert "s_load_dwordx4" in text[m.end():end], "work-list entries are not read with scalar loads"
+    assert seen == 24
