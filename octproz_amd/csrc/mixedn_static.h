@@ -42,6 +42,15 @@ template <int N_, int PADP_, int R0, int R1 = 1, int R2 = 1, int R3 = 1, int R4 
 #ifndef OCT_MXS_LUT_AHEAD
 #define OCT_MXS_LUT_AHEAD 8  // table entries in flight per lane in the first pass (16 B each)
 #endif
+#ifndef OCT_MXS_CW
+#define OCT_MXS_CW 0  // 1: cubic resampling from the table of tap weights every handle holds (FusedArgs::cubicW, oct_tap_weights_kernel): four FMAs per sample
+                      // instead of the Catmull-Rom polynomial evaluated from the fraction for every sample of every A-scan.  Measured in round 6: 21 % fewer
+                      // VALU instructions and 6-25 % SLOWER at N = 1000 / 2000, +4 % at N = 3000 (profiles/r6q_mxs_cubic_weight_table_ab.txt); with the
+                      // gather table in LDS (OCT_MXS_LUT_LDS) +-1 % at N = 1000, -6 % at 1200 (r6s): these kernels do not wait for VALU issue -- off
+#endif
+#ifndef OCT_MXS_LUT_AHEAD_CW
+#define OCT_MXS_LUT_AHEAD_CW 6  // entries in flight with the tap weights travelling along (32 B per sample)
+#endif
 // MODE bit of this kernel only (next to MODE_ROLL / MODE_SPECTRUM / MODE_LOG / MODE_BG of kernels.h): two A-scans per transform.
 // Without dispersion compensation the FFT input is real: a wave transforms the PAIR z = x1 + i x2 and separates the spectra
 // afterwards, X1[k] = (Z[k] + conj Z[N - k]) / 2, X2[k] = (Z[k] - conj Z[N - k]) / (2i) -- the scheme of real2n_kernel.h.  Both rows
@@ -80,13 +89,14 @@ template <int T> OCT_DEV void team_sync() {
 
 // where the last pass delivers: the output row (PAIR: both rows) or the spectrum row of the current A-scan, the grey-scale mapping
 struct Sink {
-	__amdgpu_buffer_rsrc_t out0, out1, spec, lanczos;
+	__amdgpu_buffer_rsrc_t out0, out1, spec, lanczos, cubicW;
 	float sA, sB;  // out = sA f(P) + sB (PAIR: for P' = 4 P, see body)
 };
 
 // pass p of the plan on the wave's slice (xb = exchange buffer, row = the staged row(s) at the same address)
-template <class P, int p, int RS, int MODE, int MEANN>
-OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
+// (lutL: the gather table in LDS, or nullptr -- then through lutR)
+template <class P, int p, int RS, int MODE, int MEANN, bool LUTL>
+OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const f32x4* lutL, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, R = D.radix[p], NB = N / R, NS = pd_ns(D, p), ITS = pd_its(D, p), PADP = pd_padp(D), LN = pd_lanes(D), T = pd_team(D);  // (`lane`: the lane of the TEAM, 0 .. LN - 1)
 	constexpr bool FIRST = p == 0, LAST = p == D.passes - 1;
@@ -110,10 +120,18 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 		// paid the L2 latency once per chunk)
 		// (Lanczos: the 16 tap weights of a sample -- 64 B of the table the host computed, cu:297-326 -- travel with its entry: two samples in flight)
 		constexpr bool LZ = RS == RS_LANCZOS;
-		constexpr int S = ITS * R, WANT = LZ ? 2 : OCT_MXS_LUT_AHEAD, AHEAD = S < WANT ? S : WANT;
-		f32x4 L[AHEAD], LW[LZ ? AHEAD : 1][4];
+		constexpr bool CWT = RS == RS_CUBIC && OCT_MXS_CW != 0;  // the four tap weights of a sample travel with its entry
+		constexpr int S = ITS * R, WANT = LZ ? 2 : CWT ? OCT_MXS_LUT_AHEAD_CW : OCT_MXS_LUT_AHEAD, AHEAD = S < WANT ? S : WANT;
+		f32x4 L[AHEAD], LW[LZ ? AHEAD : 1][4], CW[CWT ? AHEAD : 1];
+		auto cubic = [&](auto t0, auto t1, auto t2, auto t3, int sIdx) {
+			// cu:258-271 as weights of the four taps (the form of the dedicated kernels: kernels.h REGTAB, team_kernel.h)
+			if constexpr (CWT) { const f32x4 cw = CW[sIdx % AHEAD]; return t3 * cw.w + (t2 * cw.z + (t1 * cw.y + t0 * cw.x)); }
+			else return cubic_hermite(t0, t1, t2, t3, __builtin_amdgcn_fractf(L[sIdx % AHEAD].x));
+		};
 		auto request = [&](int sIdx) {
-			L[sIdx % AHEAD] = buf_load128(lutR, bIn[sIdx / R] * 16, (sIdx % R) * NB * 16);
+			if constexpr (LUTL) L[sIdx % AHEAD] = lutL[bIn[sIdx / R] + (sIdx % R) * NB];
+			else L[sIdx % AHEAD] = buf_load128(lutR, bIn[sIdx / R] * 16, (sIdx % R) * NB * 16);
+			if constexpr (CWT) CW[sIdx % AHEAD] = buf_load128(sink.cubicW, bIn[sIdx / R] * 16, (sIdx % R) * NB * 16);
 			if constexpr (LZ) {
 #pragma unroll
 				for (int c = 0; c < 4; c++) LW[sIdx % AHEAD][c] = buf_load128(sink.lanczos, bIn[sIdx / R] * 64, (sIdx % R) * NB * 64 + c * 16);
@@ -151,13 +169,13 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 				if constexpr (PAIR) {
 					const f2* tp = T2[sIdx % (TA + 1)];
 					f2 y;
-					if constexpr (RS == RS_CUBIC) y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], fr);
+					if constexpr (RS == RS_CUBIC) y = cubic(tp[0], tp[1], tp[2], tp[3], sIdx);
 					else y = tp[0] + (tp[1] - tp[0]) * fr;
 					x[it][t] = y * e.y;
 				} else {
 					const float* tp = T1[sIdx % (TA + 1)];
 					float y;
-					if constexpr (RS == RS_CUBIC) y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], fr);
+					if constexpr (RS == RS_CUBIC) y = cubic(tp[0], tp[1], tp[2], tp[3], sIdx);
 					else y = tp[0] + (tp[1] - tp[0]) * fr;
 					const float yw = y * e.y;
 					x[it][t] = f2{yw * e.z, yw * e.w};
@@ -169,7 +187,7 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 				f2 y;
 				if constexpr (RS == RS_CUBIC) {
 					const f2* tp = rp + ROW_OFF + (int)e.x - 1;
-					y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], __builtin_amdgcn_fractf(e.x));
+					y = cubic(tp[0], tp[1], tp[2], tp[3], sIdx);
 				} else if constexpr (RS == RS_LINEAR) {
 					const f2* tp = rp + ROW_OFF + (int)e.x;
 					y = tp[0] + (tp[1] - tp[0]) * __builtin_amdgcn_fractf(e.x);
@@ -181,7 +199,7 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 				float y;
 				if constexpr (RS == RS_CUBIC) {
 					const float* tp = row + ROW_OFF + (int)e.x - 1;  // tap 0 = sample n1 - 1 (the mirror tap of n1 = 0 sits at row[ROW_OFF - 1])
-					y = cubic_hermite(tp[0], tp[1], tp[2], tp[3], __builtin_amdgcn_fractf(e.x));
+					y = cubic(tp[0], tp[1], tp[2], tp[3], sIdx);
 				} else if constexpr (RS == RS_LINEAR) {
 					const float* tp = row + ROW_OFF + (int)e.x;
 					y = tp[0] + (tp[1] - tp[0]) * __builtin_amdgcn_fractf(e.x);
@@ -285,10 +303,10 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 	}
 }
 
-template <class P, int p, int RS, int MODE, int MEANN>
-OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
-	pass<P, p, RS, MODE, MEANN>(row, xb, twL, lutR, sink, mean, termL, lane);
-	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN>(row, xb, twL, lutR, sink, mean, termL, lane);
+template <class P, int p, int RS, int MODE, int MEANN, bool LUTL>
+OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const f32x4* lutL, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
+	pass<P, p, RS, MODE, MEANN, LUTL>(row, xb, twL, lutR, lutL, sink, mean, termL, lane);
+	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN, LUTL>(row, xb, twL, lutR, lutL, sink, mean, termL, lane);
 }
 
 // INTYPE: IN_U16 (raw rows, bitDepth 9..16) or IN_F32 (rows prepared by oct_prepare[_rows]_kernel: other containers, wide rolling-average
@@ -316,8 +334,14 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	char* slice = smem + pd_tw_bytes(D) + wave * pd_slice_bytes(D, ROLL, PAIR);
 	float* row = reinterpret_cast<float*>(slice);
 	f2* xb = reinterpret_cast<f2*>(slice);
-	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + (W / T) * pd_slice_bytes(D, ROLL, PAIR));
+	constexpr int LUT_BYTES = pd_lut_bytes(D, W, BG, ROLL, PAIR);
+	constexpr bool LUTL = LUT_BYTES != 0;
+	f32x4* lutL = reinterpret_cast<f32x4*>(smem + pd_tw_bytes(D) + (W / T) * pd_slice_bytes(D, ROLL, PAIR));
+	float* termL = reinterpret_cast<float*>(smem + pd_tw_bytes(D) + (W / T) * pd_slice_bytes(D, ROLL, PAIR) + LUT_BYTES);
 	if constexpr (BG) fill_bg_term(termL, a.bgTerm, HALF, tid, W * 64);
+	if constexpr (LUTL) {
+		for (int i = tid; i < N; i += W * 64) lutL[i] = reinterpret_cast<const f32x4*>(a.lut)[i];
+	}
 	for (int i = tid; i < pd_twelems(D); i += W * 64) twL[i] = a.twiddle[i];
 	// the lane's share of the mean A-line (cu:492-520) for the whole persistent loop: bins b + u NB of the last pass (PAIR: twice the
 	// mean -- the separated spectra come as 2 X1, 2 X2)
@@ -339,6 +363,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	sink.sA = PAIR && !LOGSCALE ? 0.5f * a.sA : a.sA;
 	sink.sB = PAIR && LOGSCALE ? a.sB - 2.0f * a.sA : a.sB;
 	sink.lanczos = make_rsrc(a.lanczosW, RS == RS_LANCZOS ? N * 64 : 0);
+	sink.cubicW = make_rsrc(a.cubicW, RS == RS_CUBIC ? N * 16 : 0);
 
 	constexpr int LOADS = (HALF + LN - 1) / LN;
 	typedef typename RawWord<INTYPE>::T RawT;
@@ -480,7 +505,7 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 		sink.out0 = make_rsrc(a.out + (size_t)orow[0] * HALF, HALF * 4);
 		sink.out1 = make_rsrc(a.out + (size_t)orow[1] * HALF, (PAIR && line + 1u < a.numLines) ? HALF * 4 : 0);
 		sink.spec = make_rsrc(a.spectrum + (size_t)line * N, (MODE & MODE_SPECTRUM) ? N * 8 : 0);
-		passes_from<P, 0, RS, MODE, MEANN>(row, xb, twL, lutR, sink, mean, termL, lane);
+		passes_from<P, 0, RS, MODE, MEANN, LUTL>(row, xb, twL, lutR, lutL, sink, mean, termL, lane);
 		team_sync<T>();  // the last pass' reads of the slice precede the next row
 	}
 }

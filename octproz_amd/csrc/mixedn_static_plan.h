@@ -71,7 +71,21 @@ constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bo
 	if (w > cap) w = cap;
 	return w;
 }
-constexpr int pd_lds_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false, bool pair = false) { return pd_tw_bytes(d) + (waves / pd_team(d)) * pd_slice_bytes(d, roll, pair) + (bg ? d.N * 2 : 0); }
+// Round 6: the gather table (FusedArgs::lut, 16 B per sample) in LDS behind the slices wherever the workgroup has the room: one ds_read_b128 per sample
+// instead of a 1 KB wave read through the vector L1 per sample and A-scan (N = 1000: 20 KB per A-scan next to the 2 KB row).  Same box, 13 settings
+// (profiles/r6s_mxs_gather_table_in_lds_ab.txt): N = 1000 +3-4 % (no resampling +17 %, Lanczos +12 %), N = 1200 -1 ... +4 % (Lanczos +12 %); the lengths whose
+// slices leave no room (1536, 2000 and up) keep the table in global memory.  0: always there.
+#ifndef OCT_MXS_LUT_LDS
+#define OCT_MXS_LUT_LDS 1
+#endif
+constexpr int pd_lut_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false, bool pair = false) {
+	const int rest = pd_tw_bytes(d) + (waves / pd_team(d)) * pd_slice_bytes(d, roll, pair) + (bg ? d.N * 2 : 0);
+	return (OCT_MXS_LUT_LDS != 0 && rest + d.N * 16 <= 160 * 1024) ? d.N * 16 : 0;
+}
+// [twiddles | slices | gather table | background term]
+constexpr int pd_lds_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false, bool pair = false) {
+	return pd_tw_bytes(d) + (waves / pd_team(d)) * pd_slice_bytes(d, roll, pair) + pd_lut_bytes(d, waves, bg, roll, pair) + (bg ? d.N * 2 : 0);
+}
 
 }  // namespace mxs
 }  // namespace oct
