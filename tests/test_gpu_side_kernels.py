@@ -2,6 +2,7 @@
 810-967, given the SAME float volume: these stages are elementwise / index maps on float32 data, so the bar is bit-exact.
 Sizes are chosen to hit the vector paths (N/2 % 4 == 0), the scalar paths (Bluestein lengths with odd N/2) and the tails."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -113,11 +114,9 @@ SINUS_STORE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("N,A,B,settings,route,bpw", SINUS_STORE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else ",".join("%s=%s" % kv for kv in v.items()) or "v180")
-def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_own_image(N, A, B, settings, route, bpw):
-    """cu:491-514 inside the image store (MODE_SINUS) == the oracle's pass applied to the image the same kernel writes without the
-    correction, bit for bit -- and == the post-pass route: flip, rolling average, background removal behind it, every block size, the
-    buffer's last A-scan left as it is, B-scans that end inside a block"""
+def _check_sinus_in_store(N, A, B, settings, route, bpw, seed=None, require_fused=True):
+    """the correction inside the store == the oracle's pass on the image the same transform kernel writes without it == the post-pass route, bit for bit.
+    Returns whether the correction ran inside the store."""
     p = v180_benchmark_params(N, A, B)
     _grey(p)
     p.fixedPatternNoiseRemoval = 0
@@ -125,7 +124,7 @@ def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_o
         setattr(p, k, v)
     bg = p.postProcessBackgroundRemoval
     p.postProcessBackgroundRemoval = 0
-    raw = synthetic_raw(N, A, B, seed=N + A + B)
+    raw = synthetic_raw(N, A, B, seed=N + A + B if seed is None else seed)
     d = _dev(raw)
     # the kernel that will run with the correction is the general one: keep the uncorrected reference image on it too
     plain = Pipeline(p, device=0, route=route | _lib.ROUTE_NO_REAL_INPUT)
@@ -142,11 +141,14 @@ def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_o
         want = octref.postproc_background_removal(want, bgline, 0.75, 0.01, W)
     pipe = Pipeline(p, device=0, route=route)
     pipe.set_sinus_blocks_per_wave(bpw)
+    fused = False
     for _ in range(2):  # (idempotent per call)
         pipe.process_device(d.data_ptr()); pipe.synchronize()
-        assert pipe.last_path() & _lib.PATH_FUSED_SINUS
+        fused = bool(pipe.last_path() & _lib.PATH_FUSED_SINUS)
+        assert fused or not require_fused
         got = pipe.processed_host()
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "rows that differ: %s" % np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).reshape(A * B, W).any(axis=1))[:20]
+        if fused:  # (otherwise the default route may run a different transform kernel -- the real-input one -- than `plain`: the post route below is the check then)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "rows that differ: %s" % np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).reshape(A * B, W).any(axis=1))[:20]
     pipe.close()
     p.loadPostProcessingBackground(bgline)  # (the first handle's parameter sync has consumed the "updated" flag of the shared object)
     post = Pipeline(p, device=0, route=route | _lib.ROUTE_NO_FUSED_SINUS | _lib.ROUTE_NO_REAL_INPUT)
@@ -154,6 +156,56 @@ def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_o
     assert not (post.last_path() & _lib.PATH_FUSED_SINUS)
     assert np.array_equal(post.processed_host().view(np.uint32), want.view(np.uint32))
     post.close()
+    return fused
+
+
+@pytest.mark.parametrize("N,A,B,settings,route,bpw", SINUS_STORE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else ",".join("%s=%s" % kv for kv in v.items()) or "v180")
+def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_own_image(N, A, B, settings, route, bpw):
+    """cu:491-514 inside the image store (MODE_SINUS) == the oracle's pass applied to the image the same kernel writes without the
+    correction, bit for bit -- and == the post-pass route: flip, rolling average, background removal behind it, every block size, the
+    buffer's last A-scan left as it is, B-scans that end inside a block"""
+    _check_sinus_in_store(N, A, B, settings, route, bpw)
+
+
+_SINUS_FUZZ = {"draws": 0, "fused": 0}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SINUS_SEEDS", "300"))))
+def test_sinusoidal_correction_in_the_store_random_shapes_and_settings(seed):
+    """the same three-way identity on drawn configurations: every length with an in-store variant, B-scan widths from 2 to 700 (few, odd, prime, more
+    pairs than persistent waves), 1-6 B-scans per buffer, every setting that composes with the correction, every block size of the work list.
+    Draws the routing function keeps on the post pass (Lanczos, cubic + rolling average at some lengths, A = 2) still compare the default route
+    with the oracle through the post-pass handle."""
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.choice([256, 512, 1024, 1024, 2048, 4096, 8192, 1664, 1664]))
+    cap = {256: 4000, 512: 3000, 1024: 2400, 2048: 1200, 4096: 500, 8192: 160, 1664: 1500}[N]
+    B = int(rng.integers(1, 7))
+    A = int(rng.choice([2, 3, 4, 5, 7, 17, 31, 64, 100, 130, 257, 512, 700]))
+    A = max(2, min(A, cap // B))
+    s = {}
+    if rng.random() < 0.5: s["bscanFlip"] = 1
+    r = rng.random()
+    if r < 0.25: s["resampling"] = 0
+    elif r < 0.55: s["resamplingInterpolation"] = 0
+    elif r < 0.60: s["resamplingInterpolation"] = 2
+    if rng.random() < 0.3: s["dispersionCompensation"] = 0
+    if rng.random() < 0.2: s["windowing"] = 0
+    if rng.random() < 0.3: s["signalLogScaling"] = 0
+    if rng.random() < 0.4:
+        s["backgroundRemoval"] = 1
+        s["rollingAverageWindowSize"] = int(rng.choice([2, 4, 16, 64, 200]))
+    if rng.random() < 0.4: s["postProcessBackgroundRemoval"] = 1
+    route = _lib.ROUTE_TEAM1664_ALWAYS if N == 1664 else (_lib.ROUTE_TINY_GRID if rng.random() < 0.25 else 0)
+    bpw = int(rng.choice([0, 0, 1, 2, 3, 5, 8]))
+    fused = _check_sinus_in_store(N, A, B, s, route, bpw, seed=seed, require_fused=False)
+    _SINUS_FUZZ["draws"] += 1
+    _SINUS_FUZZ["fused"] += int(fused)
+
+
+def test_most_of_the_random_draws_ran_the_correction_in_the_store():
+    if _SINUS_FUZZ["draws"] < 40:
+        pytest.skip("the draws did not run in this session")
+    assert _SINUS_FUZZ["fused"] >= 0.6 * _SINUS_FUZZ["draws"], _SINUS_FUZZ
 
 
 def test_sinusoidal_correction_in_the_store_with_several_buffers_per_volume():
