@@ -61,7 +61,8 @@ def parse_args(argv=None):
                     "launch costs the stream 2-4 us, i.e. the measurement itself would take 2 %% off the step rate it is reported next to")
     ap.add_argument("--blocks", type=int, default=8, help="after the timed region: this many more blocks of --steps steps, alternately with and without the per-launch HIP events, "
                     "reported as medians next to the contract's single timed block (a 20-step block is 3 ms: box noise is +-2-4 %%)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the host_loop, real_input, rolling_average and north_star_chain records (A/B runs, profiler passes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host_loop, real_input, rolling_average, north_star_chain and config3 records (A/B runs, profiler passes)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config3 record (2048 x 1024 x 512, 17 GiB of device buffers) of the default run")
     ap.add_argument("--host-loop-seconds", type=float, default=3.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for testing)")
     ap.add_argument("--group", action="store_true",
@@ -651,6 +652,35 @@ def main():
                                    "what": "same workload, v1.8.0 settings plus rolling-average DC removal (W = 64), B-scan flip and sinusoidal scan correction "
                                            "(cu:165-211, cu:787-807, cu:491-514): every stage north_star names, one kernel per buffer"}
         rp.close()
+        # (i3) BASELINE config 3 (the long-FFT configuration, 2048 x 1024 x 512: 2 GiB raw per buffer) with the same buffer rotation, when this run is the
+        # default headline workload and the device has the room (4 x 2 GiB raw + 4 x 2 GiB processed)
+        if (N, A, B) == (1024, 512, 256) and not args.no_config3:
+            try:
+                N3, A3, B3 = 2048, 1024, 512
+                free_b, _tot = torch.cuda.mem_get_info(dev)
+                if free_b < 24 * 2**30:
+                    raise RuntimeError("less than 24 GiB of device memory free")
+                q = v180_benchmark_params(N3, A3, B3, buffers_per_volume=slots)
+                vols3 = []
+                for i in range(n_vols):
+                    t = torch.empty((B3, A3, N3), dtype=torch.int16, device=dev)
+                    for b0 in range(0, B3, 128):
+                        t[b0:b0 + 128] = synthetic_raw_torch(N3, A3, 128, dev, seed=31 + i + 17 * b0)
+                    vols3.append(t)
+                torch.cuda.synchronize()
+                rp = Pipeline(q, device=local_rank)
+                rp.process_device(vols3[0].data_ptr()); rp.synchronize()
+                steps3 = 60
+                rdt, rms, rl = timed_run(rp, vols3, steps3, 5, min(args.warmup_seconds, 0.5))
+                out["config3"] = {"value": A3 * B3 * steps3 / rdt, "unit": "A-scans/s", "ms_per_step": rdt / steps3 * 1e3, "kernel_ms": rms, "steps": steps3,
+                                  "roofline_frac": (4.0 * N3 * A3 * B3 / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rms > 0 else None,
+                                  "what": "BASELINE config 3: 2048 x 1024 x 512 12-bit-in-uint16 raw buffer, v1.8.0 settings, %d raw buffers and %d output slots rotated; "
+                                          "4 B per sample algorithmic, oct_fused_kernel<11, 1, 2, 4>" % (n_vols, slots)}
+                rp.close()
+                del vols3, rp
+                torch.cuda.empty_cache()
+            except Exception as e:  # (a smaller device, a shared box: the headline number does not depend on it)
+                out["config3"] = {"error": str(e)}
         # (ii) the host loop incl. H2D, the reference's own metric definition
         if args.host_loop_seconds > 0:
             try:
