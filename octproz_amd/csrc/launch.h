@@ -153,7 +153,9 @@ int mixedn_rtc_compiled_count(double* seconds, std::string* lastMessage);
 void mixedn_rtc_set_options(const char* extra);
 bool mixedn_rtc_set_cache_dir(const char* dir, std::string* why);
 // start compiling a variant on the background thread (returns at once; nothing happens if it exists or is under way)
-void mixedn_rtc_prefetch(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, bool bg, const char* arch);
+void mixedn_rtc_prefetch(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, bool bg, const char* arch, bool sinus = false);
+// the length's kernel can run the sinusoidal scan correction inside its image store (MODE_SINUS: the previous row's grey values of a lane's bins fit in registers)
+bool mixedn_rtc_sinus_ok(const mxs::PlanDesc& d, int rs, bool roll);
 int mixedn_rtc_disk_hits();
 bool mixedn_rtc_wait_idle(double seconds);
 bool mixedn_rtc_compile_only(const mxs::PlanDesc& d, int intype, int rs, int mode, const char* arch, size_t* codeBytes, int* waves, double* seconds, std::string* why);

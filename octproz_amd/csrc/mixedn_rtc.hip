@@ -473,8 +473,12 @@ void mixedn_static_twiddles(const mxs::PlanDesc& d, std::vector<f2>& tw) {
 // pair: two A-scans per transform (no dispersion compensation: real FFT input; raw uint16 rows, image output, no rolling average)
 // maxBlocks > 0: at most that many persistent workgroups (tests: every wave loops over many A-scans of a small buffer)
 hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, const FusedArgs& a, hipStream_t stream, std::string* why, int maxBlocks) {
-	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (a.bgTerm ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0);
+	// a.sinEnt: the sinusoidal scan correction inside the image store (MODE_SINUS; route.h grants it for raw uint16 rows, one A-scan per transform, lengths whose
+	// registers hold the previous row of a lane's bins: mxs::pd_sinus_ok)
+	const bool sinus = a.sinEnt != nullptr;
+	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (a.bgTerm ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0) | (sinus ? MODE_SINUS : 0);
 	if (pair && (intype != IN_U16 || roll || spectrum)) return hipErrorInvalidValue;
+	if (sinus && (intype != IN_U16 || pair || spectrum || !mixedn_rtc_sinus_ok(d, rs, roll) || a.sinTotal < 2 || a.sinM == 0)) return hipErrorInvalidValue;
 	if ((intype != IN_U16 && intype != IN_F32) || rs < RS_NONE || rs > RS_LANCZOS) return hipErrorInvalidValue;
 	if (rs == RS_LANCZOS && (roll || pair || !a.lanczosW)) return hipErrorInvalidValue;
 	if (roll && (intype != IN_U16 || !roll_in_kernel_ok(a) || mxs::pd_team(d) > 1)) return hipErrorInvalidValue;
@@ -534,6 +538,18 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 		if (maxBlocks > 0 && blocks > (unsigned)maxBlocks) blocks = (unsigned)maxBlocks;
 		if (blocks == 0) return hipSuccess;
 		FusedArgs args = a;
+		if (sinus) {
+			// the work list of the buffer in blocks of sinBlk + 1 entries, one block per wave (team) by default (fused_inst.hip launch_one: the same rule)
+			blocks = (unsigned)m.numCU;
+			if (maxBlocks > 0 && blocks > (unsigned)maxBlocks) blocks = (unsigned)maxBlocks;
+			const unsigned pairs = a.sinTotal - 1u, perWalker = a.sinBlk ? a.sinBlk : 1u, walkers = blocks * perGroup;
+			unsigned len = (pairs + perWalker * walkers - 1u) / (perWalker * walkers);
+			if (len < 8u) len = pairs < 8u ? pairs : 8u;
+			if (len > 63u) len = 63u;
+			args.sinBlk = len;
+			const unsigned listBlocks = (pairs + len - 1u) / len, needGroups = (listBlocks + perGroup - 1u) / perGroup;
+			if (blocks > needGroups) blocks = needGroups;
+		}
 		void* params[] = {&args};
 		e = hipModuleLaunchKernel(m.fn, blocks, 1, 1, (unsigned)m.waves * 64u, 1, 1, 0, stream, params, nullptr);
 		if (e == hipSuccess || !stale_module_error(e) || attempt == 1) return e;
@@ -545,12 +561,15 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 	return e;
 }
 
+bool mixedn_rtc_sinus_ok(const mxs::PlanDesc& d, int rs, bool roll) { return rs != RS_LANCZOS && mxs::pd_sinus_ok(d, rs, roll); }
+
 // Start compiling a variant in the background (octpipe_create / octpipe_set_params: the variants one setting away from the
 // current one), so that the buffer that first needs it does not wait 0.5-1.2 s for the compiler.  Returns at once; a variant that
 // is already there or already being compiled costs a map lookup.
-void mixedn_rtc_prefetch(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, bool bg, const char* arch) {
-	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (bg ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0);
+void mixedn_rtc_prefetch(const mxs::PlanDesc& d, int intype, int rs, bool roll, bool pair, bool spectrum, bool logScale, bool bg, const char* arch, bool sinus) {
+	const int mode = (spectrum ? MODE_SPECTRUM : ((logScale ? MODE_LOG : 0) | (bg ? MODE_BG : 0))) | (roll ? MODE_ROLL : 0) | (pair ? mxs::MODE_PAIR : 0) | (sinus ? MODE_SINUS : 0);
 	if (pair && (intype != IN_U16 || roll || spectrum)) return;
+	if (sinus && (intype != IN_U16 || pair || spectrum || !mixedn_rtc_sinus_ok(d, rs, roll))) return;
 	if ((intype != IN_U16 && intype != IN_F32) || rs < RS_NONE || rs > RS_LANCZOS || (rs == RS_LANCZOS && (roll || pair)) || (roll && (intype != IN_U16 || mxs::pd_team(d) > 1))) return;
 	Cache& c = cache();
 	const std::string a = arch ? arch : "";

@@ -91,16 +91,23 @@ template <int T> OCT_DEV void team_sync() {
 struct Sink {
 	__amdgpu_buffer_rsrc_t out0, out1, spec, lanczos, cubicW;
 	float sA, sB;  // out = sA f(P) + sB (PAIR: for P' = 4 P, see body)
+	// MODE_SINUS (round 6; the sinusoidal scan correction inside the image store, as in kernels.h / team_kernel.h): out0 / out1 = the two output
+	// A-scans the pair (previous row, this row) of the work list blends into (fractions f0 / f1, written if st0 / st1), outL = the buffer's last A-scan,
+	// which this row is when `raw` says so (stored as it is)
+	__amdgpu_buffer_rsrc_t outL;
+	float f0, f1;
+	bool st0, st1, raw;
 };
 
 // pass p of the plan on the wave's slice (xb = exchange buffer, row = the staged row(s) at the same address)
 // (lutL: the gather table in LDS, or nullptr -- then through lutR)
-template <class P, int p, int RS, int MODE, int MEANN, bool LUTL>
-OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const f32x4* lutL, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
+// (prev: MODE_SINUS, the previous row's grey values of the lane's bins, in the order of `mean`)
+template <class P, int p, int RS, int MODE, int MEANN, bool LUTL, int PREVN>
+OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const f32x4* lutL, const Sink& sink, const f2 (&mean)[MEANN], float (&prev)[PREVN], const float* termL, int lane) {
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, R = D.radix[p], NB = N / R, NS = pd_ns(D, p), ITS = pd_its(D, p), PADP = pd_padp(D), LN = pd_lanes(D), T = pd_team(D);  // (`lane`: the lane of the TEAM, 0 .. LN - 1)
 	constexpr bool FIRST = p == 0, LAST = p == D.passes - 1;
-	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, PAIR = (MODE & MODE_PAIR) != 0;
+	constexpr bool SPECTRUM = (MODE & MODE_SPECTRUM) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, BG = (MODE & MODE_BG) != 0, PAIR = (MODE & MODE_PAIR) != 0, SINUS = (MODE & MODE_SINUS) != 0;
 	f2 x[ITS][R];
 	// ---- inputs (all of them before the first output is written: the exchange is in place)
 	// (the last iteration of a pass whose NB is no multiple of 64: the idle lanes run butterfly NB - 1 again and keep its outputs to
@@ -298,15 +305,26 @@ OCT_DEV void pass(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_
 				const f2 z = x[it][u] - mean[it * ((R + 1) / 2) + u];
 				const float pw = z.x * z.x + z.y * z.y;
 				const float s = LOGSCALE ? __builtin_amdgcn_logf(pw) : __builtin_amdgcn_sqrtf(pw);
-				store_image_masked<BG>(sink.sA * s + sink.sB, sink.out0, termL, bIn[it] * 4, u * NB * 4, active[it]);
+				const float o = sink.sA * s + sink.sB;
+				if constexpr (SINUS) {
+					// cu:506-510 on the pair (previous row, this row); every value through store_image, i.e. through the background removal that follows the correction
+					static_assert(PREVN == MEANN, "one previous value per kept bin of the lane");
+					const float pv = prev[it * ((R + 1) / 2) + u];
+					prev[it * ((R + 1) / 2) + u] = o;
+					if (sink.st0) store_image_masked<BG>(sinus_blend(pv, o, sink.f0), sink.out0, termL, bIn[it] * 4, u * NB * 4, active[it]);
+					if (sink.st1) store_image_masked<BG>(sinus_blend(pv, o, sink.f1), sink.out1, termL, bIn[it] * 4, u * NB * 4, active[it]);
+					if (sink.raw) store_image_masked<BG>(o, sink.outL, termL, bIn[it] * 4, u * NB * 4, active[it]);
+				} else {
+					store_image_masked<BG>(o, sink.out0, termL, bIn[it] * 4, u * NB * 4, active[it]);
+				}
 			}
 	}
 }
 
-template <class P, int p, int RS, int MODE, int MEANN, bool LUTL>
-OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const f32x4* lutL, const Sink& sink, const f2 (&mean)[MEANN], const float* termL, int lane) {
-	pass<P, p, RS, MODE, MEANN, LUTL>(row, xb, twL, lutR, lutL, sink, mean, termL, lane);
-	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN, LUTL>(row, xb, twL, lutR, lutL, sink, mean, termL, lane);
+template <class P, int p, int RS, int MODE, int MEANN, bool LUTL, int PREVN>
+OCT_DEV void passes_from(const float* row, f2* xb, const f2* twL, __amdgpu_buffer_rsrc_t lutR, const f32x4* lutL, const Sink& sink, const f2 (&mean)[MEANN], float (&prev)[PREVN], const float* termL, int lane) {
+	pass<P, p, RS, MODE, MEANN, LUTL, PREVN>(row, xb, twL, lutR, lutL, sink, mean, prev, termL, lane);
+	if constexpr (p + 1 < P::PASSES) passes_from<P, p + 1, RS, MODE, MEANN, LUTL, PREVN>(row, xb, twL, lutR, lutL, sink, mean, prev, termL, lane);
 }
 
 // INTYPE: IN_U16 (raw rows, bitDepth 9..16) or IN_F32 (rows prepared by oct_prepare[_rows]_kernel: other containers, wide rolling-average
@@ -321,7 +339,8 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	constexpr PlanDesc D = P::D;
 	constexpr int N = D.N, HALF = N / 2, LP = D.passes - 1, RL = D.radix[LP], NBL = N / RL;
 	constexpr int MEANN = pd_its(D, LP) * ((RL + 1) / 2);
-	constexpr bool BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0, PAIR = (MODE & MODE_PAIR) != 0, LOGSCALE = (MODE & MODE_LOG) != 0;
+	constexpr bool BG = (MODE & MODE_BG) != 0, ROLL = (MODE & MODE_ROLL) != 0, PAIR = (MODE & MODE_PAIR) != 0, LOGSCALE = (MODE & MODE_LOG) != 0, SINUS = (MODE & MODE_SINUS) != 0;
+	static_assert(!SINUS || (INTYPE == IN_U16 && !PAIR && !(MODE & MODE_SPECTRUM) && RS != RS_LANCZOS && pd_sinus_ok(D, RS, ROLL)), "sinusoidal correction in the store: image output of the raw-row variants, the previous row in registers");
 	static_assert(!ROLL || INTYPE == IN_U16, "the rolling average inside the kernel works on the raw integers");
 	static_assert(!PAIR || (INTYPE == IN_U16 && !ROLL && !(MODE & MODE_SPECTRUM) && RS != RS_LANCZOS), "two A-scans per transform: raw uint16 rows, image output");
 	static_assert(!(RS == RS_LANCZOS && ROLL), "Lanczos taps cross line borders: the rolling average of the neighbour rows comes prepared");
@@ -393,9 +412,18 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 	}
 	// one unit of work per wave and iteration: an A-scan, or (PAIR) the A-scans 2 i and 2 i + 1 (an odd last one: a row of zeros as partner)
 	const unsigned units = PAIR ? (a.numLines + 1u) / 2u : a.numLines;
+	// MODE_SINUS: every wave (team) walks blocks of the work list instead (kernels.h SinusWalk; no row prefetch in this kernel)
+	SinusWalk sw;
+	float prev[SINUS ? MEANN : 1] = {};
+	unsigned unit = blockIdx.x * (W / T) + wave;
+	if constexpr (SINUS) unit = sw.begin(a, blockIdx.x * (W / T) + wave, gridDim.x * (W / T));
 	prologue_wait();  // (kernels.h: nothing of the prologue pending inside the loop)
-	for (unsigned unit = blockIdx.x * (W / T) + wave; unit < units; unit += gridDim.x * (W / T)) {
+	while (unit < units) {
 		const unsigned line = PAIR ? 2u * unit : unit;
+		if constexpr (SINUS) {
+			sw.load_ahead();
+			(void)sw.peek_next();
+		}
 		if constexpr (RS == RS_LANCZOS) {
 			// Lanczos taps cross line borders (cu:313-321): stage [off - 8, off + N + 8) of the BUFFER, off = clamp(line N, 8, S - 9) (the
 			// reference's first-line quirk), zeros outside -- the staging of the general kernel (kernels.h), 8 samples per lane and load
@@ -495,7 +523,12 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 		}
 		team_sync<T>();
 		unsigned orow[2] = {line, line + 1u};
-		if (a.flip) {
+		if constexpr (SINUS) {
+			orow[0] = sw.out_row();
+			orow[1] = orow[0] + 1u;
+			sw.pair(&sink.f0, &sink.f1, &sink.st0, &sink.st1, &sink.raw);
+			sink.outL = make_rsrc(a.out + (size_t)(a.linesInBuffer - 1u) * HALF, HALF * 4);
+		} else if (a.flip) {
 #pragma unroll
 			for (int r = 0; r < (PAIR ? 2 : 1); r++) {
 				const unsigned ln = line + (unsigned)r, bs = ln / a.ascansPerBscan, as = ln - bs * a.ascansPerBscan;
@@ -503,10 +536,16 @@ OCT_DEV void body(const FusedArgs& a, char* smem) {
 			}
 		}
 		sink.out0 = make_rsrc(a.out + (size_t)orow[0] * HALF, HALF * 4);
-		sink.out1 = make_rsrc(a.out + (size_t)orow[1] * HALF, (PAIR && line + 1u < a.numLines) ? HALF * 4 : 0);
+		sink.out1 = make_rsrc(a.out + (size_t)orow[1] * HALF, ((PAIR && line + 1u < a.numLines) || SINUS) ? HALF * 4 : 0);
 		sink.spec = make_rsrc(a.spectrum + (size_t)line * N, (MODE & MODE_SPECTRUM) ? N * 8 : 0);
-		passes_from<P, 0, RS, MODE, MEANN, LUTL>(row, xb, twL, lutR, lutL, sink, mean, termL, lane);
+		passes_from<P, 0, RS, MODE, MEANN, LUTL, (SINUS ? MEANN : 1)>(row, xb, twL, lutR, lutL, sink, mean, prev, termL, lane);
 		team_sync<T>();  // the last pass' reads of the slice precede the next row
+		if constexpr (SINUS) {
+			bool newBlock;
+			unit = sw.advance(&newBlock);
+		} else {
+			unit += gridDim.x * (W / T);
+		}
 	}
 }
 

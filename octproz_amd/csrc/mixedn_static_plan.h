@@ -38,6 +38,7 @@ constexpr int pd_twoff(const PlanDesc& d, int p) { int o = 0; for (int q = 1; q 
 constexpr int pd_twelems(const PlanDesc& d) { return pd_twoff(d, d.passes); }
 constexpr int pd_its(const PlanDesc& d, int p) { return (d.N / d.radix[p] + pd_lanes(d) - 1) / pd_lanes(d); }
 constexpr int pd_values(const PlanDesc& d) { int v = 0; for (int p = 0; p < d.passes; p++) { const int w = pd_its(d, p) * d.radix[p]; v = w > v ? w : v; } return v; }
+constexpr int pd_sinus_prev(const PlanDesc& d) { return pd_its(d, d.passes - 1) * ((d.radix[d.passes - 1] + 1) / 2); }  // (= MEANN of the kernel body)
 constexpr int pd_row_bytes(const PlanDesc& d) { return ((d.N + 2 * ROW_OFF) * 4 + 15) & ~15; }
 // (roll: the rolling average inside the kernel keeps a [ROLL_PAD | N | ROLL_PAD] array of prefix sums behind the staged row;
 // pair: two rows staged interleaved, 8 bytes per sample)
@@ -78,6 +79,17 @@ constexpr int pd_waves(const PlanDesc& d, bool bg, int rs, bool roll = false, bo
 #ifndef OCT_MXS_LUT_LDS
 #define OCT_MXS_LUT_LDS 1
 #endif
+// MODE_SINUS (round 6) keeps the previous row's grey values of a lane's kept bins in registers (pd_sinus_prev of them).  Which lengths can afford that is a
+// register question, answered from compiled code: at the 168-register budget (more than 8 waves) N = 1000 / 1200 / 1536 fit (20-32 values, 10-12 bins; at most one register spilled) while
+// N = 1800 / 1920 (32 values, 16 bins) spill 51-83 registers; at 256 registers up to 20 bins fit (N = 2000 ... 2560: 0-1 spilled) except on the four-pass plans
+// (N = 2500: 7 spilled, 24 % slower than the post pass); next to the rolling average's window bookkeeping 12 bins (N = 2500 with both: 75 spilled).
+// One wave per A-scan only (the two-wave lengths keep 24 bins per lane).
+constexpr bool pd_sinus_ok(const PlanDesc& d, int rs, bool roll) {
+	const int waves = pd_waves(d, false, rs, roll, false), prev = pd_sinus_prev(d);
+	if (pd_team(d) > 1 || waves < 1 || (roll && prev > 12)) return false;
+	if (waves > 8) return pd_values(d) <= 32 && prev <= 12;
+	return prev <= 20 && d.passes <= 3;
+}
 constexpr int pd_lut_bytes(const PlanDesc& d, int waves, bool bg, bool roll = false, bool pair = false) {
 	const int rest = pd_tw_bytes(d) + (waves / pd_team(d)) * pd_slice_bytes(d, roll, pair) + (bg ? d.N * 2 : 0);
 	return (OCT_MXS_LUT_LDS != 0 && rest + d.N * 16 <= 160 * 1024) ? d.N * 16 : 0;

@@ -210,7 +210,7 @@ void prefetchRunTimeVariants(const octpipe* h, const OctPipeParams& q0) {
 		const bool wantBg = q.postProcessBackgroundRemoval && !q.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG);
 		const oct::RoutePlan img = oct::choose_route(facts, q, false, wantBg, false, false, h->d_sinusEnt != nullptr);
 		if (img.kind == oct::ROUTE_KIND_MXS && !img.error)
-			oct::mixedn_rtc_prefetch(h->mxsPlan, img.intype, img.rs, img.roll, img.pair, false, q.signalLogScaling != 0, img.bgFused, h->arch.c_str());
+			oct::mixedn_rtc_prefetch(h->mxsPlan, img.intype, img.rs, img.roll, img.pair, false, q.signalLogScaling != 0, img.bgFused, h->arch.c_str(), img.sinusFused);
 		if (q.fixedPatternNoiseRemoval) {
 			const oct::RoutePlan sp = oct::choose_route(facts, q, true, false, false, false, false);
 			if (sp.kind == oct::ROUTE_KIND_MXS && !sp.error) oct::mixedn_rtc_prefetch(h->mxsPlan, sp.intype, sp.rs, sp.roll, sp.pair, true, false, false, h->arch.c_str());
@@ -222,6 +222,7 @@ void prefetchRunTimeVariants(const octpipe* h, const OctPipeParams& q0) {
 	q.signalLogScaling = !q0.signalLogScaling; one(q); q = q0;
 	q.backgroundRemoval = !q0.backgroundRemoval; if (q.backgroundRemoval && q.rollingAverageWindowSize <= 0) q.rollingAverageWindowSize = 64; one(q); q = q0;
 	q.postProcessBackgroundRemoval = !q0.postProcessBackgroundRemoval; one(q); q = q0;
+	q.sinusoidalScanCorrection = !q0.sinusoidalScanCorrection; one(q); q = q0;
 	q.fixedPatternNoiseRemoval = 1; one(q); q = q0;
 	for (int mode = 0; mode < 4; ++mode) {  // off, linear, cubic, Lanczos
 		q.resampling = mode != 0;
@@ -279,7 +280,7 @@ oct::RouteFacts routeFacts(const octpipe* h) {
 	f.N = h->N; f.log2n = h->log2n; f.bytesPerSample = h->bytesPerSample; f.sampleFormat = h->sampleFormat;
 	f.bitDepth = h->acq.bitDepth; f.route = h->route; f.S = h->S;
 	f.libfft = h->libfft; f.fftLibBound = h->fftExecC2C != nullptr || h->fftLazy; f.bluestein = h->bluestein; f.mixed = h->mixed;
-	f.mixedN = h->mixedN; f.mixedStatic = h->mixedStatic; f.teamTables = h->d_twTeam != nullptr && !h->mixed; f.forcePrepared = h->forcePrepared;
+	f.mixedN = h->mixedN; f.mixedStatic = h->mixedStatic; f.mxsPlan = h->mxsPlan; f.teamTables = h->d_twTeam != nullptr && !h->mixed; f.forcePrepared = h->forcePrepared;
 	f.rowsLds = rowsKernelLds(h);
 	return f;
 }

@@ -156,7 +156,9 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 	const bool sinusTeam = sinusWanted && f.teamTables && !f.mixed && !(route & OCTPIPE_ROUTE_NO_TEAM) && (teamLib || !f.libfft) && !(roll && rs == RS_CUBIC);
 	// ... and the two-wave team kernel of N = 1664 (team1664_kernel.h MODE_SINUS: every resampling mode it has, with or without the rolling average)
 	const bool sinus1664 = sinusWanted && f.mixed && mixedDirect && !(route & OCTPIPE_ROUTE_NO_TEAM);
-	const bool sinusOk = sinusGeneral || sinusTeam || sinus1664;
+	// ... and the kernels compiled at run time (mixedn_static.h MODE_SINUS), one A-scan per transform, where a lane's bins of the previous row fit in registers
+	const bool sinusMxs = sinusWanted && mxn && mxnStatic && !teamLib && mxnDirect && mxs::pd_sinus_ok(f.mxsPlan, rs, roll);  // (mxsPlan: the plan the kernel is compiled for)
+	const bool sinusOk = sinusGeneral || sinusTeam || sinus1664 || sinusMxs;
 	// post-process background removal inside the image store of the fused / team / mixed-radix kernels: every container they read
 	// and the prepared float32 rows, with or without the rolling average inside the kernel; not on Bluestein or the library route
 	// (a mixed-radix handle keeps its Bluestein tables for OCTPIPE_ROUTE_NO_MIXED: `bluestein` alone says nothing there)
@@ -170,6 +172,7 @@ inline RoutePlan choose_route(const RouteFacts& f, const OctPipeParams& p, bool 
 		r.kind = ROUTE_KIND_MXS;
 		r.path |= OCTPIPE_PATH_MIXED_RADIX | OCTPIPE_PATH_STATIC_PLAN | (roll ? OCTPIPE_PATH_ROLL_IN_KERNEL : 0);
 		r.pair = realOk && !spectrum;
+		if (sinusMxs) { r.sinusFused = true; r.path |= OCTPIPE_PATH_FUSED_SINUS; }
 	} else if (mxn && !teamLib) {
 		r.kind = ROUTE_KIND_MXN;
 		r.path |= OCTPIPE_PATH_MIXED_RADIX;

@@ -46,7 +46,20 @@ ROUTING = [
     (1664, {"resamplingInterpolation": 0}, 0, _P.ROUTE_TEAM1664_ALWAYS | _P.ROUTE_NO_REAL_INPUT, _P.PATH_TEAM),
     (1664, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX),                         # Lanczos: post pass
     (1664, {"sinusoidalScanCorrection": 1}, 1, 0, _P.PATH_TEAM | _P.PATH_PREPARED_ROWS),                                      # packed 12 bit rows: prepared, post pass
-    (1000, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
+    # ... and of the kernels compiled at run time, where a lane's bins of the previous row fit in registers (round 6)
+    (1000, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_FUSED_SINUS),
+    (1000, {"sinusoidalScanCorrection": 1, "dispersionCompensation": 0}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_FUSED_SINUS),  # one A-scan per transform then
+    (1000, {"sinusoidalScanCorrection": 1, "postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0,
+     _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_FUSED_SINUS | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
+    (1000, {"sinusoidalScanCorrection": 1}, 0, _P.ROUTE_NO_FUSED_SINUS, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),
+    (1000, {"sinusoidalScanCorrection": 1, "resamplingInterpolation": 2}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),           # Lanczos: post pass
+    (1000, {"sinusoidalScanCorrection": 1}, 0, _P.ROUTE_NO_MIXEDN_STATIC, _P.PATH_MIXED_RADIX),                                          # the run-time-plan kernel: post pass
+    (2000, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_FUSED_SINUS),                   # 20 bins per lane
+    (2000, {"sinusoidalScanCorrection": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN | _P.PATH_ROLL_IN_KERNEL),  # ... too many next to the rolling average
+    (3000, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                                          # 25 bins per lane: post pass
+    (1800, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                                          # 30 values + 16 bins at the 168-register budget: post pass
+    (2500, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                                          # four passes: post pass (measured faster)
+    (6144, {"sinusoidalScanCorrection": 1}, 0, 0, _P.PATH_MIXED_RADIX | _P.PATH_STATIC_PLAN),                                          # two waves per A-scan, 24 bins per lane: post pass
     (1024, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
     (4096, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),
     (1664, {"postProcessBackgroundRemoval": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64}, 0, 0, _P.PATH_TEAM | _P.PATH_FUSED_BG | _P.PATH_ROLL_IN_KERNEL),

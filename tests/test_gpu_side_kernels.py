@@ -66,8 +66,8 @@ def test_post_pass_sinusoidal_and_background_bit_exact(N, A, B, sinus, bg):
 
 
 def test_the_post_pass_cases_above_took_the_store_where_it_exists():
-    """(1024, 24, 3), (256, 5, 2), (512, 130, 1) above run the correction inside the fused kernel's image store (round 6); 300 and 2046 keep the post pass"""
-    for N, A, B, want in ((1024, 24, 3, True), (256, 5, 2, True), (512, 130, 1, True), (300, 7, 2, False), (2046, 3, 2, False), (1024, 2, 4, False)):
+    """(1024, 24, 3), (256, 5, 2), (512, 130, 1) above run the correction inside the fused kernel's image store, (300, 7, 2) inside the run-time compiled kernel's (round 6); 2046 (library route) keeps the post pass"""
+    for N, A, B, want in ((1024, 24, 3, True), (256, 5, 2, True), (512, 130, 1, True), (300, 7, 2, True), (2046, 3, 2, False), (1024, 2, 4, False)):
         p = v180_benchmark_params(N, A, B)
         p.sinusoidalScanCorrection = 1
         pipe = Pipeline(p, device=0)
@@ -111,6 +111,15 @@ SINUS_STORE_CASES = [
     (1664, 70, 3, {"resampling": 0, "dispersionCompensation": 0, "bscanFlip": 1, "signalLogScaling": 0}, _lib.ROUTE_TEAM1664_ALWAYS, 0),
     (1664, 500, 5, {"bscanFlip": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64, "postProcessBackgroundRemoval": 1}, _lib.ROUTE_TEAM1664_ALWAYS, 0),
     (1664, 600, 4, {"resamplingInterpolation": 0, "backgroundRemoval": 1, "rollingAverageWindowSize": 16}, _lib.ROUTE_TEAM1664_ALWAYS, 1),  # more rows than teams
+    # the kernels compiled at run time (mixedn_static.h MODE_SINUS, the previous row in registers)
+    (1000, 512, 2, {"bscanFlip": 1}, 0, 0),
+    (1000, 130, 3, {"resamplingInterpolation": 0, "postProcessBackgroundRemoval": 1, "signalLogScaling": 0}, 0, 2),
+    (1000, 70, 5, {"bscanFlip": 1, "backgroundRemoval": 1, "rollingAverageWindowSize": 64, "postProcessBackgroundRemoval": 1}, 0, 0),
+    (1000, 64, 40, {"dispersionCompensation": 0, "bscanFlip": 1}, _lib.ROUTE_TINY_GRID, 3),   # two workgroups: every wave walks many blocks
+    (1200, 100, 3, {"resampling": 0}, 0, 0),
+    (1536, 96, 2, {"bscanFlip": 1}, 0, 1),
+    (2000, 60, 3, {"postProcessBackgroundRemoval": 1}, 0, 0),
+    (2304, 40, 2, {"bscanFlip": 1}, 0, 0),
 ]
 
 
@@ -172,13 +181,13 @@ _SINUS_FUZZ = {"draws": 0, "fused": 0}
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SINUS_SEEDS", "300"))))
 def test_sinusoidal_correction_in_the_store_random_shapes_and_settings(seed):
-    """the same three-way identity on drawn configurations: every length with an in-store variant, B-scan widths from 2 to 700 (few, odd, prime, more
+    """the same three-way identity on drawn configurations: every dedicated length with an in-store variant and five run-time compiled ones, B-scan widths from 2 to 700 (few, odd, prime, more
     pairs than persistent waves), 1-6 B-scans per buffer, every setting that composes with the correction, every block size of the work list.
     Draws the routing function keeps on the post pass (Lanczos, cubic + rolling average at some lengths, A = 2) still compare the default route
     with the oracle through the post-pass handle."""
     rng = np.random.default_rng(9000 + seed)
-    N = int(rng.choice([256, 512, 1024, 1024, 2048, 4096, 8192, 1664, 1664]))
-    cap = {256: 4000, 512: 3000, 1024: 2400, 2048: 1200, 4096: 500, 8192: 160, 1664: 1500}[N]
+    N = int(rng.choice([256, 512, 1024, 1024, 2048, 4096, 8192, 1664, 1664, 1000, 1000, 1200, 1536, 2000]))
+    cap = {256: 4000, 512: 3000, 1024: 2400, 2048: 1200, 4096: 500, 8192: 160, 1664: 1500, 1000: 2400, 1200: 2000, 1536: 1500, 2000: 1200}[N]
     B = int(rng.integers(1, 7))
     A = int(rng.choice([2, 3, 4, 5, 7, 17, 31, 64, 100, 130, 257, 512, 700]))
     A = max(2, min(A, cap // B))

@@ -178,3 +178,18 @@ def test_opt_in_disk_cache_of_compiled_kernels(tmp_path):
     n = len(os.listdir(d))
     _compile(1260, IN_U16, RS_NONE, MODE_LOG)
     assert len(os.listdir(d)) == n  # switched off again: nothing is written
+
+
+@needs_hiprtc
+@pytest.mark.parametrize("n,ok", [(1000, True), (300, True), (1536, True), (2000, True), (2304, True), (1800, False), (2500, False), (3000, False), (6144, False)])
+def test_in_store_sinusoidal_instances_compile_where_the_routing_function_offers_them(n, ok):
+    """MODE_SINUS = 32 (round 6): the previous row's grey values of a lane's bins in registers.  The kernel's static_assert and the routing function share one
+    rule (mixedn_static_plan.h pd_sinus_ok): lengths it refuses do not compile, and octpipe_debug_route never sends them there (tests/routing_table.py)"""
+    for rs, mode in ((RS_CUBIC, MODE_LOG | 32), (RS_NONE, MODE_BG | 32)):
+        rc, radices, waves, code, sec, err = _compile(n, IN_U16, rs, mode)
+        assert (rc == 0) == ok, (n, rs, mode, err[:300])
+    # next to the rolling average twelve bins per lane at most
+    rc, radices, waves, code, sec, err = _compile(n, IN_U16, RS_LINEAR, MODE_LOG | 32 | 1)
+    assert (rc == 0) == (ok and n not in (2000, 2304)), (n, err[:300])
+    # prepared rows and two A-scans per transform never
+    assert _compile(n, IN_F32, RS_CUBIC, MODE_LOG | 32)[0] != 0 and _compile(n, IN_U16, RS_CUBIC, MODE_LOG | 32 | 16)[0] != 0
