@@ -980,39 +980,10 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	if (OCT_XCD_REMAP != 0 && (gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
 	unsigned line = (blk * (unsigned)WAVES + (unsigned)wave) * BLK;
 	unsigned inBlock = 0;  // position of `line` inside its block
-	// MODE_SINUS: the wave's walk over the work list (FusedArgs::sinEnt; everything here is wave-uniform and lives in scalar registers).
-	// sBlk: the wave's block; sT / sTEnd: position in it and its last position.  Entries are read with scalar loads through the constant
-	// address space, two A-scans ahead of their use: sE0 = the entry of the row being processed (its pair is written by the epilogue),
-	// sE1 = the next one (its raw row is prefetched while this row is staged), sE2 = in flight.  sI2: index of sE2's entry in the list;
-	// (sBA, sBB, sFl): first row, number and flip rule of the B-scan of sE1's entry, sBA0 of sE0's.
-	typedef const __attribute__((address_space(4))) u32x4 sin_ent_t;
-	sin_ent_t* sinE = reinterpret_cast<sin_ent_t*>(reinterpret_cast<uintptr_t>(a.sinEnt));
-	unsigned sBlk = 0, sT = 0, sTEnd = 0, sI2 = 0, sBA = 0, sBA0 = 0, sBB = 0, sNext = 0xFFFFFFFFu;
-	bool sFl = false;
-	u32x4 sE0 = u32x4{0u, 0u, 0u, 0u}, sE1 = sE0, sE2 = sE0;
-	auto sin_flip = [&](unsigned bb) -> bool { return a.flip && (bb & 1u) == 0u && (bb + 2u) * a.ascansPerBscan <= a.linesInBuffer; };  // (flipped_row's rule)
-	auto sin_row = [&](unsigned ba, bool fl, uint32_t x) -> unsigned { const unsigned pp = x & 0xffffu; return ba + (fl ? a.ascansPerBscan - 1u - pp : pp); };
-	auto sin_wrap = [&](unsigned i) -> unsigned { return i + 1u == a.sinM ? 0u : i + 1u; };
-	// the first entry of block sBlk -> `line`, the following two entries under way (one exposed scalar round trip per BLOCK)
-	auto sin_enter_block = [&]() {
-		const unsigned g0 = sBlk * a.sinBlk, last = a.sinTotal - 1u;
-		sTEnd = min(a.sinBlk, last - g0);
-		sT = 0;
-		const unsigned bb = g0 / a.sinM, i0 = g0 - bb * a.sinM, i1 = sin_wrap(i0);
-		sE0 = sinE[i0];
-		sE1 = sinE[i1];
-		sI2 = sin_wrap(i1);
-		sBA0 = bb * a.ascansPerBscan;
-		line = sin_row(sBA0, sin_flip(bb), sE0.x);
-		sBB = i1 == 0u ? bb + 1u : bb;
-		sBA = sBB * a.ascansPerBscan;
-		sFl = sin_flip(sBB);
-	};
-	if constexpr (SINUS) {
-		sBlk = blk * (unsigned)WAVES + (unsigned)wave;
-		if (sBlk * a.sinBlk + 1u < a.sinTotal) sin_enter_block();
-		else line = 0xFFFFFFFFu;
-	}
+	// MODE_SINUS: the wave's walk over the work list (SinusWalk above: everything in it is wave-uniform and lives in scalar registers; entries arrive by
+	// scalar loads, two A-scans ahead of their use)
+	SinusWalk sw;
+	if constexpr (SINUS) line = sw.begin(a, blk * (unsigned)WAVES + (unsigned)wave, wavesTotal);
 	// the A-scan this wave processes after `ln` (>= numLines: none)
 	auto next_line = [&](unsigned ln, unsigned pos) -> unsigned {
 		if (BLK > 1u && pos + 1u < BLK) return ln + 1u;   // (beyond the buffer only in the buffer's last block: nothing follows it)
@@ -1035,24 +1006,12 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 	// (its entries and its first raw row are fetched here, one exposed round trip each per BLOCK)
 	auto advance = [&]() {
 		if constexpr (SINUS) {
-			if (sT < sTEnd) {
-				sT++;
-				line = sNext;
-				sE0 = sE1; sBA0 = sBA;
-				sE1 = sE2;
-				// (sE1 is now the entry at list index sI2: index 0 is the first row of the next B-scan)
-				if (sI2 == 0u) { sBB++; sBA += a.ascansPerBscan; sFl = sin_flip(sBB); }
-				sI2 = sin_wrap(sI2);
-			} else {
-				sBlk += wavesTotal;
-				if (sBlk * a.sinBlk + 1u < a.sinTotal) {
-					sin_enter_block();
-					const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
+			bool newBlock;
+			line = sw.advance(&newBlock);
+			if (newBlock && line < lineEnd) {  // (inside a block the row was prefetched while its predecessor was staged)
+				const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)line * rowBytes, rowBytes);
 #pragma unroll
-					for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
-				} else {
-					line = 0xFFFFFFFFu;
-				}
+				for (int i = 0; i < NL; i++) pre[i] = load_chunk<INTYPE, N>(rawR, lane * CB, i * 64 * CB);
 			}
 		} else {
 			line = next_line(line, inBlock);
@@ -1149,7 +1108,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 #ifndef OCT_SINUS_LOAD_AT
 #define OCT_SINUS_LOAD_AT 0
 #endif
-		if constexpr (SINUS && OCT_SINUS_LOAD_AT == 0) sE2 = sinE[sI2];  // (two A-scans ahead of its use)
+		if constexpr (SINUS && OCT_SINUS_LOAD_AT == 0) sw.load_ahead();  // (the entry two A-scans ahead of its use)
 		// ---- stage the raw row in LDS as float32
 		if constexpr (RS != RS_LANCZOS) {
 			bool staged = false;
@@ -1257,7 +1216,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 				}
 			}
 			unsigned next;  // prefetch the next row of this wave
-			if constexpr (SINUS) { next = sT < sTEnd ? sin_row(sBA, sFl, sE1.x) : 0xFFFFFFFFu; sNext = next; }
+			if constexpr (SINUS) next = sw.peek_next();
 			else next = next_line(line, inBlock);
 			if (next < lineEnd) {
 				const __amdgpu_buffer_rsrc_t rawR = make_rsrc(reinterpret_cast<const char*>(a.raw) + (size_t)next * rowBytes, rowBytes);
@@ -1452,7 +1411,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		}
 		wave_sync_lds();  // the row is dead from here on; its LDS is reused by the FFT
 
-		if constexpr (SINUS && OCT_SINUS_LOAD_AT == 1) sE2 = sinE[sI2];
+		if constexpr (SINUS && OCT_SINUS_LOAD_AT == 1) sw.load_ahead();
 		// ---- inverse FFT
 		if constexpr (Cfg<LOG2N>::PRIO) __builtin_amdgcn_s_setprio(OCT_PRIO_FFT);
 		// N = 1024: a fifth priority point behind the reads of the transform's one LDS exchange.  Gather 3 > first pass 2 > rest of the
@@ -1471,7 +1430,7 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 		} else {
 			// ---- mean A-line subtraction, |z|^2, log / lin scaling, flip folded into the address
 			unsigned orow = line;  // output row; only the flip needs the (B-scan, A-scan) split of the line index
-			if constexpr (SINUS) orow = sBA0 + (sE0.x >> 16);  // (the first output A-scan of the pair this row completes)
+			if constexpr (SINUS) orow = sw.out_row();  // (the first output A-scan of the pair this row completes)
 			else if (a.flip) orow = flipped_row(a, line);
 			const __amdgpu_buffer_rsrc_t outR = make_rsrc(a.out + (size_t)orow * (N / 2), N * 2u);
 			constexpr bool BG = (MODE & MODE_BG) != 0;
@@ -1482,15 +1441,8 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 			bool sSt0 = false, sSt1 = false, sRaw = false;
 			__amdgpu_buffer_rsrc_t outR1 = outR, outRL = outR;
 			if constexpr (SINUS) {
-				const uint32_t f0Bits = sE0.y, f1Bits = sE0.z;  // (__builtin_bit_cast on a vector-element expression reads element 0 whatever the swizzle)
-				sF0 = __builtin_bit_cast(float, f0Bits);
-				sF1 = __builtin_bit_cast(float, f1Bits);
+				sw.pair(&sF0, &sF1, &sSt0, &sSt1, &sRaw);  // (the reference's launch bound `i + width < samples`: the buffer's last A-scan is never a blended one)
 				sRow0 = orow;
-				sRaw = sBA0 + (sE0.x & 0xffffu) + 1u == a.linesInBuffer;
-				const bool pair = sT > 0u && sF0 >= 0.0f;
-				// (the reference's launch bound `i + width < samples`: the buffer's last A-scan is never a blended one)
-				sSt0 = pair && sRow0 + 1u != a.linesInBuffer;
-				sSt1 = pair && sF1 >= 0.0f && sRow0 + 2u != a.linesInBuffer;
 				outR1 = make_rsrc(a.out + (size_t)(sRow0 + 1u) * (N / 2), N * 2u);
 				outRL = make_rsrc(a.out + (size_t)(a.linesInBuffer - 1u) * (N / 2), N * 2u);
 			}
