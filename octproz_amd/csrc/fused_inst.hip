@@ -45,10 +45,7 @@ hipError_t launch_one(const FusedArgs& a, int requestedBlocks, hipStream_t strea
 		if (a.sinTotal < 2 || a.sinM == 0 || a.sinEnt == nullptr) return hipErrorInvalidValue;
 		FusedArgs s = a;
 		const unsigned pairs = a.sinTotal - 1u, perWave = a.sinBlk ? a.sinBlk : (unsigned)OCT_SINUS_BLOCKS_PER_WAVE;
-		const unsigned wavesAll = blocks * (unsigned)waves;
-		unsigned len = (pairs + perWave * wavesAll - 1u) / (perWave * wavesAll);
-		if (len < 8u) len = pairs < 8u ? pairs : 8u;
-		if (len > 63u) len = 63u;
+		const unsigned len = sinus_block_len(pairs, perWave, blocks * (unsigned)waves);
 		s.sinBlk = len;
 		const unsigned listBlocks = (pairs + len - 1u) / len, need = (listBlocks + waves - 1) / waves;
 		if (blocks > need) blocks = need;

@@ -1134,8 +1134,9 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 						const uint4 x = chunk_to_uint(pre[i], 0, shift);
 						const uint32_t tot = x.x + x.y + x.z + x.w;
 						const uint32_t incl = wave_inclusive_scan(tot);
-						const uint32_t p0 = base + incl - tot + x.x, p1 = p0 + x.y, p2 = p1 + x.z;
-						*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + 4 * lane + 256 * i]) = uint4{p0, p1, p2, p2 + x.w};
+						// (from the lane's inclusive total downwards: three subtractions instead of an exclusive start plus three additions)
+						const uint32_t p3 = base + incl, p2 = p3 - x.w, p1 = p2 - x.z, p0 = p1 - x.y;
+						*reinterpret_cast<uint4*>(&pfx[ROLL_PAD + 4 * lane + 256 * i]) = uint4{p0, p1, p2, p3};
 						base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 					}
 					// pads (the FFT exchange of the previous A-scan has run over them): 64 lanes x 4 entries on each side
@@ -1185,7 +1186,11 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 						if (whole) {
 #pragma unroll
 							for (int c = 0; c < 4; c++)
+#if OCT_ROLL_FAST == 2  // (round 5's form: both operands as bit patterns under the exponents of 2^23 and 2^(23-k): or, shift, or per sample)
 								o[c] = __builtin_fmaf(-__builtin_bit_cast(float, 0x4B000000u | ws[c]), rcIn, __builtin_bit_cast(float, xBias | (xs[c] << kLog)));
+#else                   // s and x converted (exact: integers below 2^24), s 2^-k exact, one rounding: two conversions per sample
+								o[c] = __builtin_fmaf((float)ws[c], -rcIn, (float)xs[c]);
+#endif
 						} else
 #pragma unroll
 						for (int c = 0; c < 4; c++) {

@@ -137,6 +137,16 @@ int mixed1664_lanczos_unit(int sample, int c);  // 16-byte unit of weights 4 c .
 // the same length with a real transform input (no dispersion compensation): two A-scans per transform (mixed1664_real2.h)
 hipError_t launch_mixed1664_real2(int rs, bool logScale, const FusedArgs& a, hipStream_t stream);
 
+// MODE_SINUS launches (kernels.h SinusWalk): the work list of a buffer (`pairs` + 1 entries, sinus_plan.h) is walked in blocks of `len` pairs, neighbours sharing
+// one entry: about `perWalker` blocks per walker (a wave or a team of waves; 0 = one), 8 ... 63 pairs per block
+inline unsigned sinus_block_len(unsigned pairs, unsigned perWalker, unsigned walkers) {
+	if (perWalker == 0u) perWalker = 1u;
+	if (walkers == 0u) walkers = 1u;
+	unsigned len = (pairs + perWalker * walkers - 1u) / (perWalker * walkers);
+	if (len < 8u) len = pairs < 8u ? pairs : 8u;
+	if (len > 63u) len = 63u;
+	return len;
+}
 // every other even length whose prime factors lie in {2, 3, 5, 7, 11, 13} and whose tables fit the LDS: generic mixed-radix kernel
 // (mixedn_kernel.h).  mixedn_plan: the radices of its passes (at most 8); launch_mixedn: FusedArgs::twiddle = W_N^j, j < N
 bool mixedn_plan(unsigned n, int* passes, int* radix, bool simpleRadicesOnly = false);

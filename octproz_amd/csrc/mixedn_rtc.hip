@@ -542,10 +542,7 @@ hipError_t launch_mixedn_rtc(const mxs::PlanDesc& d, int intype, int rs, bool ro
 			// the work list of the buffer in blocks of sinBlk + 1 entries, one block per wave (team) by default (fused_inst.hip launch_one: the same rule)
 			blocks = (unsigned)m.numCU;
 			if (maxBlocks > 0 && blocks > (unsigned)maxBlocks) blocks = (unsigned)maxBlocks;
-			const unsigned pairs = a.sinTotal - 1u, perWalker = a.sinBlk ? a.sinBlk : 1u, walkers = blocks * perGroup;
-			unsigned len = (pairs + perWalker * walkers - 1u) / (perWalker * walkers);
-			if (len < 8u) len = pairs < 8u ? pairs : 8u;
-			if (len > 63u) len = 63u;
+			const unsigned pairs = a.sinTotal - 1u, len = sinus_block_len(pairs, a.sinBlk, blocks * perGroup);
 			args.sinBlk = len;
 			const unsigned listBlocks = (pairs + len - 1u) / len, needGroups = (listBlocks + perGroup - 1u) / perGroup;
 			if (blocks > needGroups) blocks = needGroups;

@@ -18,10 +18,7 @@ hipError_t launch_team1664_one(const FusedArgs& a, hipStream_t stream) {
 		// the work list of the buffer in blocks of sinBlk + 1 entries, one block per team by default (team_inst.hip launch_team_one: the same rule)
 		if (a.sinTotal < 2 || a.sinM == 0 || a.sinEnt == nullptr) return hipErrorInvalidValue;
 		FusedArgs s = a;
-		const unsigned pairs = a.sinTotal - 1u, perTeam = a.sinBlk ? a.sinBlk : 1u;
-		unsigned len = (pairs + perTeam * blocks - 1u) / (perTeam * blocks);
-		if (len < 8u) len = pairs < 8u ? pairs : 8u;
-		if (len > 63u) len = 63u;
+		const unsigned pairs = a.sinTotal - 1u, len = sinus_block_len(pairs, a.sinBlk, blocks);
 		s.sinBlk = len;
 		const unsigned listBlocks = (pairs + len - 1u) / len;
 		if (blocks > listBlocks) blocks = listBlocks;
