@@ -1149,10 +1149,11 @@ __global__ __launch_bounds__((KCfg<LOG2N, RS, (MODE & 1) != 0>::WAVES) * 64, (KC
 					const float cntIn = (float)(2 * W), rcIn = __fdiv_rn(1.0f, cntIn);
 					const bool quad = (W & 3) == 0;  // (uniform) the lane's four P[j +- W] are 16-byte aligned: one ds_read_b128 each
 					// Whole windows whose length 2 W is a power of two 2^k (the GUI's default W = 64; rollExact == 2): s / 2^k is exact, so the
-					// reference's x - RN(s / cnt) is ONE rounding of x - s 2^-k, and with s and x placed under the exponents of 2^23 and
-					// 2^(23-k) as bit patterns -- (2^23 + s) and (2^(23-k) + x) exactly -- that is one FMA: -(2^23 + s) 2^-k + (2^(23-k) + x).
-					// Five instructions per sample (subtract, or, extract, shift-or, fma) instead of nine (two conversions, multiply, two FMAs
-					// of the exact quotient, subtract); the first and the last chunk, where windows are clipped, keep the general form.
+					// reference's x - RN(s / cnt) is ONE rounding of x - s 2^-k: one FMA on the converted sum and sample (both integers below 2^24:
+					// exact).  Three and a half instructions per sample (subtract, two conversions, half a packed FMA) instead of nine (two
+					// conversions, multiply, two FMAs of the exact quotient, subtract); the first and the last chunk, where windows are clipped, keep
+					// the general form.  (OCT_ROLL_FAST == 2: round 5's form of the same FMA, its operands built as bit patterns under the exponents of
+					// 2^23 and 2^(23-k) -- or, shift, or per sample; equal within the noise, profiles/r6z_roll_trim_ab.txt)
 #ifndef OCT_ROLL_FAST
 #define OCT_ROLL_FAST 1  // Round 5, first measurement: 1 % SLOWER than the general form (profiles/r5k_roll_fast_ab.txt) -- the variant was waiting on
                          // its dependent LDS round trips, not on instruction issue.  With the window sums, the tap reads and the LDS twiddles read in
