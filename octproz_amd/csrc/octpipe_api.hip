@@ -293,7 +293,7 @@ oct::RoutePlan imagePlan(const octpipe* h, bool wantBg, const DispFold* wantDisp
 // preparedDone: the prepared float32 rows of this buffer are already in h->d_prepared (the retry on another route after a run-time
 // compilation failed: the prepare kernel is not enqueued twice)
 int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2* spectrumOut, float* out, bool timeIt, bool wantBg = false,
-                bool* bgApplied = nullptr, const DispFold* wantDisp = nullptr, bool* dispApplied = nullptr, bool preparedDone = false) {
+                bool* bgApplied = nullptr, const DispFold* wantDisp = nullptr, bool* dispApplied = nullptr, bool preparedDone = false, bool* sinusApplied = nullptr) {
 	const OctPipeParams& p = h->params;
 	// WHICH implementation: route.h (a pure function of the handle's facts and the parameter snapshot; tests/test_route.py)
 	const oct::RoutePlan plan = oct::choose_route(routeFacts(h), p, spectrum, wantBg, wantDisp != nullptr, wantDisp && wantDisp->bgPostPassFollowsUnlessFused, h->d_sinusEnt != nullptr);
@@ -310,6 +310,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 	}
 	if (bgApplied) *bgApplied = plan.bgFused;
 	if (dispApplied) *dispApplied = plan.dispFused;
+	if (sinusApplied) *sinusApplied = plan.sinusFused;  // (a retry on another route below overwrites it: the caller then owes the post pass)
 	if (plan.bgFused) {
 		int rc = ensure(h, (void**)&h->d_bgTerm, sizeof(float) * (h->N / 2));
 		if (rc) return rc;
@@ -397,7 +398,7 @@ int launchFused(octpipe* h, const void* d_raw, unsigned lines, bool spectrum, f2
 			h->mixedStatic = false;
 			h->rtcMessage = "left the run-time compiled kernel after a failure: " + why;
 			// (the other routes of such a length read the same prepared rows where this one did: same container rule in route.h)
-			return launchFused(h, d_raw, lines, spectrum, spectrumOut, out, timeIt, wantBg, bgApplied, wantDisp, dispApplied, plan.prepared);
+			return launchFused(h, d_raw, lines, spectrum, spectrumOut, out, timeIt, wantBg, bgApplied, wantDisp, dispApplied, plan.prepared, sinusApplied);
 		}
 		HIP_TRY(e);
 		break;
@@ -595,7 +596,8 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 	bool bgRemoval = p.postProcessBackgroundRemoval != 0;
 	const bool wantBgInStore = bgRemoval && !p.postProcessBackgroundRecordingRequested && !(h->route & OCTPIPE_ROUTE_NO_FUSED_BG);
 	bool sinus = p.sinusoidalScanCorrection != 0;  // from here on: "the post pass has to apply the correction"
-	if (sinus && imagePlan(h, wantBgInStore, nullptr).sinusFused) sinus = false;
+	const bool sinusPlanned = sinus && imagePlan(h, wantBgInStore, nullptr).sinusFused;
+	if (sinusPlanned) sinus = false;
 	if (sinus) {
 		if ((rc = ensure(h, (void**)&h->d_sinusTmp, sizeof(float) * (S / 2)))) return rc;
 		d_fusedOut = h->d_sinusTmp;
@@ -632,9 +634,18 @@ int processDeviceRaw(octpipe* h, const void* d_raw) {
 		fold.bgPostPassFollowsUnlessFused = bgRemoval;
 		foldAsked = fold.bscan || fold.enface;
 	}
+	bool sinusInStore = false;
 	if ((rc = launchFused(h, d_raw, (unsigned)(A * B), false, nullptr, d_fusedOut, true, wantBgInStore, &bgFused,
-	                      foldAsked ? &fold : nullptr, &dispFused))) return rc;
+	                      foldAsked ? &fold : nullptr, &dispFused, false, &sinusInStore))) return rc;
 	if (bgFused) bgRemoval = false;
+	if (sinusPlanned && !sinusInStore) {
+		// the variant with the correction in its store could not be had (a run-time compiled kernel whose compilation failed: launchFused has taken the
+		// length's other route, which wrote the UNCORRECTED image into the volume slot): move it to the scratch slot and let the post pass correct it
+		if ((rc = ensure(h, (void**)&h->d_sinusTmp, sizeof(float) * (S / 2)))) return rc;
+		HIP_TRY(hipMemcpyAsync(h->d_sinusTmp, d_fusedOut, sizeof(float) * (S / 2), hipMemcpyDeviceToDevice, h->stream));
+		d_fusedOut = h->d_sinusTmp;
+		sinus = true;
+	}
 
 	if (bgRemoval && p.postProcessBackgroundRecordingRequested) {  // cu:1557-1568: record from the corrected first B-scan, then remove
 		if (sinus && (rc = launchPostPass(h, true, false, d_fusedOut, d_curr))) return rc;

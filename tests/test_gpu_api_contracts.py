@@ -404,6 +404,44 @@ def test_a_failed_run_time_compilation_is_reported_and_survivable():
     o.close()
 
 
+def test_a_failed_compilation_of_the_in_store_correction_variant_still_corrects_the_image():
+    """round 6: the run-time compiled kernels carry the sinusoidal correction in their store (MODE_SINUS), and processDeviceRaw decides BEFORE the launch that no
+    post pass is needed.  When that variant cannot be had at launch time the handle takes the length's other route, which writes the uncorrected image -- the
+    post pass has to follow after all: the result equals, bit for bit, a handle that ran that other route + post pass from the start"""
+    import torch
+    L = _lib.lib()
+    N, A, B = 1200, 40, 3
+    p = v180_benchmark_params(N, A, B)
+    p.fixedPatternNoiseRemoval = 0
+    p.sinusoidalScanCorrection, p.bscanFlip, p.postProcessBackgroundRemoval = 1, 1, 1
+    p.postProcessBackgroundWeight, p.postProcessBackgroundOffset = 0.75, 0.01
+    bgline = (np.random.default_rng(3).random(N // 2) * 0.2).astype(np.float32)
+    p.loadPostProcessingBackground(bgline)
+    p.update_all_curves()
+    raw = synthetic_raw(N, A, B, seed=21)
+    d = torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).to("cuda:0")
+    ref = Pipeline(p, device=0, route=_lib.ROUTE_NO_MIXEDN_STATIC)  # the run-time-plan kernel + post pass
+    ref.process_device(d.data_ptr()); ref.synchronize()
+    assert ref.last_path() & _lib.PATH_MIXED_RADIX and not ref.last_path() & (_lib.PATH_STATIC_PLAN | _lib.PATH_FUSED_SINUS)
+    want = ref.processed_host()
+    ref.close()
+    try:
+        p.loadPostProcessingBackground(bgline)
+        good = Pipeline(p, device=0)
+        good.process_device(d.data_ptr()); good.synchronize()
+        assert good.last_path() & _lib.PATH_STATIC_PLAN and good.last_path() & _lib.PATH_FUSED_SINUS and good.last_path() & _lib.PATH_FUSED_BG, hex(good.last_path())
+        L.octpipe_debug_rtc_set_options(b"-DOCT_MXS_LUT_AHEAD=not_a_number")  # every instance is looked up under the current options: none can be built now
+        good.process_device(d.data_ptr()); good.synchronize()
+        assert not good.last_path() & (_lib.PATH_STATIC_PLAN | _lib.PATH_FUSED_SINUS) and good.last_path() & _lib.PATH_MIXED_RADIX, hex(good.last_path())
+        got = good.processed_host()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "the image of the fallback route left the handle without the correction"
+        good.process_device(d.data_ptr()); good.synchronize()  # ... and the handle stays on that route
+        assert np.array_equal(good.processed_host().view(np.uint32), want.view(np.uint32))
+        good.close()
+    finally:
+        L.octpipe_debug_rtc_set_options(None)
+
+
 def test_device_work_inside_a_callback_is_refused_not_deadlocked():
     """callbacks run inside hipLaunchHostFunc: HIP calls are not allowed there and a wait for the stream that runs the callback would
     never return.  The library refuses every device-touching entry point on such a thread with OCTPIPE_ERR_IN_CALLBACK (7) -- found
