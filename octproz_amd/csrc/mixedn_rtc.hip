@@ -6,7 +6,8 @@
 // Two caches, both for the life of the process (round 5):
 //   code objects  per (architecture, plan, container, resampling mode, output mode, options): compiled ONCE per process whatever the
 //                 number of devices, OUTSIDE the cache's lock -- the first thread that needs a variant compiles it, the others that
-//                 need the same one wait for exactly that variant, everything else goes on; octpipe_create / octpipe_set_params
+//                 need the same one wait for exactly that variant, everything else goes on (hiprtc itself runs one compilation at a time
+//                 since round 6: compileCode); octpipe_create / octpipe_set_params
 //                 start the variants a handle can reach next on a background thread (mixedn_rtc_prefetch), so that toggling a
 //                 setting in the middle of an acquisition finds its kernel compiled;
 //   modules       per (device, code object): hipModuleLoadData only.  A module whose launch reports a stale handle (the host
@@ -232,6 +233,10 @@ bool compileCode(const mxs::PlanDesc& d, int intype, int rs, int mode, const cha
 			return true;
 		}
 	}
+	// ONE compilation at a time in the process (round 6): the background thread and a launch that needs another variant now could until here run
+	// hiprtc -- comgr, LLVM with its process-wide option state -- side by side; a second compilation waits the ~1 s the first one takes instead
+	static std::mutex* compiling = new std::mutex;  // (never destroyed: the detached worker may outlive static destruction)
+	std::lock_guard<std::mutex> oneAtATime(*compiling);
 	rtcProgram prog = nullptr;
 	if (r.createProgram(&prog, src, "oct_mxs.hip", 5, texts, names) != 0) { *why = "hiprtcCreateProgram failed"; return false; }
 	const std::string archOpt = std::string("--offload-arch=") + arch;

@@ -261,7 +261,8 @@ def test_handles_created_concurrently_share_one_run_time_compilation():
     assert L.octpipe_debug_rtc_wait_idle(C.c_double(120.0)) == 0
     # the four variants just run had all been compiled ahead (each is one setting away from the one before): whatever the last set_params
     # queued on top of that is bounded the same way
-    assert probe.rtc_status()["compiled_in_process"] - n1 <= 12, (n1, probe.rtc_status())
+    # (round 6: one more neighbour per parameter set, the variant with the sinusoidal correction in its store)
+    assert probe.rtc_status()["compiled_in_process"] - n1 <= 16, (n1, probe.rtc_status())
     q.close(); probe.close(); o.close()
 
 
