@@ -179,7 +179,7 @@ def test_sinusoidal_correction_in_the_store_is_the_oracles_pass_on_the_kernels_o
 _SINUS_FUZZ = {"draws": 0, "fused": 0}
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SINUS_SEEDS", "300"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OCT_FUZZ_SINUS_SEEDS", "200"))))
 def test_sinusoidal_correction_in_the_store_random_shapes_and_settings(seed):
     """the same three-way identity on drawn configurations: every dedicated length with an in-store variant and five run-time compiled ones, B-scan widths from 2 to 700 (few, odd, prime, more
     pairs than persistent waves), 1-6 B-scans per buffer, every setting that composes with the correction, every block size of the work list.
