@@ -39,7 +39,7 @@ enum {
 	OCTPIPE_ROUTE_TINY_GRID = 1024,    /* the run-time compiled kernel and the general fused kernel on TWO persistent workgroups: every wave loops over many A-scans even of a small test buffer */
 	OCTPIPE_ROUTE_MIXEDN_SIMPLE_RADICES = 256, /* the generic plan from prime and power-of-two radices only (no 6, 10, 12, 14, 15, 20 butterflies) */
 	OCTPIPE_ROUTE_TEAM1664_ALWAYS = 16384, /* samplesPerLine = 1664: the two-wave team kernel for every resampling mode it has (by default linear / no resampling run on the one-wave kernel, faster there); A/Bs and the parity of the in-store correction, which always runs on the team kernel */
-	OCTPIPE_ROUTE_NO_FUSED_SINUS = 8192, /* sinusoidal scan correction always as the post pass (cu:1551-1554 as one gather pass), never inside the general fused kernel's image store (MODE_SINUS) */
+	OCTPIPE_ROUTE_NO_FUSED_SINUS = 8192, /* sinusoidal scan correction always as the post pass (cu:1551-1554 as one gather pass), never inside a transform kernel's image store (MODE_SINUS of the general, team, N = 1664 and run-time compiled kernels) */
 	OCTPIPE_ROUTE_FUSED_DISPLAY = 4096 /* display frames (one frame per view) written by the general fused kernel's image store (MODE_DISP) instead of by oct_display_frames_kernel.
 	                                      Opt-in: bit-identical frames, one launch per buffer instead of two, but not faster -- the store side costs the kernel what the extraction kernel
 	                                      cost (profiles/r5b..r5f_*_ab.txt) */
@@ -68,7 +68,7 @@ enum {
 	OCTPIPE_PATH_BLUESTEIN     = 128,
 	OCTPIPE_PATH_STATIC_PLAN   = 256, /* with MIXED_RADIX: the kernel compiled for this length (mixedn_static.h) instead of the run-time plan */
 	OCTPIPE_PATH_FUSED_DISPLAY = 512, /* the display frames (one frame per view) written by the image store of the fused kernel */
-	OCTPIPE_PATH_FUSED_SINUS   = 1024 /* sinusoidal scan correction inside the image store of the fused kernel (no scratch slot, no post pass) */
+	OCTPIPE_PATH_FUSED_SINUS   = 1024 /* sinusoidal scan correction inside the image store of the transform kernel (general, team, N = 1664 or run-time compiled; no scratch slot, no post pass) */
 };
 int octpipe_debug_last_path(const octpipe_t* h, unsigned* path);
 /* The same decision WITHOUT a device (csrc/route.h: derive_route_facts + choose_route, the pure functions octpipe_debug_create and
