@@ -35,10 +35,26 @@ def _native_built(request):
                 fd = int(request.config.stash[fault_handler_stderr_fd_key])
             except Exception:
                 fd = -1
-            ctypes.CDLL(abrt).abrt_install(fd)
+            lib = ctypes.CDLL(abrt)
+            lib.abrt_install(fd)
+            # ... with the name of the running test in front of it, and both in a file of their own next to the GPU box's other outputs
+            # (a log that a caller cuts to its tail keeps neither: round 6)
+            out = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(out):
+                lib.abrt_set_marker(os.path.join(out, "pytest_fatal_signal.txt").encode())
+            global _ABRT
+            _ABRT = lib
         except OSError:
             pass
     yield
+
+
+_ABRT = None
+
+
+def pytest_runtest_logstart(nodeid, location):
+    if _ABRT is not None:
+        _ABRT.abrt_set_test(nodeid.encode())
 
 
 def _has_gpu():

@@ -82,3 +82,22 @@ def test_unsupported_length_is_reported():
     rc = L.octpipe_create(C.byref(h), 0, C.byref(acq), C.byref(p), None, None)
     assert rc == 5 and not h.value
     assert b"samplesPerLine" in L.octpipe_last_error()
+
+
+def test_fatal_signal_helper_names_the_running_test(tmp_path):
+    """tests/native/abrt.c (test infrastructure): on SIGABRT / SIGSEGV the log and a marker file carry the name of the test that was running and the
+    C call stack of the faulting thread, in front of faulthandler's Python stacks"""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "libabrt.so")
+    if not os.path.exists(lib):
+        pytest.skip("tests/native/libabrt.so is built by __graft_entry__.build()")
+    marker = tmp_path / "fatal.txt"
+    for how, name in (("os.abort()", "SIGABRT"), ("ctypes.string_at(0)", "SIGSEGV")):
+        code = ("import ctypes, os, faulthandler; faulthandler.enable(); L = ctypes.CDLL(%r); L.abrt_install(2); L.abrt_set_marker(%r); "
+                "L.abrt_set_test(b'tests/test_x.py::test_y[3]'); %s" % (lib, str(marker).encode(), how))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        assert r.returncode != 0
+        assert ("fatal signal %s while running: tests/test_x.py::test_y[3]" % name) in r.stderr, r.stderr[-600:]
+        assert "C call stack of the faulting thread" in r.stderr and "Fatal Python error" in r.stderr
+        assert marker.read_text().startswith("%s while running: tests/test_x.py::test_y[3]" % name)
